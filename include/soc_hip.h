@@ -1,0 +1,112 @@
+/*
+ * soc_hip.h -- C ABI of libsoc_hip.so: the four hand-written gfx950 (MI355X / CDNA4) kernels of
+ * SOC's per-clip inference hot path (SURVEY.md section 8, rows a7 / a14 / a11+a16 / a19).
+ *
+ * Conventions (all entry points):
+ *   - plain C, no torch types; every pointer is a DEVICE pointer unless stated otherwise;
+ *   - inputs are borrowed, outputs are caller-allocated and fully overwritten;
+ *   - asynchronous on `stream` (a hipStream_t passed as void*; NULL = the null stream);
+ *   - stateless / thread-safe; forward only (the reference's backward is training-only);
+ *   - return 0 on success, a negative SOC_E* code otherwise (soc_hip_error_string()).
+ *
+ * Each function cites the reference interface it replaces (paths relative to the reference repo).
+ */
+#ifndef SOC_HIP_H
+#define SOC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SOC_HIP_ABI_VERSION 1
+
+#define SOC_OK 0
+#define SOC_EINVAL (-1)       /* null pointer / non-positive dimension */
+#define SOC_EUNSUPPORTED (-2) /* shape outside what the kernel is built for */
+#define SOC_ELAUNCH (-3)      /* hipGetLastError() != hipSuccess after the launch */
+#define SOC_EWORKSPACE (-4)   /* workspace too small */
+
+int soc_hip_abi_version(void);
+const char* soc_hip_error_string(int code);
+
+/*
+ * K2 -- multi-scale deformable attention, forward.
+ * Replaces MSDA.ms_deform_attn_forward (models/ops/src/vision.cpp:13-16,
+ * models/ops/src/ms_deform_attn.h:20-39, models/ops/src/cuda/ms_deform_attn_cuda.cu:20-80,
+ * kernel models/ops/src/cuda/ms_deform_im2col_cuda.cuh:237-299).
+ *   value          [N, S, M, D]        contiguous
+ *   spatial_shapes [L, 2] int64 (H_l, W_l), level_start_index [L] int64  (device memory)
+ *   sampling_loc   [N, Lq, M, L, P, 2] (x, y) normalised to [0,1]
+ *   attn_weight    [N, Lq, M, L, P]
+ *   out            [N, Lq, M*D]
+ * im2col_step of the reference only chunks the batch and has no numerical effect; it is not
+ * part of this ABI (the Python binding still validates it like the reference does).
+ */
+int soc_msda_fwd_f32(const float* value, const int64_t* spatial_shapes,
+                     const int64_t* level_start_index, const float* sampling_loc,
+                     const float* attn_weight, float* out, int N, int S, int M, int D, int L,
+                     int Lq, int P, void* stream);
+int soc_msda_fwd_f64(const double* value, const int64_t* spatial_shapes,
+                     const int64_t* level_start_index, const double* sampling_loc,
+                     const double* attn_weight, double* out, int N, int S, int M, int D, int L,
+                     int Lq, int P, void* stream);
+
+/*
+ * K1 -- 3-D (shifted) window attention with relative position bias, fused with the
+ * pad / cyclic-roll / window-partition / reverse / un-roll / crop index math.
+ * Replaces WindowAttention3D.forward between `qkv` and `proj`
+ * (models/video_swin_transformer.py:144-166) together with the data movement of
+ * SwinTransformerBlock3D.forward_part1 (:219-249), window_partition/window_reverse (:40-68) and
+ * compute_mask (:316-329).
+ *   qkv        [B, D, H, W, 3*C]  qkv Linear applied to the un-padded, LayerNorm-ed tokens
+ *   qkv_bias   [3*C]              what a zero (padded) token projects to
+ *   bias_table [(2*tab_d-1)*(2*tab_h-1)*(2*tab_w-1), n_heads]
+ *   out        [B, D, H, W, C]    attention output (before `proj`), token layout
+ * win_* / shift_* are the values AFTER the reference's clamping (get_window_size :71-84);
+ * tab_* is the module's nominal window (8,7,7) that sizes the bias table and defines the
+ * `relative_position_index[:N,:N]` slicing rule (:151).  head_dim = C / n_heads must be 32;
+ * win_d*win_h*win_w <= 400.  Shift mask value is -100 (:328), not -inf.
+ */
+int soc_win_attn3d_f32(const float* qkv, const float* qkv_bias, const float* bias_table,
+                       float* out, int B, int D, int H, int W, int C, int n_heads, int win_d,
+                       int win_h, int win_w, int shift_d, int shift_h, int shift_w, int tab_d,
+                       int tab_h, int tab_w, void* stream);
+
+/*
+ * K3 -- multi-head attention core softmax(q k^T / sqrt(d)) v on already-projected tensors,
+ * sequence-first layout.  Replaces the core of torch.nn.MultiheadAttention as used by
+ * MMF.forward (models/vla.py:20-23), VOC's Self/CrossAttentionLayer (models/voc.py:89-90,
+ * 146-149) and the decoder self-attention (models/deformable_transformer.py:333).
+ *   q [Lq, B, n_heads*head_dim], k / v [Lk, B, n_heads*head_dim]
+ *   key_pad_mask [B, Lk] uint8, non-zero = ignore key (may be NULL)
+ *   out [Lq, B, n_heads*head_dim]
+ * head_dim must be 32.  Long key sets with few queries are split over keys and need a
+ * workspace of soc_xattn_workspace_bytes() bytes (may be NULL when that returns 0).
+ */
+size_t soc_xattn_workspace_bytes(int Lq, int Lk, int B, int n_heads, int head_dim);
+int soc_xattn_f32(const float* q, const float* k, const float* v, const uint8_t* key_pad_mask,
+                  float* out, int Lq, int Lk, int B, int n_heads, int head_dim, void* workspace,
+                  size_t workspace_bytes, void* stream);
+
+/*
+ * K4 -- per-instance dynamic mask head (3 dynamic 1x1 conv layers over
+ * [C feature channels, rel_x, rel_y]) with the relative-coordinate generation fused in.
+ * Replaces SOC.dynamic_mask_with_coords + compute_locations + parse_dynamic_params +
+ * mask_heads_forward (models/soc.py:399-483, 486-509, 536-549) for batch size 1.
+ *   feats  [T, C, h, w]           FPN output (C = mask_kernels_dim = 8)
+ *   params [T*Q, (C+2)*8+8*8+8+8+8+1] controller output, order w0 w1 w2 b0 b1 b2, row-major [out][in]
+ *   refs   [T*Q, 2]               normalised (x, y) reference points, instance order (t, q)
+ *   out    [T*Q, h, w]
+ * rel = ref * (img_w, img_h) - (stride*x + stride/2, stride*y + stride/2).
+ */
+int soc_dyn_mask_f32(const float* feats, const float* params, const float* refs, float* out,
+                     int T, int Q, int C, int h, int w, float img_h, float img_w, int stride,
+                     void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SOC_HIP_H */

@@ -1,0 +1,60 @@
+"""ctypes binding of libsoc_hip.so (include/soc_hip.h).  Fails loudly: there is no CPU or
+PyTorch fallback for the four hot ops -- if the library is missing the product path raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  -- loads the process's single HIP runtime before our library
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libsoc_hip.so")
+
+EXPORTS = ("soc_hip_abi_version", "soc_hip_error_string", "soc_msda_fwd_f32", "soc_msda_fwd_f64",
+           "soc_win_attn3d_f32", "soc_xattn_workspace_bytes", "soc_xattn_f32", "soc_dyn_mask_f32")
+ABI_VERSION = 1
+
+_lib = None
+
+
+class SocHipError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SocHipError(
+            f"{LIB_PATH} is missing: build it with `python -m neurips2023_soc_amd.build` "
+            "(hipcc --offload-arch=gfx950).  The SOC hot path has no CPU/PyTorch fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name in EXPORTS:
+        if not hasattr(lib, name):
+            raise SocHipError(f"libsoc_hip.so does not export {name}")
+    p, i, f = C.c_void_p, C.c_int, C.c_float
+    lib.soc_hip_abi_version.restype = i
+    lib.soc_hip_error_string.restype = C.c_char_p
+    lib.soc_hip_error_string.argtypes = [i]
+    for fn in (lib.soc_msda_fwd_f32, lib.soc_msda_fwd_f64):
+        fn.restype = i
+        fn.argtypes = [p, p, p, p, p, p, i, i, i, i, i, i, i, p]
+    lib.soc_win_attn3d_f32.restype = i
+    lib.soc_win_attn3d_f32.argtypes = [p, p, p, p] + [i] * 15 + [p]
+    lib.soc_xattn_workspace_bytes.restype = C.c_size_t
+    lib.soc_xattn_workspace_bytes.argtypes = [i] * 5
+    lib.soc_xattn_f32.restype = i
+    lib.soc_xattn_f32.argtypes = [p, p, p, p, p, i, i, i, i, i, p, C.c_size_t, p]
+    lib.soc_dyn_mask_f32.restype = i
+    lib.soc_dyn_mask_f32.argtypes = [p, p, p, p, i, i, i, i, i, f, f, i, p]
+    if lib.soc_hip_abi_version() != ABI_VERSION:
+        raise SocHipError("libsoc_hip.so ABI version mismatch; rebuild it")
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        msg = load().soc_hip_error_string(code).decode()
+        raise SocHipError(f"{what}: {msg} (code {code})")

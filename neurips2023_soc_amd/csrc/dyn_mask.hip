@@ -1,0 +1,86 @@
+// K4: per-instance dynamic mask head for gfx950.
+//
+// For instance (t, q) and pixel (y, x) of the 1/4-scale map:
+//   in  = [feats[t, 0..C-1, y, x], rx, ry],  (rx, ry) = ref*(img_w, img_h) - (stride*x + stride/2, ...)
+//   out = W2 . relu(W1 . relu(W0 . in + b0) + b1) + b2
+// The reference materialises a [1, T*Q*(C+2), h, w] tensor (92 MB at config) and runs three
+// grouped convolutions (models/soc.py:439-443, 465-483); here each thread keeps one pixel's C
+// features in registers and walks the Q instances of its frame, so HBM traffic is the
+// algorithmic minimum: feats read once, [T*Q, h, w] written once (13 MB at config).
+// The 169 parameters of an instance are wave-uniform: they are read through the scalar cache
+// (s_load) and used as SGPR operands of the FMAs.
+#include "soc_common.h"
+
+namespace {
+
+constexpr int CF = 8;    // feature channels (mask_kernels_dim)
+constexpr int CH = 8;    // hidden channels (dynamic_mask_channels)
+constexpr int NPARAM = (CF + 2) * CH + CH * CH + CH + CH + CH + 1;  // 169
+
+__global__ __launch_bounds__(256) void dyn_mask_kernel(
+    const float* __restrict__ feats, const float* __restrict__ params,
+    const float* __restrict__ refs, float* __restrict__ out, int Q, int hw, int w, float img_h,
+    float img_w, int stride) {
+    const int t = blockIdx.y;
+    const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = pix < hw;
+    const int pc = live ? pix : hw - 1;
+    const int y = pc / w, x = pc - y * w;
+    const float px = (float)(stride * x + stride / 2);
+    const float py = (float)(stride * y + stride / 2);
+
+    float f[CF];
+    const float* fp = feats + (long)t * CF * hw + pc;
+#pragma unroll
+    for (int c = 0; c < CF; ++c) f[c] = fp[(long)c * hw];
+
+    for (int q = 0; q < Q; ++q) {
+        const int inst = t * Q + q;
+        const float* __restrict__ P = params + (long)inst * NPARAM;  // wave-uniform
+        const float rx = refs[inst * 2] * img_w - px;
+        const float ry = refs[inst * 2 + 1] * img_h - py;
+        float h0[CH], h1[CH];
+        const float* W0 = P;
+        const float* W1 = P + (CF + 2) * CH;
+        const float* W2 = W1 + CH * CH;
+        const float* B0 = W2 + CH;
+        const float* B1 = B0 + CH;
+        const float* B2 = B1 + CH;
+#pragma unroll
+        for (int o = 0; o < CH; ++o) {
+            float a = B0[o];
+#pragma unroll
+            for (int c = 0; c < CF; ++c) a += W0[o * (CF + 2) + c] * f[c];
+            a += W0[o * (CF + 2) + CF] * rx;
+            a += W0[o * (CF + 2) + CF + 1] * ry;
+            h0[o] = fmaxf(a, 0.f);
+        }
+#pragma unroll
+        for (int o = 0; o < CH; ++o) {
+            float a = B1[o];
+#pragma unroll
+            for (int c = 0; c < CH; ++c) a += W1[o * CH + c] * h0[c];
+            h1[o] = fmaxf(a, 0.f);
+        }
+        float r = B2[0];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) r += W2[c] * h1[c];
+        if (live) out[(long)inst * hw + pix] = r;
+    }
+}
+
+}  // namespace
+
+extern "C" int soc_dyn_mask_f32(const float* feats, const float* params, const float* refs,
+                                float* out, int T, int Q, int C, int h, int w, float img_h,
+                                float img_w, int stride, void* stream) {
+    if (!feats || !params || !refs || !out || T < 0 || Q < 0 || h <= 0 || w <= 0 || stride <= 0)
+        return SOC_EINVAL;
+    if (C != CF) return SOC_EUNSUPPORTED;
+    if (T == 0 || Q == 0) return SOC_OK;
+    const int hw = h * w;
+    dim3 grid(soc_ceil_div(hw, 256), T);
+    hipLaunchKernelGGL(dyn_mask_kernel, grid, dim3(256), 0, (hipStream_t)stream, feats, params,
+                       refs, out, Q, hw, w, img_h, img_w, stride);
+    return soc_check_launch();
+}

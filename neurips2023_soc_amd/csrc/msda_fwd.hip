@@ -1,0 +1,170 @@
+// K2: multi-scale deformable attention forward for gfx950.
+//
+// out[n,q,m,:] = sum_{l,p} w[n,q,m,l,p] * bilinear(value_l[n,:,m,:], loc[n,q,m,l,p])
+// Sampling rules restate the reference CUDA kernel (models/ops/src/cuda/ms_deform_im2col_cuda.cuh
+// :33-84 bilinear taps with per-tap zero padding, :237-299 per-output loop): pixel coordinates
+// h = y*H - 0.5, w = x*W - 0.5; a point contributes only when -1 < h < H and -1 < w < W.
+//
+// MI355X mapping (HBM/L2-bound gather):
+//   * fast path D == 32, f32: 8 lanes x float4 cover one (query, head) row of 32 channels, so a
+//     64-lane wave covers 8 heads of one query and every tap is one fully used 128-B line;
+//   * the block -> frame mapping is round-robin (frame = block % N), which is how the dispatcher
+//     deals blocks to the 8 XCDs: with N = 8 frames each XCD's private 4 MiB L2 only ever sees
+//     one frame's 4.9 MB value map (speed only, never correctness);
+//   * the generic path (any D, f64) is one thread per output scalar.
+#include "soc_common.h"
+
+namespace {
+
+template <typename T>
+__device__ __forceinline__ T ldg(const T* p) { return *p; }
+
+// ---------------------------------------------------------------------------------------------
+// fast path: D = 32, float, one lane = 4 channels
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void msda_fwd_d32_kernel(
+    const float* __restrict__ value, const int64_t* __restrict__ shapes,
+    const int64_t* __restrict__ lsi, const float* __restrict__ loc,
+    const float* __restrict__ attw, float* __restrict__ out, int N, int S, int M, int L, int Lq,
+    int P, int groups_per_frame /* = Lq*M */, int blocks_per_frame) {
+    const int n = blockIdx.x % N;        // XCD-friendly: blocks b, b+8, ... share an XCD
+    const int chunk = blockIdx.x / N;
+    const int sub = threadIdx.x >> 3;    // 32 (query, head) groups per block
+    const int c4 = threadIdx.x & 7;      // which float4 of the 32 channels
+    const int g = chunk * 32 + sub;      // (q, m) flat index inside frame n
+    if (g >= groups_per_frame) return;
+    const int m = g % M;
+    const long gi = (long)n * groups_per_frame + g;          // (n, q, m) flat
+    const float* lp = loc + gi * (long)(L * P * 2);
+    const float* wp = attw + gi * (long)(L * P);
+    const float* vbase = value + (long)n * S * M * 32 + m * 32 + c4 * 4;
+    const int rstride = M * 32;  // floats between consecutive spatial positions
+
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int l = 0; l < L; ++l) {
+        const int Hl = (int)shapes[2 * l], Wl = (int)shapes[2 * l + 1];
+        const float* vl = vbase + (long)lsi[l] * rstride;
+        for (int p = 0; p < P; ++p) {
+            const float2 xy = *reinterpret_cast<const float2*>(lp + (l * P + p) * 2);
+            const float wgt = wp[l * P + p];
+            const float him = xy.y * Hl - 0.5f;
+            const float wim = xy.x * Wl - 0.5f;
+            if (him > -1.f && wim > -1.f && him < Hl && wim < Wl) {
+                const int h0 = (int)floorf(him), w0 = (int)floorf(wim);
+                const float lh = him - h0, lw = wim - w0;
+                const float hh = 1.f - lh, hw = 1.f - lw;
+                const bool h0ok = h0 >= 0, h1ok = h0 + 1 <= Hl - 1;
+                const bool w0ok = w0 >= 0, w1ok = w0 + 1 <= Wl - 1;
+                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                const float* r0 = vl + ((long)h0 * Wl + w0) * rstride;
+                const float* r1 = r0 + (long)Wl * rstride;
+                const float4 v1 = (h0ok && w0ok) ? *reinterpret_cast<const float4*>(r0) : z;
+                const float4 v2 = (h0ok && w1ok) ? *reinterpret_cast<const float4*>(r0 + rstride) : z;
+                const float4 v3 = (h1ok && w0ok) ? *reinterpret_cast<const float4*>(r1) : z;
+                const float4 v4 = (h1ok && w1ok) ? *reinterpret_cast<const float4*>(r1 + rstride) : z;
+                const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+                acc.x += (w1 * v1.x + w2 * v2.x + w3 * v3.x + w4 * v4.x) * wgt;
+                acc.y += (w1 * v1.y + w2 * v2.y + w3 * v3.y + w4 * v4.y) * wgt;
+                acc.z += (w1 * v1.z + w2 * v2.z + w3 * v3.z + w4 * v4.z) * wgt;
+                acc.w += (w1 * v1.w + w2 * v2.w + w3 * v3.w + w4 * v4.w) * wgt;
+            }
+        }
+    }
+    *reinterpret_cast<float4*>(out + gi * 32 + c4 * 4) = acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// generic path: one thread per output scalar (any D, float or double)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void msda_fwd_generic_kernel(
+    const T* __restrict__ value, const int64_t* __restrict__ shapes,
+    const int64_t* __restrict__ lsi, const T* __restrict__ loc, const T* __restrict__ attw,
+    T* __restrict__ out, long total, int S, int M, int D, int L, int Lq, int P) {
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % D);
+        const long gi = idx / D;  // (n, q, m)
+        const int m = (int)(gi % M);
+        const long n = gi / ((long)M * Lq);
+        const T* lp = loc + gi * (long)(L * P * 2);
+        const T* wp = attw + gi * (long)(L * P);
+        const long rstride = (long)M * D;
+        const T* vb = value + n * S * rstride + (long)m * D + c;
+        T acc = 0;
+        for (int l = 0; l < L; ++l) {
+            const int Hl = (int)shapes[2 * l], Wl = (int)shapes[2 * l + 1];
+            const T* vl = vb + (long)lsi[l] * rstride;
+            for (int p = 0; p < P; ++p) {
+                const T x = lp[(l * P + p) * 2], y = lp[(l * P + p) * 2 + 1];
+                const T wgt = wp[l * P + p];
+                const T him = y * Hl - (T)0.5, wim = x * Wl - (T)0.5;
+                if (him > -1 && wim > -1 && him < Hl && wim < Wl) {
+                    const int h0 = (int)floor(him), w0 = (int)floor(wim);
+                    const T lh = him - h0, lw = wim - w0, hh = 1 - lh, hw = 1 - lw;
+                    T v1 = 0, v2 = 0, v3 = 0, v4 = 0;
+                    const T* r0 = vl + ((long)h0 * Wl + w0) * rstride;
+                    if (h0 >= 0 && w0 >= 0) v1 = r0[0];
+                    if (h0 >= 0 && w0 + 1 <= Wl - 1) v2 = r0[rstride];
+                    if (h0 + 1 <= Hl - 1 && w0 >= 0) v3 = r0[(long)Wl * rstride];
+                    if (h0 + 1 <= Hl - 1 && w0 + 1 <= Wl - 1) v4 = r0[(long)Wl * rstride + rstride];
+                    acc += (hh * hw * v1 + hh * lw * v2 + lh * hw * v3 + lh * lw * v4) * wgt;
+                }
+            }
+        }
+        out[idx] = acc;
+    }
+}
+
+template <typename T>
+int launch_generic(const T* value, const int64_t* shapes, const int64_t* lsi, const T* loc,
+                   const T* attw, T* out, int N, int S, int M, int D, int L, int Lq, int P,
+                   hipStream_t st) {
+    const long total = (long)N * Lq * M * D;
+    if (total == 0) return SOC_OK;
+    const int blocks = (int)((total + 255) / 256 > 65536 ? 65536 : (total + 255) / 256);
+    hipLaunchKernelGGL(msda_fwd_generic_kernel<T>, dim3(blocks), dim3(256), 0, st, value, shapes,
+                       lsi, loc, attw, out, total, S, M, D, L, Lq, P);
+    return soc_check_launch();
+}
+
+bool bad_args(const void* a, const void* b, const void* c, const void* d, const void* e,
+              const void* f, int N, int S, int M, int D, int L, int Lq, int P) {
+    return !a || !b || !c || !d || !e || !f || N < 0 || S <= 0 || M <= 0 || D <= 0 || L <= 0 ||
+           Lq < 0 || P <= 0;
+}
+
+}  // namespace
+
+extern "C" int soc_msda_fwd_f32(const float* value, const int64_t* spatial_shapes,
+                                const int64_t* level_start_index, const float* sampling_loc,
+                                const float* attn_weight, float* out, int N, int S, int M, int D,
+                                int L, int Lq, int P, void* stream) {
+    if (N == 0 || Lq == 0) return (N < 0 || Lq < 0) ? SOC_EINVAL : SOC_OK;
+    if (bad_args(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, out, N, S,
+                 M, D, L, Lq, P))
+        return SOC_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (D == 32) {
+        const int gpf = Lq * M;
+        const int bpf = soc_ceil_div(gpf, 32);
+        hipLaunchKernelGGL(msda_fwd_d32_kernel, dim3(bpf * N), dim3(256), 0, st, value,
+                           spatial_shapes, level_start_index, sampling_loc, attn_weight, out, N,
+                           S, M, L, Lq, P, gpf, bpf);
+        return soc_check_launch();
+    }
+    return launch_generic<float>(value, spatial_shapes, level_start_index, sampling_loc,
+                                 attn_weight, out, N, S, M, D, L, Lq, P, st);
+}
+
+extern "C" int soc_msda_fwd_f64(const double* value, const int64_t* spatial_shapes,
+                                const int64_t* level_start_index, const double* sampling_loc,
+                                const double* attn_weight, double* out, int N, int S, int M,
+                                int D, int L, int Lq, int P, void* stream) {
+    if (N == 0 || Lq == 0) return (N < 0 || Lq < 0) ? SOC_EINVAL : SOC_OK;
+    if (bad_args(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, out, N, S,
+                 M, D, L, Lq, P))
+        return SOC_EINVAL;
+    return launch_generic<double>(value, spatial_shapes, level_start_index, sampling_loc,
+                                  attn_weight, out, N, S, M, D, L, Lq, P, (hipStream_t)stream);
+}

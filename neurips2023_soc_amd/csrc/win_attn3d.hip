@@ -1,0 +1,266 @@
+// K1: 3-D shifted-window attention for gfx950.
+//
+// One workgroup = one (window, head) pair (optionally one slice of its query tiles).
+//   stage 0  every thread derives, for the window's N <= 400 tokens, where the token lives in
+//            the un-padded token-major qkv tensor after pad + cyclic roll (or that it is a
+//            zero-padded token, whose q/k/v are the qkv bias), its shift-mask region id and its
+//            relative-position code e(i) -- no mask / index tensors are ever read from HBM;
+//   stage 1  K and V of the head (N x 32 f32 each) and the head's bias-table column are staged
+//            in LDS (row stride 36 floats: conflict-free V reads, 2-way K reads);
+//   stage 2  each wave owns 16-query tiles.  S^T = K . Q^T is computed with
+//            v_mfma_f32_16x16x4_f32 (exact f32, SURVEY 8d: fp32 only on this path) for ALL key
+//            tiles at once -- 25 tiles x 4 accumulators = 100 VGPRs hold the whole 16 x 400
+//            score block, so the softmax is the exact two-pass form (no online rescale) and is
+//            done in registers: bias via LDS lookup table[e(i) - e(j) + E0], shift mask -100,
+//            row max / sum by two cross-lane xor-shuffles (the C layout of S^T keeps one query
+//            per lane column);
+//   stage 3  O^T = V^T . P^T reuses the score accumulators directly as the MFMA B operand (the
+//            key order inside each 4-wide k-step is permuted consistently on the V side), so P
+//            never leaves registers; the result is scaled by 1/rowsum and scattered back to the
+//            token-major output with the inverse roll, dropping padded tokens.
+// MFMA work per (window, head): 2 * 25 * 25 * 8 = 10 000 instructions of 2048 FLOP.
+#include "soc_common.h"
+#include <math.h>
+
+namespace {
+
+constexpr int HD = 32;          // head dim (all Video-Swin variants)
+constexpr int RS = 36;          // LDS row stride in floats for K and V
+constexpr int NT_MAX = 25;      // key / query tiles of 16 -> up to 400 tokens
+constexpr int NP_MAX = NT_MAX * 16;
+constexpr int THREADS = 512;    // 8 waves, 2 per SIMD
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct WinParams {
+    int B, D, H, W, C, nH;
+    int wd, wh, ww;      // clamped window
+    int sd, sh, sw;      // clamped shift
+    int td, th, tw;      // nominal (table) window
+    int Dp, Hp, Wp;      // padded volume
+    int nwd, nwh, nww;   // windows per axis
+    int N;               // tokens per window
+    int NT;              // tiles of 16
+    int qsplit;          // blocks per (window, head)
+    int table_len;
+    int shifted;
+};
+
+__device__ __forceinline__ int region1d(int c, int P, int w, int s) {
+    // reference compute_mask slices: [0,P-w) -> 0, [P-w,P-s) -> 1, [P-s,P) -> 2; shift 0 -> uniform
+    if (s == 0) return 0;
+    return c < P - w ? 0 : (c < P - s ? 1 : 2);
+}
+
+__global__ __launch_bounds__(THREADS, 2) void win_attn3d_kernel(
+    const float* __restrict__ qkv, const float* __restrict__ qkv_bias,
+    const float* __restrict__ table, float* __restrict__ out, const WinParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* Ks = reinterpret_cast<float*>(smem_raw);           // [NP][RS]
+    float* Vs = Ks + NP_MAX * RS;                              // [NP][RS]
+    float* Tb = Vs + NP_MAX * RS;                              // [table_len]
+    int* src = reinterpret_cast<int*>(Tb + ((p.table_len + 3) & ~3));  // [NP] token offset or <0
+    int* code = src + NP_MAX;                                  // [NP] e(i) | region << 16
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bid = blockIdx.x;
+    const int qpart = bid % p.qsplit; bid /= p.qsplit;
+    const int head = bid % p.nH; bid /= p.nH;
+    const int wx = bid % p.nww; bid /= p.nww;
+    const int wy = bid % p.nwh; bid /= p.nwh;
+    const int wz = bid % p.nwd; bid /= p.nwd;
+    const int b = bid;
+    const int NP = p.NT * 16;
+    const int C3 = 3 * p.C;
+
+    // ---- stage 0: token metadata ------------------------------------------------------------
+    for (int i = tid; i < NP; i += THREADS) {
+        int s = -2, cd = 0;
+        if (i < p.N) {
+            const int dz = i / (p.wh * p.ww), r = i - dz * (p.wh * p.ww);
+            const int dy = r / p.ww, dx = r - dy * p.ww;
+            const int zs = wz * p.wd + dz, ys = wy * p.wh + dy, xs = wx * p.ww + dx;  // shifted frame
+            int z = zs + p.sd; if (z >= p.Dp) z -= p.Dp;
+            int y = ys + p.sh; if (y >= p.Hp) y -= p.Hp;
+            int x = xs + p.sw; if (x >= p.Wp) x -= p.Wp;
+            s = (z < p.D && y < p.H && x < p.W) ? ((b * p.D + z) * p.H + y) * p.W + x : -1;
+            // relative_position_index[:N,:N]: token i is decoded with the NOMINAL window dims
+            const int tz = i / (p.th * p.tw), tr = i - tz * (p.th * p.tw);
+            const int ty = tr / p.tw, tx = tr - ty * p.tw;
+            const int e = (tz * (2 * p.th - 1) + ty) * (2 * p.tw - 1) + tx;
+            const int reg = (region1d(zs, p.Dp, p.wd, p.sd) * 3 + region1d(ys, p.Hp, p.wh, p.sh)) * 3 +
+                            region1d(xs, p.Wp, p.ww, p.sw);
+            cd = e | (reg << 16);
+        }
+        src[i] = s;
+        code[i] = cd;
+    }
+    for (int i = tid; i < p.table_len; i += THREADS) Tb[i] = table[(long)i * p.nH + head];
+    __syncthreads();
+
+    // ---- stage 1: K, V -> LDS (float4 per thread: 8 threads per token row) --------------------
+    {
+        const int part = tid & 7;
+        const float4 kbias = *reinterpret_cast<const float4*>(qkv_bias + p.C + head * HD + part * 4);
+        const float4 vbias = *reinterpret_cast<const float4*>(qkv_bias + 2 * p.C + head * HD + part * 4);
+        for (int i = tid >> 3; i < NP; i += THREADS / 8) {
+            const int s = src[i];
+            float4 kv, vv;
+            if (s >= 0) {
+                const float* row = qkv + (long)s * C3 + head * HD + part * 4;
+                kv = *reinterpret_cast<const float4*>(row + p.C);
+                vv = *reinterpret_cast<const float4*>(row + 2 * p.C);
+            } else if (s == -1) {
+                kv = kbias; vv = vbias;
+            } else {
+                kv = make_float4(0.f, 0.f, 0.f, 0.f); vv = kv;
+            }
+            *reinterpret_cast<float4*>(Ks + i * RS + part * 4) = kv;
+            *reinterpret_cast<float4*>(Vs + i * RS + part * 4) = vv;
+        }
+    }
+    __syncthreads();
+
+    // ---- stage 2/3: per 16-query tile ---------------------------------------------------------
+    const int r = lane & 15;   // MFMA column: query inside the tile (also A-operand row)
+    const int g = lane >> 4;   // MFMA k index / C row group
+    const float scale = 0.17677669529663687f;  // 32^-0.5
+    const int E0 = ((p.td - 1) * (2 * p.th - 1) + (p.th - 1)) * (2 * p.tw - 1) + (p.tw - 1);
+    const int nwaves_total = (THREADS / 64) * p.qsplit;
+
+    for (int qt = qpart * (THREADS / 64) + wave; qt < p.NT; qt += nwaves_total) {
+        const int qtok = qt * 16 + r;
+        const int qsrc = src[qtok];
+        // Q^T fragment (B operand): lane (r,g) holds q[token r][dim 4*kk+g] * scale
+        float qf[8];
+        if (qsrc >= 0) {
+            const float* qrow = qkv + (long)qsrc * C3 + head * HD + g;
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) qf[kk] = qrow[4 * kk] * scale;
+        } else if (qsrc == -1) {
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) qf[kk] = qkv_bias[head * HD + 4 * kk + g] * scale;
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) qf[kk] = 0.f;
+        }
+        const int qcode = code[qtok];
+        const int qe = (qcode & 0xFFFF) + E0;
+        const int qreg = qcode >> 16;
+
+        // S^T tiles: acc[t][i] = S[query r][key 16t + 4g + i]
+        f32x4 acc[NT_MAX];
+#pragma unroll
+        for (int t = 0; t < NT_MAX; ++t) {
+            acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (t < p.NT) {
+                const float* kp = Ks + (16 * t + r) * RS + g;
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk)
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kp[4 * kk], qf[kk], acc[t], 0, 0, 0);
+            }
+        }
+        // bias + mask + row max
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < NT_MAX; ++t) {
+            if (t < p.NT) {
+                const int4 kc = *reinterpret_cast<const int4*>(code + 16 * t + 4 * g);
+                const int kcs[4] = {kc.x, kc.y, kc.z, kc.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int key = 16 * t + 4 * g + i;
+                    float s = acc[t][i] + Tb[qe - (kcs[i] & 0xFFFF)];
+                    if (p.shifted && (kcs[i] >> 16) != qreg) s += -100.0f;
+                    if (key >= p.N) s = -INFINITY;
+                    acc[t][i] = s;
+                    mx = fmaxf(mx, s);
+                }
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT_MAX; ++t) {
+            if (t < p.NT) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float e = __expf(acc[t][i] - mx);
+                    acc[t][i] = e;
+                    sum += e;
+                }
+            }
+        }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+
+        // O^T = V^T . P^T : A = V[key 16t+4g+s][dim 16*dt + r], B = acc[t][s]
+        f32x4 o0 = (f32x4){0.f, 0.f, 0.f, 0.f}, o1 = o0;
+#pragma unroll
+        for (int t = 0; t < NT_MAX; ++t) {
+            if (t < p.NT) {
+                const float* vp = Vs + (16 * t + 4 * g) * RS + r;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[s * RS], acc[t][s], o0, 0, 0, 0);
+                    o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[s * RS + 16], acc[t][s], o1, 0, 0, 0);
+                }
+            }
+        }
+        // C layout of O^T: column = query r, rows = dims 4g..4g+3 (o0) and 16+4g.. (o1)
+        if (qsrc >= 0) {
+            const float inv = 1.f / sum;
+            float* orow = out + (long)qsrc * p.C + head * HD + 4 * g;
+            *reinterpret_cast<float4*>(orow) = make_float4(o0[0] * inv, o0[1] * inv, o0[2] * inv, o0[3] * inv);
+            *reinterpret_cast<float4*>(orow + 16) = make_float4(o1[0] * inv, o1[1] * inv, o1[2] * inv, o1[3] * inv);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int soc_win_attn3d_f32(const float* qkv, const float* qkv_bias, const float* bias_table,
+                                  float* out, int B, int D, int H, int W, int C, int n_heads,
+                                  int win_d, int win_h, int win_w, int shift_d, int shift_h,
+                                  int shift_w, int tab_d, int tab_h, int tab_w, void* stream) {
+    if (!qkv || !qkv_bias || !bias_table || !out) return SOC_EINVAL;
+    if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0 || n_heads <= 0) return SOC_EINVAL;
+    if (win_d <= 0 || win_h <= 0 || win_w <= 0 || tab_d <= 0 || tab_h <= 0 || tab_w <= 0) return SOC_EINVAL;
+    if (shift_d < 0 || shift_h < 0 || shift_w < 0 || shift_d >= win_d || shift_h >= win_h || shift_w >= win_w)
+        return SOC_EINVAL;
+    if (C != n_heads * HD) return SOC_EUNSUPPORTED;
+    WinParams p;
+    p.B = B; p.D = D; p.H = H; p.W = W; p.C = C; p.nH = n_heads;
+    p.wd = win_d; p.wh = win_h; p.ww = win_w;
+    p.sd = shift_d; p.sh = shift_h; p.sw = shift_w;
+    p.td = tab_d; p.th = tab_h; p.tw = tab_w;
+    p.N = win_d * win_h * win_w;
+    if (p.N > NP_MAX || p.N > tab_d * tab_h * tab_w) return SOC_EUNSUPPORTED;
+    p.NT = (p.N + 15) / 16;
+    p.nwd = (D + win_d - 1) / win_d; p.nwh = (H + win_h - 1) / win_h; p.nww = (W + win_w - 1) / win_w;
+    p.Dp = p.nwd * win_d; p.Hp = p.nwh * win_h; p.Wp = p.nww * win_w;
+    p.table_len = (2 * tab_d - 1) * (2 * tab_h - 1) * (2 * tab_w - 1);
+    p.shifted = (shift_d | shift_h | shift_w) != 0;
+    if ((long)B * D * H * W * 3 * C >= (1L << 31)) return SOC_EUNSUPPORTED;  // int token offsets
+    const long pairs = (long)B * p.nwd * p.nwh * p.nww * n_heads;
+    // few (window, head) pairs (late stages): split the query tiles over more workgroups so the
+    // 256 CUs stay busy; every split re-stages K/V, so only split while the grid is small.
+    p.qsplit = 1;
+    while (pairs * p.qsplit < 512 && p.qsplit < 4 && (p.NT + (THREADS / 64) * p.qsplit - 1) / ((THREADS / 64) * p.qsplit) > 1)
+        p.qsplit *= 2;
+    const size_t lds = (size_t)(2 * NP_MAX * RS + ((p.table_len + 3) & ~3)) * sizeof(float) + 2 * NP_MAX * sizeof(int);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(win_attn3d_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return SOC_ELAUNCH;
+        attr_set = true;
+    }
+    if (lds > 160 * 1024) return SOC_EUNSUPPORTED;
+    hipLaunchKernelGGL(win_attn3d_kernel, dim3((unsigned)(pairs * p.qsplit)), dim3(THREADS), lds,
+                       (hipStream_t)stream, qkv, qkv_bias, bias_table, out, p);
+    return soc_check_launch();
+}

@@ -1,0 +1,182 @@
+"""Deformable transformer (3 enc + 3 dec layers) around K2/K3
+(reference models/deformable_transformer.py:25-445, two_stage=False, box refinement on)."""
+from __future__ import annotations
+
+import copy
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .attention import HipMultiheadAttention
+from .ms_deform_attn import MSDeformAttn
+from .nested_tensor import inverse_sigmoid
+
+
+class DeformableTransformerEncoderLayer(nn.Module):
+    def __init__(self, d_model, d_ffn, n_levels, n_heads, n_points):
+        super().__init__()
+        self.self_attn = MSDeformAttn(d_model, n_levels, n_heads, n_points)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.linear1 = nn.Linear(d_model, d_ffn)
+        self.linear2 = nn.Linear(d_ffn, d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+
+    def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None):
+        a, _, _ = self.self_attn(src + pos, reference_points, src, spatial_shapes, level_start_index, padding_mask)
+        src = self.norm1(src + a)
+        return self.norm2(src + self.linear2(F.relu(self.linear1(src))))
+
+
+class DeformableTransformerEncoder(nn.Module):
+    def __init__(self, layer, num_layers):
+        super().__init__()
+        self.layers = nn.ModuleList([copy.deepcopy(layer) for _ in range(num_layers)])
+        self.num_layers = num_layers
+
+    @staticmethod
+    def get_reference_points(spatial_shapes, valid_ratios, device):
+        """Pixel-centre grid of every level, normalised by the valid extent (reference :273-285)."""
+        pts = []
+        for lvl, (H_, W_) in enumerate(spatial_shapes.tolist()):
+            ys = torch.linspace(0.5, H_ - 0.5, H_, dtype=torch.float32, device=device)
+            xs = torch.linspace(0.5, W_ - 0.5, W_, dtype=torch.float32, device=device)
+            gy, gx = torch.meshgrid(ys, xs, indexing="ij")
+            gy = gy.reshape(-1)[None] / (valid_ratios[:, None, lvl, 1] * H_)
+            gx = gx.reshape(-1)[None] / (valid_ratios[:, None, lvl, 0] * W_)
+            pts.append(torch.stack((gx, gy), -1))
+        return torch.cat(pts, 1)[:, :, None] * valid_ratios[:, None]
+
+    def forward(self, src, spatial_shapes, level_start_index, valid_ratios, pos=None, padding_mask=None):
+        ref = self.get_reference_points(spatial_shapes, valid_ratios, src.device)
+        for layer in self.layers:
+            src = layer(src, pos, ref, spatial_shapes, level_start_index, padding_mask)
+        return src
+
+
+class DeformableTransformerDecoderLayer(nn.Module):
+    def __init__(self, d_model, d_ffn, n_levels, n_heads, n_points):
+        super().__init__()
+        self.cross_attn = MSDeformAttn(d_model, n_levels, n_heads, n_points)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.self_attn = HipMultiheadAttention(d_model, n_heads)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.linear1 = nn.Linear(d_model, d_ffn)
+        self.linear2 = nn.Linear(d_ffn, d_model)
+        self.norm3 = nn.LayerNorm(d_model)
+
+    def forward(self, tgt, query_pos, reference_points, src, spatial_shapes, level_start_index, src_padding_mask=None):
+        qk = (tgt + query_pos).transpose(0, 1)  # sequence-first for the attention core
+        tgt = self.norm2(tgt + self.self_attn(qk, qk, tgt.transpose(0, 1)).transpose(0, 1))
+        c, loc, w = self.cross_attn(tgt + query_pos, reference_points, src, spatial_shapes,
+                                    level_start_index, src_padding_mask)
+        tgt = self.norm1(tgt + c)
+        tgt = self.norm3(tgt + self.linear2(F.relu(self.linear1(tgt))))
+        return tgt, loc, w
+
+
+class DeformableTransformerDecoder(nn.Module):
+    def __init__(self, layer, num_layers, return_intermediate=False):
+        super().__init__()
+        self.layers = nn.ModuleList([copy.deepcopy(layer) for _ in range(num_layers)])
+        self.num_layers, self.return_intermediate = num_layers, return_intermediate
+        self.bbox_embed = None  # set by SOC to share the box heads (reference models/soc.py:95)
+        self.class_embed = None
+
+    def forward(self, tgt, reference_points, src, spatial_shapes, level_start_index, valid_ratios,
+                query_pos=None, src_padding_mask=None):
+        out = tgt
+        inter, inter_refs = [], []
+        for lid, layer in enumerate(self.layers):
+            if reference_points.shape[-1] == 4:
+                ref_in = reference_points[:, :, None] * torch.cat([valid_ratios, valid_ratios], -1)[:, None]
+            else:
+                ref_in = reference_points[:, :, None] * valid_ratios[:, None]
+            out, _, _ = layer(out, query_pos, ref_in, src, spatial_shapes, level_start_index, src_padding_mask)
+            # (the reference's top-30 sample bookkeeping :383-389 feeds nothing in SOC.forward)
+            if self.bbox_embed is not None:
+                delta = self.bbox_embed[lid](out)
+                if reference_points.shape[-1] == 4:
+                    new_ref = (delta + inverse_sigmoid(reference_points)).sigmoid()
+                else:
+                    xy = delta[..., :2] + inverse_sigmoid(reference_points)
+                    new_ref = torch.cat([xy, delta[..., 2:]], -1).sigmoid()
+                reference_points = new_ref.detach()
+            if self.return_intermediate:
+                inter.append(out)
+                inter_refs.append(reference_points)
+        if self.return_intermediate:
+            return torch.stack(inter), torch.stack(inter_refs), None
+        return out, reference_points, None
+
+
+class DeformableTransformer(nn.Module):
+    def __init__(self, d_model=256, nhead=8, num_encoder_layers=6, num_decoder_layers=6,
+                 dim_feedforward=1024, dropout=0.1, activation="relu", return_intermediate_dec=False,
+                 num_feature_levels=4, dec_n_points=4, enc_n_points=4, two_stage=False,
+                 two_stage_num_proposals=300):
+        super().__init__()
+        if two_stage:
+            raise NotImplementedError("two_stage=True is not on SOC's path (all shipped configs use False)")
+        if activation != "relu":
+            raise NotImplementedError("SOC builds the transformer with relu (reference :438)")
+        self.d_model, self.nhead, self.num_feature_level = d_model, nhead, num_feature_levels
+        enc = DeformableTransformerEncoderLayer(d_model, dim_feedforward, num_feature_levels, nhead, enc_n_points)
+        self.encoder = DeformableTransformerEncoder(enc, num_encoder_layers)
+        dec = DeformableTransformerDecoderLayer(d_model, dim_feedforward, num_feature_levels, nhead, dec_n_points)
+        self.decoder = DeformableTransformerDecoder(dec, num_decoder_layers, return_intermediate_dec)
+        self.level_embed = nn.Parameter(torch.empty(num_feature_levels, d_model))
+        self.reference_points = nn.Linear(d_model, 2)
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+        for m in self.modules():
+            if isinstance(m, MSDeformAttn):
+                m._reset_parameters()
+        nn.init.zeros_(self.reference_points.bias)
+        nn.init.normal_(self.level_embed)
+
+    @staticmethod
+    def get_valid_ratio(mask):
+        _, H, W = mask.shape
+        vh = (~mask[:, :, 0]).sum(1).float() / H
+        vw = (~mask[:, 0, :]).sum(1).float() / W
+        return torch.stack([vw, vh], -1)
+
+    def forward(self, srcs, tgt, masks, pos_embeds, query_embed=None):
+        """srcs/masks/pos per level '(b t) c h w'; tgt [b,t,q,c]; query_embed [q,c]
+        -> hs [l,(b t),q,c], memory maps, init_ref [(b t),q,2], inter_refs [l,(b t),q,4], None, None, None"""
+        flat, mflat, pflat, shapes = [], [], [], []
+        for lvl, (s, m, pe) in enumerate(zip(srcs, masks, pos_embeds)):
+            shapes.append(tuple(s.shape[-2:]))
+            flat.append(s.flatten(2).transpose(1, 2))
+            mflat.append(m.flatten(1))
+            pflat.append(pe.flatten(2).transpose(1, 2) + self.level_embed[lvl].view(1, 1, -1))
+        src, mask, pos = torch.cat(flat, 1), torch.cat(mflat, 1), torch.cat(pflat, 1)
+        spatial_shapes = torch.as_tensor(shapes, dtype=torch.long, device=src.device)
+        level_start = torch.cat((spatial_shapes.new_zeros(1), spatial_shapes.prod(1).cumsum(0)[:-1]))
+        ratios = torch.stack([self.get_valid_ratio(m) for m in masks], 1)
+
+        memory = self.encoder(src, spatial_shapes, level_start, ratios, pos, mask)
+
+        b, t, q, c = tgt.shape
+        tgt = tgt.reshape(b * t, q, c)
+        qpos = query_embed.unsqueeze(0).expand(b * t, -1, -1)
+        ref = self.reference_points(qpos).sigmoid()
+        hs, inter_refs, inter_samples = self.decoder(tgt, ref, memory, spatial_shapes, level_start, ratios, qpos, mask)
+
+        maps, at = [], 0
+        for (h, w) in shapes[:self.num_feature_level - 1]:
+            maps.append(memory[:, at:at + h * w].reshape(b * t, h, w, c).permute(0, 3, 1, 2).contiguous())
+            at += h * w
+        return hs, maps, ref, inter_refs, None, None, inter_samples
+
+
+def build_deforamble_transformer(args):  # (sic) name kept from the reference :430
+    return DeformableTransformer(
+        d_model=args["d_model"], nhead=args["nheads"], num_encoder_layers=args["enc_layers"],
+        num_decoder_layers=args["dec_layers"], dim_feedforward=args["dim_feedforward"],
+        dropout=args["dropout"], activation="relu", return_intermediate_dec=True,
+        num_feature_levels=args["num_feature_levels"], dec_n_points=args["dec_n_points"],
+        enc_n_points=args["enc_n_points"], two_stage=args["two_stage"],
+        two_stage_num_proposals=args["num_queries"])

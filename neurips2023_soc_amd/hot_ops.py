@@ -1,0 +1,140 @@
+"""Host-side entry points of the four HIP hot ops (torch tensors in, torch tensors out).
+
+Every function requires CUDA(=HIP) tensors and calls straight into libsoc_hip.so through the C
+ABI of include/soc_hip.h on torch's current stream.  There is deliberately no fallback: CPU
+tensors or a missing library raise.
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib
+
+Tensor = torch.Tensor
+
+
+def _need_gpu(*ts: Tensor) -> None:
+    for x in ts:
+        if x is not None and not x.is_cuda:
+            raise _lib.SocHipError(
+                "SOC hot ops run only on an MI355X (HIP) device tensor; got a CPU tensor. "
+                "There is no CPU fallback in the product path.")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _f32c(x: Tensor) -> Tensor:
+    if x.dtype != torch.float32:
+        raise _lib.SocHipError(f"expected float32, got {x.dtype}")
+    return x if x.is_contiguous() else x.contiguous()
+
+
+def msda_forward(value: Tensor, spatial_shapes: Tensor, level_start_index: Tensor,
+                 sampling_loc: Tensor, attn_weight: Tensor) -> Tensor:
+    """K2.  value [N,S,M,D], shapes [L,2] i64, lsi [L] i64, loc [N,Lq,M,L,P,2], w [N,Lq,M,L,P]
+    -> [N,Lq,M*D].  float32 or float64 (reference AT_DISPATCH_FLOATING_TYPES)."""
+    _need_gpu(value, spatial_shapes, level_start_index, sampling_loc, attn_weight)
+    lib = _lib.load()
+    for name, x in (("value", value), ("spatial_shapes", spatial_shapes),
+                    ("level_start_index", level_start_index), ("sampling_loc", sampling_loc),
+                    ("attn_weight", attn_weight)):
+        if not x.is_contiguous():  # reference ms_deform_attn_cuda.cu:28-32
+            raise RuntimeError(f"{name} tensor has to be contiguous")
+    if spatial_shapes.dtype != torch.int64 or level_start_index.dtype != torch.int64:
+        raise RuntimeError("spatial_shapes / level_start_index must be int64")
+    N, S, M, D = value.shape
+    _, Lq, _, L, P, _ = sampling_loc.shape
+    out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
+    if value.dtype == torch.float32:
+        fn = lib.soc_msda_fwd_f32
+    elif value.dtype == torch.float64:
+        fn = lib.soc_msda_fwd_f64
+    else:
+        raise RuntimeError("ms_deform_attn_forward supports float32/float64 only")
+    if sampling_loc.dtype != value.dtype or attn_weight.dtype != value.dtype:
+        raise RuntimeError("value / sampling_loc / attn_weight dtypes differ")
+    code = fn(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+              sampling_loc.data_ptr(), attn_weight.data_ptr(), out.data_ptr(), N, S, M, D, L, Lq, P,
+              _stream())
+    _lib.check(code, "soc_msda_fwd")
+    return out
+
+
+def clamp_window(size: Sequence[int], window: Sequence[int], shift: Sequence[int]):
+    """get_window_size of the reference (models/video_swin_transformer.py:71-84)."""
+    w, s = list(window), list(shift)
+    for i in range(3):
+        if size[i] <= window[i]:
+            w[i], s[i] = size[i], 0
+    return tuple(w), tuple(s)
+
+
+def window_attention3d(qkv: Tensor, qkv_bias: Tensor, bias_table: Tensor, n_heads: int,
+                       window: Sequence[int], shift: Sequence[int]) -> Tensor:
+    """K1.  qkv [B,D,H,W,3C] (token layout, un-padded) -> attention output [B,D,H,W,C].
+    ``window``/``shift`` are the module's nominal values; clamping happens here."""
+    _need_gpu(qkv, qkv_bias, bias_table)
+    lib = _lib.load()
+    qkv, qkv_bias, bias_table = _f32c(qkv), _f32c(qkv_bias), _f32c(bias_table)
+    B, D, H, W, C3 = qkv.shape
+    C = C3 // 3
+    win, sh = clamp_window((D, H, W), window, shift)
+    out = torch.empty((B, D, H, W, C), dtype=torch.float32, device=qkv.device)
+    code = lib.soc_win_attn3d_f32(qkv.data_ptr(), qkv_bias.data_ptr(), bias_table.data_ptr(),
+                                  out.data_ptr(), B, D, H, W, C, n_heads, *win, *sh, *window, _stream())
+    _lib.check(code, "soc_win_attn3d_f32")
+    return out
+
+
+_ws_cache = {}
+
+
+def mha_core(q: Tensor, k: Tensor, v: Tensor, n_heads: int,
+             key_padding_mask: Optional[Tensor] = None) -> Tensor:
+    """K3.  q [Lq,B,E], k/v [Lk,B,E] projected, key_padding_mask [B,Lk] bool -> [Lq,B,E]."""
+    _need_gpu(q, k, v, key_padding_mask)
+    lib = _lib.load()
+    q, k, v = _f32c(q), _f32c(k), _f32c(v)
+    Lq, B, E = q.shape
+    Lk = k.shape[0]
+    hd = E // n_heads
+    out = torch.empty_like(q)
+    kpm_ptr = None
+    if key_padding_mask is not None:
+        kpm = key_padding_mask.to(torch.uint8).contiguous()
+        kpm_ptr = kpm.data_ptr()
+    need = lib.soc_xattn_workspace_bytes(Lq, Lk, B, n_heads, hd)
+    ws_ptr = None
+    if need:
+        key = (q.device.index, torch.cuda.current_stream().cuda_stream)
+        ws = _ws_cache.get(key)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(need, dtype=torch.uint8, device=q.device)
+            _ws_cache[key] = ws
+        ws_ptr = ws.data_ptr()
+    code = lib.soc_xattn_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), kpm_ptr, out.data_ptr(),
+                             Lq, Lk, B, n_heads, hd, ws_ptr, need, _stream())
+    _lib.check(code, "soc_xattn_f32")
+    return out
+
+
+def dynamic_mask(feats: Tensor, params: Tensor, refs: Tensor, img_hw: Sequence[float],
+                 stride: int = 4) -> Tensor:
+    """K4.  feats [T,C,h,w], params [T*Q,169], refs [T*Q,2], img_hw=(H_img,W_img) -> [T*Q,h,w]."""
+    _need_gpu(feats, params, refs)
+    lib = _lib.load()
+    feats, params, refs = _f32c(feats), _f32c(params), _f32c(refs)
+    T, Cm, h, w = feats.shape
+    TQ = params.shape[0]
+    Q = TQ // max(T, 1)
+    if params.shape[1] != (Cm + 2) * 8 + 64 + 8 + 8 + 8 + 1:
+        raise _lib.SocHipError(f"unexpected dynamic-parameter count {params.shape[1]}")
+    out = torch.empty((TQ, h, w), dtype=torch.float32, device=feats.device)
+    code = lib.soc_dyn_mask_f32(feats.data_ptr(), params.data_ptr(), refs.data_ptr(), out.data_ptr(),
+                                T, Q, Cm, h, w, float(img_hw[0]), float(img_hw[1]), stride, _stream())
+    _lib.check(code, "soc_dyn_mask_f32")
+    return out

@@ -1,0 +1,224 @@
+"""Video-Swin backbone on MI355X (reference models/video_swin_transformer.py).
+
+MI355X-first data flow per block: LayerNorm -> ONE qkv GEMM over the un-padded token-major map
+-> HIP kernel K1 (soc_win_attn3d_f32) which does pad / cyclic roll / window partition / relative
+position bias / shift mask / softmax / PV / window reverse / un-roll / crop in a single launch
+-> proj GEMM -> residual -> LayerNorm -> MLP.  The reference materialises padded, rolled and
+partitioned copies plus a [nW*nH, 392, 392] score tensor per block (551 MB at stage 0); none of
+that exists here.  Module / parameter names follow the reference so its checkpoints load
+(`backbone.0.body.{patch_embed,layers.N.blocks.M.*,downsamples.N.*}`).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Sequence
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import hot_ops
+from .nested_tensor import NestedTensor
+from .position_encoding import PositionEmbeddingSine2D
+
+SWIN_CONFIGS = {  # reference :733-779
+    "video-swin-t": dict(embed_dim=96, depths=(2, 2, 6, 2), num_heads=(3, 6, 12, 24)),
+    "video-swin-s": dict(embed_dim=96, depths=(2, 2, 18, 2), num_heads=(3, 6, 12, 24)),
+    "video-swin-b": dict(embed_dim=128, depths=(2, 2, 18, 2), num_heads=(4, 8, 16, 32)),
+}
+WINDOW = (8, 7, 7)
+PATCH = (1, 4, 4)
+
+
+def relative_position_index(window: Sequence[int]) -> torch.Tensor:
+    """Buffer kept for checkpoint compatibility (reference :113-128); K1 derives it implicitly."""
+    axes = [torch.arange(w) for w in window]
+    grid = torch.stack(torch.meshgrid(*axes, indexing="ij")).flatten(1)
+    rel = (grid[:, :, None] - grid[:, None, :]).permute(1, 2, 0).contiguous()
+    for a in range(3):
+        rel[:, :, a] += window[a] - 1
+    rel[:, :, 0] *= (2 * window[1] - 1) * (2 * window[2] - 1)
+    rel[:, :, 1] *= 2 * window[2] - 1
+    return rel.sum(-1)
+
+
+class WindowAttention3D(nn.Module):
+    """Parameter holder + launcher of K1.  forward takes the *token-major* normed map."""
+
+    def __init__(self, dim: int, window_size: Sequence[int], num_heads: int):
+        super().__init__()
+        self.dim, self.window_size, self.num_heads = dim, tuple(window_size), num_heads
+        n_rel = (2 * window_size[0] - 1) * (2 * window_size[1] - 1) * (2 * window_size[2] - 1)
+        self.relative_position_bias_table = nn.Parameter(torch.zeros(n_rel, num_heads))
+        self.register_buffer("relative_position_index", relative_position_index(window_size))
+        self.qkv = nn.Linear(dim, dim * 3, bias=True)
+        self.proj = nn.Linear(dim, dim)
+        nn.init.trunc_normal_(self.relative_position_bias_table, std=0.02)
+
+    def forward(self, x: torch.Tensor, shift: Sequence[int]) -> torch.Tensor:
+        """x [B,D,H,W,C] (after norm1, un-padded) -> attention branch output [B,D,H,W,C]."""
+        qkv = self.qkv(x)
+        attn = hot_ops.window_attention3d(qkv, self.qkv.bias, self.relative_position_bias_table,
+                                          self.num_heads, self.window_size, shift)
+        return self.proj(attn)
+
+
+class Mlp(nn.Module):
+    def __init__(self, dim: int, hidden: int):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.fc2 = nn.Linear(hidden, dim)
+
+    def forward(self, x):
+        return self.fc2(F.gelu(self.fc1(x)))
+
+
+class SwinTransformerBlock3D(nn.Module):
+    def __init__(self, dim: int, num_heads: int, window_size, shift_size, mlp_ratio: float = 4.0):
+        super().__init__()
+        self.shift_size = tuple(shift_size)
+        self.norm1 = nn.LayerNorm(dim)
+        self.attn = WindowAttention3D(dim, window_size, num_heads)
+        self.norm2 = nn.LayerNorm(dim)
+        self.mlp = Mlp(dim, int(dim * mlp_ratio))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        x = x + self.attn(self.norm1(x), self.shift_size)
+        return x + self.mlp(self.norm2(x))
+
+
+class BasicLayer(nn.Module):
+    """One stage; ``downsample`` lives outside (reference VideoSwinTransformerBackbone :663-670)."""
+
+    def __init__(self, dim: int, depth: int, num_heads: int, window_size):
+        super().__init__()
+        shift = tuple(w // 2 for w in window_size)
+        self.blocks = nn.ModuleList([
+            SwinTransformerBlock3D(dim, num_heads, window_size, (0, 0, 0) if i % 2 == 0 else shift)
+            for i in range(depth)])
+        self.downsample = None
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:  # [B,D,H,W,C] token-major throughout
+        for blk in self.blocks:
+            x = blk(x)
+        return x
+
+
+class PatchMerging(nn.Module):
+    def __init__(self, dim: int):
+        super().__init__()
+        self.reduction = nn.Linear(4 * dim, 2 * dim, bias=False)
+        self.norm = nn.LayerNorm(4 * dim)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        H, W = x.shape[2], x.shape[3]
+        if H % 2 or W % 2:
+            x = F.pad(x, (0, 0, 0, W % 2, 0, H % 2))
+        x = torch.cat([x[:, :, 0::2, 0::2], x[:, :, 1::2, 0::2], x[:, :, 0::2, 1::2], x[:, :, 1::2, 1::2]], -1)
+        return self.reduction(self.norm(x))
+
+
+class PatchEmbed3D(nn.Module):
+    def __init__(self, embed_dim: int):
+        super().__init__()
+        self.proj = nn.Conv3d(3, embed_dim, kernel_size=PATCH, stride=PATCH)
+        self.norm = nn.LayerNorm(embed_dim)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """[B,3,T,H,W] -> token-major [B,T,H/4,W/4,C]; the (1,4,4) conv is a per-frame 4x4/4 conv."""
+        B, _, T, H, W = x.shape
+        if W % 4:
+            x = F.pad(x, (0, 4 - W % 4))
+        if H % 4:
+            x = F.pad(x, (0, 0, 0, 4 - H % 4))
+        f = x.transpose(1, 2).reshape(B * T, 3, x.shape[-2], x.shape[-1])
+        f = F.conv2d(f, self.proj.weight[:, :, 0], self.proj.bias, stride=4)
+        f = f.permute(0, 2, 3, 1).reshape(B, T, f.shape[-2], f.shape[-1], -1)
+        return self.norm(f)
+
+
+class VideoSwinTransformerBackbone(nn.Module):
+    def __init__(self, name: str):
+        super().__init__()
+        cfg = SWIN_CONFIGS[name]
+        d = cfg["embed_dim"]
+        self.patch_embed = PatchEmbed3D(d)
+        self.layers = nn.ModuleList([BasicLayer(d * 2 ** i, cfg["depths"][i], cfg["num_heads"][i], WINDOW)
+                                     for i in range(4)])
+        self.downsamples = nn.ModuleList([PatchMerging(d * 2 ** i) for i in range(3)] + [None])
+        self.layer_output_channels = [d * 2 ** i for i in range(4)]
+
+    def forward(self, samples: torch.Tensor, num_frames: int) -> Dict[str, torch.Tensor]:
+        n, c, h, w = samples.shape
+        x = samples.view(n // num_frames, num_frames, c, h, w).transpose(1, 2)
+        x = self.patch_embed(x)
+        out = {}
+        for i, layer in enumerate(self.layers):
+            x = layer(x)
+            B, T, hh, ww, C = x.shape
+            out[str(i)] = x.permute(0, 1, 4, 2, 3).reshape(B * T, C, hh, ww)  # '(b t) c h w'
+            if self.downsamples[i] is not None:
+                x = self.downsamples[i](x)
+        return out
+
+
+def resize_pad_mask(mask: torch.Tensor, size) -> torch.Tensor:
+    return F.interpolate(mask[None].float(), size=size).to(torch.bool)[0]
+
+
+class Backbone(nn.Module):
+    """reference BackboneBase/Backbone :701-730"""
+
+    def __init__(self, name: str):
+        super().__init__()
+        self.body = VideoSwinTransformerBackbone(name)
+        self.strides = [4, 8, 16, 32]
+        self.num_channels = list(self.body.layer_output_channels)
+
+    def forward(self, tensor_list: NestedTensor, num_frames: int) -> Dict[str, NestedTensor]:
+        xs = self.body(tensor_list.tensors, num_frames)
+        return {k: NestedTensor(x, resize_pad_mask(tensor_list.mask, x.shape[-2:])) for k, x in xs.items()}
+
+
+class Joiner(nn.Sequential):
+    """backbone[0] = Backbone, backbone[1] = position embedding (reference :781-800).
+
+    Like the reference it rewrites ``samples`` in place to the '(b t)' layout."""
+
+    def __init__(self, backbone: Backbone, position_embedding: nn.Module):
+        super().__init__(backbone, position_embedding)
+        self.strides, self.num_channels = backbone.strides, backbone.num_channels
+
+    def forward(self, tensor_list: NestedTensor):
+        t, b = tensor_list.tensors.shape[:2]
+        tensor_list.tensors = tensor_list.tensors.transpose(0, 1).flatten(0, 1)
+        tensor_list.mask = tensor_list.mask.transpose(0, 1).flatten(0, 1)
+        xs = self[0](tensor_list, num_frames=t)
+        out: List[NestedTensor] = [xs[k] for k in sorted(xs)]
+        pos = [self[1](x).to(x.tensors.dtype) for x in out]
+        return out, pos
+
+
+def build_video_swin_backbone(args) -> Joiner:
+    pe = PositionEmbeddingSine2D(args.DeformTransformer["d_model"] // 2, normalize=True)
+    model = Joiner(Backbone(args.backbone), pe)
+    path = getattr(args, "backbone_pretrained_path", None)
+    if isinstance(path, str):
+        load_kinetics_weights(model[0].body, path)
+    return model
+
+
+def load_kinetics_weights(body: VideoSwinTransformerBackbone, path: str) -> None:
+    """Kinetics-400 Video-Swin checkpoint -> backbone (reference :651-661): strip 'backbone.',
+    sum the patch-embed kernel over its temporal taps, move layers.N.downsample.* to downsamples.N.*"""
+    sd = torch.load(path, map_location="cpu")["state_dict"]
+    sd = {k[9:]: v for k, v in sd.items() if k.startswith("backbone.")}
+    sd["patch_embed.proj.weight"] = sd["patch_embed.proj.weight"].sum(dim=2, keepdim=True)
+    remap = {}
+    for k, v in sd.items():
+        parts = k.split(".")
+        if len(parts) > 3 and parts[0] == "layers" and parts[2] == "downsample":
+            k = ".".join(["downsamples", parts[1]] + parts[3:])
+        if k.startswith("norm."):
+            continue
+        remap[k] = v
+    body.load_state_dict(remap, strict=False)

@@ -1,0 +1,190 @@
+"""-m gpu: parity of the four HIP kernels (through the C ABI) against the CPU oracle and the
+reference-generated golden fixtures.  Tolerances are absolute unless stated; fp32 everywhere."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import soc_oracle as O
+from tests.golden_utils import t
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from neurips2023_soc_amd import hot_ops
+    return hot_ops
+
+
+def dev(x):
+    return x.cuda() if torch.is_tensor(x) else t(x).cuda()
+
+
+def maxdiff(a, b):
+    return float((a.detach().cpu().double() - torch.as_tensor(b).double()).abs().max())
+
+
+# ------------------------------------------------------------------ K2 MSDA
+@pytest.mark.parametrize("tag,tol", [("a64", 1e-12), ("a32", 1e-7), ("b", 2e-5)])
+def test_msda_reference_recipe(ops, golden, tag, tol):
+    """models/ops/test.py recipe (double + float) and a model-shaped case with out-of-range points."""
+    g = golden("msda_cases.npz")
+    dt = torch.float64 if tag == "a64" else torch.float32
+    out = ops.msda_forward(dev(g[f"{tag}_value"]).to(dt), dev(g[f"{tag}_shapes"]), dev(g[f"{tag}_lsi"]),
+                           dev(g[f"{tag}_loc"]).to(dt), dev(g[f"{tag}_w"]).to(dt))
+    assert out.dtype == dt
+    assert maxdiff(out, g[f"{tag}_out"]) < tol
+    # the reference's own float tolerance (models/ops/test.py:56)
+    assert torch.allclose(out.cpu(), t(g[f"{tag}_out"]).to(dt), rtol=1e-2, atol=1e-3)
+
+
+def test_msda_model_capture(ops, golden):
+    g = golden("tiny_kernels.npz")
+    out = ops.msda_forward(dev(g["msda_dec_value"]), dev(g["msda_dec_shapes"]), dev(g["msda_dec_lsi"]),
+                           dev(g["msda_dec_loc"]), dev(g["msda_dec_w"]))
+    assert maxdiff(out, g["msda_dec_out"]) < 2e-5
+
+
+@pytest.mark.parametrize("N,Lq,D", [(8, 4820, 32), (3, 77, 32), (2, 5, 16), (1, 0, 32)])
+def test_msda_vs_oracle_seeded(ops, N, Lq, D):
+    """Config-sized encoder call (N=8, Lq=S=4820) plus ragged / empty shapes."""
+    g = torch.Generator().manual_seed(N * 1000 + Lq)
+    shapes = torch.tensor([[45, 80], [23, 40], [12, 20], [6, 10]]) if Lq == 4820 else torch.tensor([[9, 7], [5, 4], [3, 2], [1, 1]])
+    lsi = torch.cat((shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]))
+    S, M, L, P = int(shapes.prod(1).sum()), 8, 4, 4
+    value = torch.randn(N, S, M, D, generator=g)
+    loc = torch.rand(N, Lq, M, L, P, 2, generator=g) * 1.3 - 0.15
+    w = torch.softmax(torch.randn(N, Lq, M, L * P, generator=g), -1).view(N, Lq, M, L, P)
+    out = ops.msda_forward(dev(value), dev(shapes), dev(lsi), dev(loc), dev(w))
+    assert out.shape == (N, Lq, M * D)
+    if Lq:
+        ref = O.msda_core(value, shapes, lsi, loc, w)
+        assert maxdiff(out, ref) < 3e-5
+
+
+def test_msda_rejects_bad_input(ops):
+    shapes = torch.tensor([[2, 2]]).cuda()
+    lsi = torch.tensor([0]).cuda()
+    v = torch.randn(1, 4, 8, 32).cuda()
+    loc = torch.rand(1, 3, 8, 1, 4, 2).cuda()
+    w = torch.rand(1, 3, 8, 1, 4).cuda()
+    with pytest.raises(RuntimeError):
+        ops.msda_forward(v.transpose(1, 2), shapes, lsi, loc, w)  # non-contiguous
+    with pytest.raises(RuntimeError):
+        ops.msda_forward(v.cpu(), shapes, lsi, loc, w)  # CPU tensor: no fallback
+
+
+# ------------------------------------------------------------------ K1 window attention
+def _win_case(ops, B, D, H, W, nH, shift, seed):
+    g = torch.Generator().manual_seed(seed)
+    C = nH * 32
+    qkv = torch.randn(B, D, H, W, 3 * C, generator=g)
+    bias = torch.randn(3 * C, generator=g) * 0.5
+    table = torch.randn(15 * 13 * 13, nH, generator=g) * 0.5
+    ref = O.window_attention_core(qkv, bias, table, nH, O.WINDOW, shift)
+    out = ops.window_attention3d(dev(qkv), dev(bias), dev(table), nH, O.WINDOW, shift)
+    return maxdiff(out, ref), float(ref.abs().max())
+
+
+@pytest.mark.parametrize("D,H,W,nH,shift", [
+    (8, 14, 21, 3, (0, 0, 0)),      # exact windows, no shift
+    (8, 14, 21, 3, (4, 3, 3)),      # T=8: shift clamps to (0,3,3)
+    (8, 12, 20, 6, (4, 3, 3)),      # stage-3 geometry: padded tokens + shift mask
+    (8, 12, 20, 2, (0, 0, 0)),      # padded tokens attend in un-shifted blocks
+    (3, 8, 10, 4, (4, 3, 3)),       # clamped temporal window (N=147), bias index slicing
+    (10, 9, 8, 2, (4, 3, 3)),       # T>8: temporal shift 4, D padded to 16
+    (10, 9, 8, 2, (0, 0, 0)),
+    (2, 5, 6, 1, (4, 3, 3)),        # every axis clamped: single window, no shift at all
+])
+def test_window_attention_vs_oracle(ops, D, H, W, nH, shift):
+    d, scale = _win_case(ops, 1, D, H, W, nH, shift, seed=D * 100 + H)
+    assert d < 2e-5 * max(scale, 1.0), (d, scale)
+
+
+def test_window_attention_batch_gt1(ops):
+    d, scale = _win_case(ops, 2, 8, 9, 15, 2, (4, 3, 3), seed=5)
+    assert d < 2e-5 * max(scale, 1.0)
+
+
+@pytest.mark.parametrize("blk,shift", [("s3b0", (0, 0, 0)), ("s3b1", (4, 3, 3))])
+def test_window_attention_golden_block(ops, golden, synthetic_sd, blk, shift):
+    """Reference SwinTransformerBlock3D.forward_part1 capture (stage 3 of the tiny run)."""
+    g = golden("tiny_kernels.npz")
+    sd = synthetic_sd
+    p = f"backbone.0.body.layers.3.blocks.{blk[-1]}"
+    x = t(g[blk + "_in"])
+    qkv = O.linear(sd, p + ".attn.qkv", O.layer_norm(sd, p + ".norm1", x))
+    a = ops.window_attention3d(dev(qkv), dev(sd[p + ".attn.qkv.bias"]),
+                               dev(sd[p + ".attn.relative_position_bias_table"]), 24, O.WINDOW, shift)
+    y = O.linear(sd, p + ".attn.proj", a.cpu())
+    assert maxdiff(y, g[blk + "_out"]) < 5e-5 * max(1.0, float(np.abs(g[blk + "_out"]).max()))
+
+
+def test_window_attention_full_config_stage0(ops):
+    """BASELINE config size (stage 0: 8x90x160, 3 heads, shifted): oracle on a few windows' worth
+    is too slow for the whole map, so check the size-independent property instead: rows of the
+    softmax sum to one => with V == 1 the output is exactly 1 for every real token."""
+    g = torch.Generator().manual_seed(1)
+    qkv = torch.randn(1, 8, 90, 160, 288, generator=g)
+    qkv[..., 192:] = 1.0
+    bias = torch.zeros(288)
+    bias[192:] = 1.0
+    table = torch.randn(2535, 3, generator=g)
+    out = ops.window_attention3d(dev(qkv), dev(bias), dev(table), 3, O.WINDOW, (4, 3, 3))
+    assert out.shape == (1, 8, 90, 160, 96)
+    assert float((out.cpu() - 1.0).abs().max()) < 1e-5
+
+
+# ------------------------------------------------------------------ K3 attention core
+@pytest.mark.parametrize("Lq,Lk,B,pad", [(240, 10, 1, 0), (60, 13, 1, 4), (10, 240, 1, 0),
+                                         (10, 1920, 1, 0), (160, 160, 1, 0), (20, 160, 1, 0),
+                                         (20, 20, 8, 0), (1, 1, 1, 0), (700, 17, 2, 5)])
+def test_mha_core_vs_oracle(ops, Lq, Lk, B, pad):
+    g = torch.Generator().manual_seed(Lq * 7 + Lk)
+    q, k, v = (torch.randn(L, B, 256, generator=g) for L in (Lq, Lk, Lk))
+    kpm = None
+    if pad:
+        kpm = torch.zeros(B, Lk, dtype=torch.bool)
+        kpm[:, Lk - pad:] = True
+    ref = O.mha_core(q, k, v, 8, kpm)
+    out = ops.mha_core(dev(q), dev(k), dev(v), 8, dev(kpm) if kpm is not None else None)
+    assert maxdiff(out, ref) < 2e-5
+
+
+@pytest.mark.parametrize("tag,mod", [("vlf2", "vlf"), ("vlf3", "vlf"), ("lvf2", "lvf")])
+def test_mmf_golden(ops, golden, synthetic_sd, tag, mod):
+    """Reference MMF.forward capture: projections on CPU, attention core on the GPU."""
+    import torch.nn.functional as F
+    g = golden("tiny_kernels.npz")
+    sd = synthetic_sd
+    p = mod + ".multihead_attn"
+    tgt, mem, pos, kpm = t(g[tag + "_tgt"]), t(g[tag + "_mem"]), t(g[tag + "_pos"]), t(g[tag + "_kpm"])
+    w, b = sd[p + ".in_proj_weight"], sd[p + ".in_proj_bias"]
+    q = F.linear(tgt, w[:256], b[:256])
+    k = F.linear(mem + pos, w[256:512], b[256:512])
+    v = F.linear(mem, w[512:], b[512:])
+    o = ops.mha_core(dev(q), dev(k), dev(v), 8, dev(kpm)).cpu()
+    out = tgt * F.linear(o, sd[p + ".out_proj.weight"], sd[p + ".out_proj.bias"])
+    assert maxdiff(out, g[tag + "_out"]) < 1e-5 * max(1.0, float(np.abs(g[tag + "_out"]).max()))
+
+
+# ------------------------------------------------------------------ K4 dynamic mask head
+def test_dynamic_mask_golden(ops, golden):
+    g = golden("tiny_kernels.npz")
+    out = ops.dynamic_mask(dev(g["dyn_feats"][0]), dev(g["dyn_params"][0]), dev(g["dyn_refs"][0]),
+                           tuple(int(v) for v in g["dyn_img_hw"]))
+    ref = g["dyn_out"][0]
+    assert maxdiff(out, ref) < 2e-6 * float(np.abs(ref).max()) + 1e-5
+    assert np.array_equal(out.cpu().numpy() > 0, ref > 0)
+
+
+@pytest.mark.parametrize("T,Q,h,w", [(8, 20, 90, 160), (1, 1, 3, 5), (2, 7, 33, 17)])
+def test_dynamic_mask_vs_oracle(ops, T, Q, h, w):
+    g = torch.Generator().manual_seed(T * 10 + Q)
+    feats = torch.randn(T, 8, h, w, generator=g)
+    params = torch.randn(T * Q, 169, generator=g) * 0.2
+    refs = torch.rand(T * Q, 2, generator=g)
+    ref = O.dynamic_mask_core(feats, params, refs, (4 * h, 4 * w))
+    out = ops.dynamic_mask(dev(feats), dev(params), dev(refs), (4 * h, 4 * w))
+    assert maxdiff(out, ref) < 1e-5 * max(1.0, float(ref.abs().max()))
