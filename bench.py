@@ -1,0 +1,172 @@
+#!/usr/bin/env python
+"""Headline benchmark: clips/s of SOC's per-clip inference hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+A step = one eval forward of Video-Swin-T SOC on one synthetic clip [T=8,3,360,640] (random
+deterministic weights, pre-tokenised 10-token expression) + query selection, i.e. the body of
+the reference's inference loop (infer_refytb.py:206-227).  Inputs are resident in HBM before the
+timed region.  Clips shard over ranks (weak scaling: K clips per rank, no data-path collective);
+the single result all_gather sits inside the timed region.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32-input MFMA peak
+PEAK_HBM_GBS = 8000.0          # HBM3E spec
+WEIGHT_SEED = 2023
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--backbone", default="video-swin-t")
+    ap.add_argument("--frames", type=int, default=8)
+    ap.add_argument("--height", type=int, default=360)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    assert torch.cuda.is_available(), "bench.py measures the HIP path; it needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import neurips2023_soc_amd as S
+    from neurips2023_soc_amd import clip_parallel as CP, hot_ops, postprocessing as P, weights as W
+
+    model, _, _ = S.build_model(S.default_args(a.backbone, text_encoder_random_init=True))
+    sd = W.load_synthetic(model, WEIGHT_SEED)
+    model = model.to(dev).eval()
+
+    T, H, Wd, L, Q = a.frames, a.height, a.width, 10, 20
+    n_pool = 4
+    clips_cpu = [W.synthetic_clip(1 + 1000 * rank + i, T, H, Wd) for i in range(n_pool)]
+    clips = [c.to(dev) for c in clips_cpu]
+    ids_cpu = W.synthetic_token_ids(1, L)
+    text = {"input_ids": ids_cpu.to(dev), "attention_mask": torch.ones_like(ids_cpu).to(dev)}
+    pad = torch.zeros(T, 1, H, Wd, dtype=torch.bool, device=dev)
+    targets = [[{"size": (H, Wd)}] for _ in range(T)]
+    hm, wm = -(-H // 4), -(-Wd // 4)
+    results = torch.zeros(a.steps, CP.record_size(T, Q, hm, wm), device=dev)
+
+    def step(i, record=None):
+        samples = S.NestedTensor(clips[i % n_pool][:, None], pad)
+        out = model(samples, None, text, targets)
+        idx, masks = P.select_trajectory(out)
+        if record is not None:
+            CP.pack_record(record, idx, out["pred_cls"][:, 0, :, 0], masks)
+        return out
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        step(i, results[0])
+    if world > 1:
+        CP.gather_results(results)  # RCCL warm-up, outside the timed region
+
+    fence()
+    hot_ops.profile_begin()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(i, results[i])
+    gathered = CP.gather_results(results)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof = hot_ops.profile_end()
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    assert gathered.shape[0] == world
+
+    if rank == 0:
+        line = {
+            "metric": "clips/s (T=8, 360x640, Video-Swin-T)" if (a.backbone, T, H, Wd) == ("video-swin-t", 8, 360, 640)
+                      else f"clips/s (T={T}, {H}x{Wd}, {a.backbone})",
+            "value": world * a.steps / dt, "unit": "clips/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"SOC eval forward + query selection, {a.backbone}, T={T}, {H}x{Wd}, B=1, "
+                                   f"L={L} tokens, random deterministic weights (seed {WEIGHT_SEED})",
+                       "clips_per_rank": a.steps, "parallelism": f"clip-parallel x{world}, one result all_gather"},
+        }
+        k1 = prof.get("win_attn3d")
+        if k1:
+            ach = k1["work"] / (k1["ms"] * 1e-3) / 1e12
+            line["roofline"] = {"kernel": "soc_win_attn3d_f32 (all 12 launches of a forward)", "bound": "mfma",
+                                "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                                "avg_launch_us": 1e3 * k1["ms"] / k1["launches"],
+                                "ms_per_clip": k1["ms"] / a.steps}
+        other = {}
+        for name in ("msda_fwd", "xattn", "dyn_mask"):
+            if name in prof:
+                r = prof[name]
+                gbs = r["work"] / (r["ms"] * 1e-3) / 1e9
+                other[name] = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                               "frac": gbs / PEAK_HBM_GBS, "avg_launch_us": 1e3 * r["ms"] / r["launches"],
+                               "ms_per_clip": r["ms"] / a.steps}
+        line["roofline_other"] = other
+
+        if world == 1 and not a.no_cpu_baseline:
+            from oracle import soc_oracle as O
+            enc = O.build_text_encoder(sd)
+            torch.set_num_threads(os.cpu_count() or 1)
+            t1 = time.perf_counter()
+            ref = O.soc_forward(sd, clips_cpu[0], ids_cpu, torch.ones_like(ids_cpu), (H, Wd),
+                                backbone=a.backbone, text_encoder=enc)
+            cpu_s = time.perf_counter() - t1
+            n_done = 1
+            if cpu_s < 8.0:  # cheap enough: time a second, warm forward and keep the better one
+                t1 = time.perf_counter()
+                O.soc_forward(sd, clips_cpu[0], ids_cpu, torch.ones_like(ids_cpu), (H, Wd),
+                              backbone=a.backbone, text_encoder=enc)
+                cpu_s = min(cpu_s, time.perf_counter() - t1)
+                n_done = 2
+            line["cpu_baseline"] = {"value": 1.0 / cpu_s, "unit": "clips/s", "cores": torch.get_num_threads(),
+                                    "kind": "port", "sample": f"{n_done} forward(s) of the same workload "
+                                    "(oracle/soc_oracle.py, torch-CPU fp32), best time"}
+            got = step(0)
+            torch.cuda.synchronize()
+            d = (got["pred_masks"].cpu() - ref["pred_masks"]).abs().max().item()
+            flips = int(((got["pred_masks"].cpu() > 0) != (ref["pred_masks"] > 0)).sum())
+            line["parity"] = {"mask_logit_max_abs_diff_vs_cpu_oracle": d,
+                              "max_abs_logit": ref["pred_masks"].abs().max().item(),
+                              "thresholded_mask_flips": flips}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

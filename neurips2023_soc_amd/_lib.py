@@ -27,7 +27,7 @@ def load() -> C.CDLL:
         return _lib
     if not os.path.exists(LIB_PATH):
         raise SocHipError(
-            f"{LIB_PATH} is missing: build it with `python -m neurips2023_soc_amd.build` "
+            f"{LIB_PATH} is missing: build it with `python -m neurips2023_soc_amd.build_ext` "
             "(hipcc --offload-arch=gfx950).  The SOC hot path has no CPU/PyTorch fallback.")
     lib = C.CDLL(LIB_PATH)
     for name in EXPORTS:

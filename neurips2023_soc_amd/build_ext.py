@@ -1,6 +1,6 @@
 """Compile libsoc_hip.so (the four gfx950 kernels behind include/soc_hip.h) in-tree with hipcc.
 
-    python -m neurips2023_soc_amd.build [--force]
+    python -m neurips2023_soc_amd.build_ext [--force]
 
 hipcc cross-compiles for gfx950 without a GPU; the built .so is git-ignored but travels to the
 GPU box with the repo snapshot.  No CUDA shims, no hipify, gfx950 only.

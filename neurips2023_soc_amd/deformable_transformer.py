@@ -36,9 +36,12 @@ class DeformableTransformerEncoder(nn.Module):
 
     @staticmethod
     def get_reference_points(spatial_shapes, valid_ratios, device):
-        """Pixel-centre grid of every level, normalised by the valid extent (reference :273-285)."""
+        """Pixel-centre grid of every level, normalised by the valid extent (reference :273-285).
+        ``spatial_shapes`` may be a python list of (H, W) -- preferred: no device->host sync."""
         pts = []
-        for lvl, (H_, W_) in enumerate(spatial_shapes.tolist()):
+        if torch.is_tensor(spatial_shapes):
+            spatial_shapes = spatial_shapes.tolist()
+        for lvl, (H_, W_) in enumerate(spatial_shapes):
             ys = torch.linspace(0.5, H_ - 0.5, H_, dtype=torch.float32, device=device)
             xs = torch.linspace(0.5, W_ - 0.5, W_, dtype=torch.float32, device=device)
             gy, gx = torch.meshgrid(ys, xs, indexing="ij")
@@ -47,8 +50,10 @@ class DeformableTransformerEncoder(nn.Module):
             pts.append(torch.stack((gx, gy), -1))
         return torch.cat(pts, 1)[:, :, None] * valid_ratios[:, None]
 
-    def forward(self, src, spatial_shapes, level_start_index, valid_ratios, pos=None, padding_mask=None):
-        ref = self.get_reference_points(spatial_shapes, valid_ratios, src.device)
+    def forward(self, src, spatial_shapes, level_start_index, valid_ratios, pos=None, padding_mask=None,
+                shapes_list=None):
+        ref = self.get_reference_points(shapes_list if shapes_list is not None else spatial_shapes,
+                                        valid_ratios, src.device)
         for layer in self.layers:
             src = layer(src, pos, ref, spatial_shapes, level_start_index, padding_mask)
         return src
@@ -157,7 +162,7 @@ class DeformableTransformer(nn.Module):
         level_start = torch.cat((spatial_shapes.new_zeros(1), spatial_shapes.prod(1).cumsum(0)[:-1]))
         ratios = torch.stack([self.get_valid_ratio(m) for m in masks], 1)
 
-        memory = self.encoder(src, spatial_shapes, level_start, ratios, pos, mask)
+        memory = self.encoder(src, spatial_shapes, level_start, ratios, pos, mask, shapes_list=shapes)
 
         b, t, q, c = tgt.shape
         tgt = tgt.reshape(b * t, q, c)

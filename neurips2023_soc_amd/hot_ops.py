@@ -15,6 +15,47 @@ from . import _lib
 Tensor = torch.Tensor
 
 
+# ---------------------------------------------------------------------------------------------
+# optional per-kernel timing (bench.py roofline): HIP events on the stream the kernels run on
+_prof = None
+
+
+def profile_begin() -> None:
+    global _prof
+    _prof = {}
+
+
+def profile_end() -> dict:
+    """-> {kernel: {"launches", "ms", "work", "unit"}} summed over everything since profile_begin()."""
+    global _prof
+    rec, _prof = _prof or {}, None
+    torch.cuda.synchronize()
+    out = {}
+    for name, items in rec.items():
+        ms = sum(s.elapsed_time(e) for s, e, _ in items)
+        out[name] = {"launches": len(items), "ms": ms, "work": float(sum(w for _, _, w in items)),
+                     "unit": "flop" if name == "win_attn3d" else "byte"}
+    return out
+
+
+class _timed:
+    def __init__(self, name: str, work: float):
+        self.name, self.work = name, work
+
+    def __enter__(self):
+        if _prof is not None:
+            self.s = torch.cuda.Event(enable_timing=True)
+            self.e = torch.cuda.Event(enable_timing=True)
+            self.s.record()
+        return self
+
+    def __exit__(self, *exc):
+        if _prof is not None:
+            self.e.record()
+            _prof.setdefault(self.name, []).append((self.s, self.e, self.work))
+        return False
+
+
 def _need_gpu(*ts: Tensor) -> None:
     for x in ts:
         if x is not None and not x.is_cuda:
@@ -57,9 +98,12 @@ def msda_forward(value: Tensor, spatial_shapes: Tensor, level_start_index: Tenso
         raise RuntimeError("ms_deform_attn_forward supports float32/float64 only")
     if sampling_loc.dtype != value.dtype or attn_weight.dtype != value.dtype:
         raise RuntimeError("value / sampling_loc / attn_weight dtypes differ")
-    code = fn(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
-              sampling_loc.data_ptr(), attn_weight.data_ptr(), out.data_ptr(), N, S, M, D, L, Lq, P,
-              _stream())
+    # algorithmic bytes: value + loc + weights read once, out written once
+    work = (value.numel() + sampling_loc.numel() + attn_weight.numel() + out.numel()) * value.element_size()
+    with _timed("msda_fwd", work):
+        code = fn(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+                  sampling_loc.data_ptr(), attn_weight.data_ptr(), out.data_ptr(), N, S, M, D, L, Lq, P,
+                  _stream())
     _lib.check(code, "soc_msda_fwd")
     return out
 
@@ -84,8 +128,12 @@ def window_attention3d(qkv: Tensor, qkv_bias: Tensor, bias_table: Tensor, n_head
     C = C3 // 3
     win, sh = clamp_window((D, H, W), window, shift)
     out = torch.empty((B, D, H, W, C), dtype=torch.float32, device=qkv.device)
-    code = lib.soc_win_attn3d_f32(qkv.data_ptr(), qkv_bias.data_ptr(), bias_table.data_ptr(),
-                                  out.data_ptr(), B, D, H, W, C, n_heads, *win, *sh, *window, _stream())
+    # algorithmic FLOPs: QK^T + PV = 4 * N^2 * head_dim per (window, head)
+    n_win = B * -(-D // win[0]) * -(-H // win[1]) * -(-W // win[2])
+    n_tok = win[0] * win[1] * win[2]
+    with _timed("win_attn3d", 4.0 * n_tok * n_tok * (C // n_heads) * n_win * n_heads):
+        code = lib.soc_win_attn3d_f32(qkv.data_ptr(), qkv_bias.data_ptr(), bias_table.data_ptr(),
+                                      out.data_ptr(), B, D, H, W, C, n_heads, *win, *sh, *window, _stream())
     _lib.check(code, "soc_win_attn3d_f32")
     return out
 
@@ -116,8 +164,9 @@ def mha_core(q: Tensor, k: Tensor, v: Tensor, n_heads: int,
             ws = torch.empty(need, dtype=torch.uint8, device=q.device)
             _ws_cache[key] = ws
         ws_ptr = ws.data_ptr()
-    code = lib.soc_xattn_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), kpm_ptr, out.data_ptr(),
-                             Lq, Lk, B, n_heads, hd, ws_ptr, need, _stream())
+    with _timed("xattn", (2 * q.numel() + k.numel() + v.numel()) * 4):
+        code = lib.soc_xattn_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), kpm_ptr, out.data_ptr(),
+                                 Lq, Lk, B, n_heads, hd, ws_ptr, need, _stream())
     _lib.check(code, "soc_xattn_f32")
     return out
 
@@ -134,7 +183,8 @@ def dynamic_mask(feats: Tensor, params: Tensor, refs: Tensor, img_hw: Sequence[f
     if params.shape[1] != (Cm + 2) * 8 + 64 + 8 + 8 + 8 + 1:
         raise _lib.SocHipError(f"unexpected dynamic-parameter count {params.shape[1]}")
     out = torch.empty((TQ, h, w), dtype=torch.float32, device=feats.device)
-    code = lib.soc_dyn_mask_f32(feats.data_ptr(), params.data_ptr(), refs.data_ptr(), out.data_ptr(),
-                                T, Q, Cm, h, w, float(img_hw[0]), float(img_hw[1]), stride, _stream())
+    with _timed("dyn_mask", (feats.numel() + params.numel() + refs.numel() + out.numel()) * 4):
+        code = lib.soc_dyn_mask_f32(feats.data_ptr(), params.data_ptr(), refs.data_ptr(), out.data_ptr(),
+                                    T, Q, Cm, h, w, float(img_hw[0]), float(img_hw[1]), stride, _stream())
     _lib.check(code, "soc_dyn_mask_f32")
     return out

@@ -1,0 +1,283 @@
+"""SOC model, MI355X build: same constructor arguments, forward signature, output dict and
+state_dict key names as the reference (models/soc.py:31-394, build :624-660) so it drops into
+infer_refytb.py:133-214 / infer_davis.py unchanged -- but inference-only, with the four hot ops
+in hand-written HIP (hot_ops.py -> libsoc_hip.so) and the rest as fp32 library GEMMs/convs.
+
+Differences that do not change results:
+  * eval returns the decoder-level-0 heads (reference zip() quirk, soc.py:375-394 + voc.py:274);
+    class/box/mask heads of levels 1-2 are never computed here, decoder layers 1-2 still run
+    because VOC consumes hs[-1];
+  * `lvf` is evaluated only on the last fused level -- the only one the reference reads (:304);
+  * the dynamic mask head never materialises the [1, T*Q*10, h, w] tensor (K4).
+"""
+from __future__ import annotations
+
+import copy
+import math
+from typing import Dict, List, Optional, Sequence, Union
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import hot_ops
+from .deformable_transformer import build_deforamble_transformer
+from .nested_tensor import NestedTensor, inverse_sigmoid
+from .position_encoding import PositionEmbeddingSine1D
+from .postprocessing import build_postprocessors
+from .spatial_decoder import FPNSpatialDecoder
+from .video_swin import build_video_swin_backbone, resize_pad_mask
+from .vla import MMF
+from .voc import VOC
+
+
+class MLP(nn.Module):
+    def __init__(self, input_dim, hidden_dim, output_dim, num_layers):
+        super().__init__()
+        self.num_layers = num_layers
+        dims = [input_dim] + [hidden_dim] * (num_layers - 1) + [output_dim]
+        self.layers = nn.ModuleList(nn.Linear(a, b) for a, b in zip(dims[:-1], dims[1:]))
+
+    def forward(self, x):
+        for i, layer in enumerate(self.layers):
+            x = layer(x)
+            if i + 1 < self.num_layers:
+                x = F.relu(x)
+        return x
+
+
+class FeatureResizer(nn.Module):
+    """Linear + LayerNorm(eps 1e-12) (+ dropout, identity in eval) -- reference :566-585."""
+
+    def __init__(self, input_feat_size, output_feat_size, dropout, do_ln=True):
+        super().__init__()
+        self.do_ln = do_ln
+        self.fc = nn.Linear(input_feat_size, output_feat_size, bias=True)
+        self.layer_norm = nn.LayerNorm(output_feat_size, eps=1e-12)
+        self.dropout = nn.Dropout(dropout)
+
+    def forward(self, x):
+        x = self.fc(x)
+        return self.dropout(self.layer_norm(x) if self.do_ln else x)
+
+
+def roberta_base_config():
+    from transformers import RobertaConfig
+    return RobertaConfig(vocab_size=50265, hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
+                         intermediate_size=3072, max_position_embeddings=514, type_vocab_size=1,
+                         layer_norm_eps=1e-5, pad_token_id=1, bos_token_id=0, eos_token_id=2)
+
+
+def _load_text_stack(config):
+    """(RobertaModel, tokenizer-or-None).  Real weights when `text_encoder_type` resolves offline;
+    a random-init roberta-base only when the caller opts in (synthetic benchmarks / tests)."""
+    from transformers import RobertaModel, RobertaTokenizerFast
+    name = config.text_encoder_type
+    try:
+        enc = RobertaModel.from_pretrained(name, local_files_only=True)
+        tok = RobertaTokenizerFast.from_pretrained(name, local_files_only=True)
+        return enc, tok
+    except Exception as exc:  # no files / no network
+        if not getattr(config, "text_encoder_random_init", False):
+            raise RuntimeError(
+                f"cannot load text encoder {name!r} offline ({type(exc).__name__}); pass "
+                "text_encoder_random_init=True for synthetic-weight runs") from exc
+        return RobertaModel(roberta_base_config()), None
+
+
+class SOC(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        if config.backbone not in ("video-swin-t", "video-swin-s", "video-swin-b"):
+            raise NotImplementedError("only the Video-Swin backbones are on the MI355X hot path "
+                                      "(resnet50 branch of the reference: SURVEY.md section 2, out of scope)")
+        self.backbone = build_video_swin_backbone(config)
+        dt = config.DeformTransformer
+        self.num_feature_levels = dt["num_feature_levels"]
+        d_model = dt["d_model"]
+        self.num_queries = dt["num_queries"]
+        self.rel_coord = config.rel_coord
+        if not self.rel_coord:
+            raise NotImplementedError("K4 is built for rel_coord=True (every shipped config)")
+        self.transformer = build_deforamble_transformer(dt)
+
+        chans = self.backbone.num_channels[-3:]
+        proj = [nn.Sequential(nn.Conv2d(c, d_model, kernel_size=1), nn.GroupNorm(32, d_model)) for c in chans]
+        c_in = chans[-1]
+        for _ in range(self.num_feature_levels - len(chans)):
+            proj.append(nn.Sequential(nn.Conv2d(c_in, d_model, kernel_size=3, stride=2, padding=1),
+                                      nn.GroupNorm(32, d_model)))
+            c_in = d_model
+        self.input_proj = nn.ModuleList(proj)
+        for p in self.input_proj:
+            nn.init.xavier_uniform_(p[0].weight, gain=1)
+            nn.init.zeros_(p[0].bias)
+
+        n_pred = self.transformer.decoder.num_layers
+        box, cls = MLP(d_model, d_model, 4, 3), nn.Linear(d_model, config.num_classes)
+        cls.bias.data.fill_(-math.log((1 - 0.01) / 0.01))
+        nn.init.zeros_(box.layers[-1].weight)
+        nn.init.zeros_(box.layers[-1].bias)
+        if not config.with_box_refine:
+            raise NotImplementedError("with_box_refine=False is not used by any shipped config")
+        self.class_embed = nn.ModuleList(copy.deepcopy(cls) for _ in range(n_pred))
+        self.bbox_embed = nn.ModuleList(copy.deepcopy(box) for _ in range(n_pred))
+        self.bbox_embed[0].layers[-1].bias.data[2:].fill_(-2.0)
+        self.transformer.decoder.bbox_embed = self.bbox_embed  # shared modules, aliased state_dict keys
+
+        self.text_encoder, self.tokenizer = _load_text_stack(config)
+        self.freeze_text_encoder = config.freeze_text_encoder
+        self.text_pos = PositionEmbeddingSine1D(d_model, normalize=True)
+        self.query_embed = nn.Embedding(self.num_queries, d_model)
+        self.spatial_decoder = FPNSpatialDecoder(d_model, 2 * [d_model] + [self.backbone.num_channels[0]],
+                                                 config.mask_kernels_dim)
+        self.voc = VOC(config.VOC)
+        self.vlf = MMF(d_model=d_model, nhead=8)
+        self.lvf = MMF(d_model=d_model, nhead=8)
+        self.txt_proj = FeatureResizer(self.text_encoder.config.hidden_size, d_model, dropout=0.1)
+
+        self.controller_layers = config.controller_layers
+        self.in_channels = config.mask_kernels_dim
+        self.dynamic_mask_channels = config.dynamic_mask_channels
+        self.mask_out_stride = self.mask_feat_stride = 4
+        c, ch, nl = self.in_channels, self.dynamic_mask_channels, self.controller_layers
+        self.weight_nums = [(c + 2) * ch] + [ch * ch] * (nl - 2) + [ch]
+        self.bias_nums = [ch] * (nl - 1) + [1]
+        self.num_gen_params = sum(self.weight_nums) + sum(self.bias_nums)
+        if (c, ch, nl) != (8, 8, 3):
+            raise NotImplementedError("K4 is built for mask_kernels_dim=8, dynamic_mask_channels=8, "
+                                      "controller_layers=3 (every shipped config)")
+        self.controller = MLP(d_model, d_model, self.num_gen_params, 3)
+        for layer in self.controller.layers:
+            nn.init.zeros_(layer.bias)
+            nn.init.xavier_uniform_(layer.weight)
+        self.vl_loss, self.aux_loss = config.vl_loss, config.aux_loss
+
+    # ------------------------------------------------------------------ text
+    def forward_text(self, text_queries, device):
+        """list[str] (needs tokenizer files) or pre-tokenised {'input_ids','attention_mask'} [B,L]."""
+        if isinstance(text_queries, (list, tuple)) and text_queries and isinstance(text_queries[0], str):
+            if self.tokenizer is None:
+                raise RuntimeError("no tokenizer files available offline: pass pre-tokenised "
+                                   "{'input_ids', 'attention_mask'} tensors instead of strings")
+            tok = self.tokenizer.batch_encode_plus(list(text_queries), padding="longest", return_tensors="pt")
+            ids, attn = tok["input_ids"], tok["attention_mask"]
+        else:
+            ids, attn = text_queries["input_ids"], text_queries["attention_mask"]
+        ids, attn = ids.to(device), attn.to(device)
+        enc = self.text_encoder(input_ids=ids, attention_mask=attn)
+        words = self.txt_proj(enc.last_hidden_state.transpose(0, 1))   # [L,B,C]
+        sentence = self.txt_proj(enc.pooler_output)                     # [B,C]
+        return NestedTensor(words, attn.ne(1)), sentence
+
+    # ------------------------------------------------------------------ forward
+    @staticmethod
+    def _seq(x, B, T):
+        """'(b t) c h w -> (t h w) b c'"""
+        _, c, h, w = x.shape
+        return x.view(B, T, c, h, w).permute(1, 3, 4, 0, 2).reshape(T * h * w, B, c)
+
+    @staticmethod
+    def _unseq(x, B, T, h, w):
+        """'(t h w) b c -> (b t) c h w'"""
+        c = x.shape[-1]
+        return x.view(T, h, w, B, c).permute(3, 0, 4, 1, 2).reshape(B * T, c, h, w)
+
+    @torch.no_grad()
+    def forward(self, samples: NestedTensor, valid_indices, text_queries, targets):
+        """samples.tensors [T,B,3,H,W] + mask [T,B,H,W]; text_queries: B strings (or pre-tokenised);
+        targets[0][b]['size'] = (H,W) of the model input.  Returns the reference's output dict:
+        pred_masks [T,B,Q,H/4,W/4], pred_cls [T,B,Q,K], pred_boxes [T,B,Q,4], pred_logit [B,Q,C],
+        text_sentence_feature [B,C], aux_outputs []."""
+        if self.training:
+            raise RuntimeError("this build of SOC is inference-only: call model.eval()")
+        if valid_indices is not None:
+            raise NotImplementedError("valid_indices is only used by the A2D/JHMDB loaders "
+                                      "(reference soc.py:208-215), outside the inference hot path")
+        device = samples.tensors.device
+        text, sentence = self.forward_text(text_queries, device)
+        words, word_pad = text.decompose()
+        B = words.shape[1]
+        backbone_out, pos = self.backbone(samples)   # rewrites samples to '(b t)' like the reference
+        T = pos[0].shape[0] // B
+        text_pos = self.text_pos(text).permute(2, 0, 1)
+
+        srcs, masks, poses, lang_last = [], [], [], None
+        levels = list(zip(backbone_out[-3:], pos[-3:]))
+        for l, (feat, pos_l) in enumerate(levels):
+            src, mask = feat.decompose()
+            proj = self.input_proj[l](src)
+            h, w = proj.shape[-2:]
+            seq = self._seq(proj, B, T)
+            fused = self.vlf(tgt=seq, memory=words, memory_key_padding_mask=word_pad, pos=text_pos)
+            if l == len(levels) - 1:  # only langs[-1] is read downstream
+                lang_last = self.lvf(tgt=words, memory=seq,
+                                     memory_key_padding_mask=mask.view(B, T, h, w).reshape(B, -1),
+                                     pos=self._seq(pos_l, B, T))
+            srcs.append(self._unseq(fused, B, T, h, w))
+            masks.append(mask)
+            poses.append(pos_l)
+        for l in range(len(levels), self.num_feature_levels):
+            src = self.input_proj[l](backbone_out[-1].tensors if l == len(levels) else srcs[-1])
+            mask = resize_pad_mask(samples.mask, src.shape[-2:])
+            pos_l = self.backbone[1](NestedTensor(src, mask)).to(src.dtype)
+            h, w = src.shape[-2:]
+            fused = self.vlf(tgt=self._seq(src, B, T), memory=words, memory_key_padding_mask=word_pad, pos=text_pos)
+            srcs.append(self._unseq(fused, B, T, h, w))
+            masks.append(mask)
+            poses.append(pos_l)
+
+        Q = self.num_queries
+        tgt = words.new_zeros(B, T, Q, words.shape[-1])
+        hs, memory, init_ref, inter_refs, _, _, _ = self.transformer(srcs, tgt, masks, poses, self.query_embed.weight)
+
+        # text feature the reference reports for its vl-loss: mean over real words of lvf's output
+        keep = (~word_pad).to(lang_last.dtype).transpose(0, 1)[..., None]   # [L,B,1]
+        text_feature = (lang_last * keep).sum(0) / keep.sum(0)
+
+        C = hs.shape[-1]
+        hs_t = hs.view(hs.shape[0], B, T, Q, C).transpose(1, 2)              # l t b q c
+        voc_hs = self.voc(hs_t, sentence)                                    # [1,B,Q,C]
+        hs0 = hs[0].view(B, T, Q, C) + voc_hs[0][:, None]                    # level 0 (b t q c)
+
+        cls = self.class_embed[0](hs0)
+        box = self.bbox_embed[0](hs0)
+        box = torch.cat([box[..., :2] + inverse_sigmoid(init_ref).view(B, T, Q, 2), box[..., 2:]], -1).sigmoid()
+
+        feats0 = backbone_out[0].tensors
+        fpn = self.spatial_decoder(memory[-1], [memory[1], memory[0], feats0])  # '(b t) 8 h/4 w/4'
+        hm, wm = fpn.shape[-2:]
+        params = self.controller(hs0)                                        # b t q 169
+        refs = inter_refs[0][..., :2].reshape(B, T * Q, 2)
+        fpn = fpn.view(B, T, fpn.shape[1], hm, wm)
+        per_b = []
+        for b in range(B):
+            size = targets[0][b]["size"]
+            img_h, img_w = (float(v) for v in (size.tolist() if torch.is_tensor(size) else size))
+            m = hot_ops.dynamic_mask(fpn[b], params[b].reshape(T * Q, -1), refs[b], (img_h, img_w),
+                                     self.mask_feat_stride)
+            per_b.append(m.view(T, Q, hm, wm))
+        pred_masks = torch.stack(per_b, 1)                                   # t b q h w
+
+        out = {"pred_masks": pred_masks,
+               "pred_logit": voc_hs[0],
+               "pred_boxes": box.transpose(0, 1),
+               "text_sentence_feature": text_feature,
+               "pred_cls": cls.transpose(0, 1)}
+        if self.aux_loss:
+            out["aux_outputs"] = []
+        return out
+
+    def num_parameters(self):
+        return sum(p.numel() for p in self.parameters() if p.requires_grad)
+
+
+def build(args):
+    """-> (model, criterion, postprocessor) like reference models/soc.py:624-646.  The criterion is
+    training-only (out of scope) and inference callers discard it (infer_refytb.py:133): None."""
+    model = SOC(args)
+    return model, None, build_postprocessors(args.dataset_name)
+
+
+def build_model(args):
+    return build(args)

@@ -1,0 +1,20 @@
+"""Video-language alignment block (reference models/vla.py:8-24): tgt * MHA(tgt, memory+pos, memory)."""
+from __future__ import annotations
+
+from typing import Optional
+
+from torch import Tensor, nn
+
+from .attention import HipMultiheadAttention
+
+
+class MMF(nn.Module):
+    def __init__(self, d_model: int, nhead: int, dropout: float = 0.0):
+        super().__init__()
+        self.multihead_attn = HipMultiheadAttention(d_model, nhead, dropout)
+
+    def forward(self, tgt: Tensor, memory: Tensor, memory_key_padding_mask: Optional[Tensor] = None,
+                pos: Optional[Tensor] = None, query_pos: Optional[Tensor] = None) -> Tensor:
+        q = tgt if query_pos is None else tgt + query_pos
+        k = memory if pos is None else memory + pos
+        return tgt * self.multihead_attn(q, k, memory, memory_key_padding_mask)

@@ -1,0 +1,91 @@
+"""-m gpu: the whole HIP hot path (SOC.forward on an MI355X) against the reference's golden
+outputs and the CPU oracle.  Tolerance: mask-logit max-abs-diff < 1e-3 (BASELINE.json north_star),
+thresholded masks and the selected query bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+import neurips2023_soc_amd as S
+from neurips2023_soc_amd import postprocessing as P, weights as W
+from tests.golden_utils import sub, t
+
+pytestmark = pytest.mark.gpu
+
+
+def maxdiff(a, b):
+    return float((torch.as_tensor(a).detach().cpu().double() - torch.as_tensor(b).double()).abs().max())
+
+
+@pytest.fixture(scope="module")
+def gpu_model(synthetic_sd):
+    assert torch.cuda.is_available()
+    model, _, _ = S.build_model(S.default_args(text_encoder_random_init=True))
+    model.load_state_dict(synthetic_sd, strict=False)
+    return model.cuda().eval()
+
+
+def run_cfg(model, cfg):
+    seed, T, H, Wd, L = (int(v) for v in cfg)
+    samples = S.nested_tensor_from_videos_list([W.synthetic_clip(seed, T, H, Wd)]).to("cuda")
+    ids = W.synthetic_token_ids(seed, L)
+    targets = [[{"size": torch.tensor([H, Wd])}] for _ in range(T)]
+    out = model(samples, None, {"input_ids": ids, "attention_mask": torch.ones_like(ids)}, targets)
+    torch.cuda.synchronize()
+    return out
+
+
+def test_tiny_config_matches_reference(gpu_model, golden):
+    g = golden("tiny_forward.npz")
+    out = run_cfg(gpu_model, g["cfg"])
+    d = maxdiff(out["pred_masks"], g["pred_masks"])
+    print("tiny: max|dlogit|", d, "of", np.abs(g["pred_masks"]).max())
+    assert d < 1e-3
+    assert np.array_equal(out["pred_masks"].cpu().numpy() > 0, g["pred_masks"] > 0)
+    assert maxdiff(out["pred_cls"], g["pred_cls"]) < 1e-4
+    assert maxdiff(out["pred_boxes"], g["pred_boxes"]) < 1e-5
+    assert maxdiff(out["pred_logit"], g["pred_logit"]) < 1e-4
+    assert maxdiff(out["text_sentence_feature"], g["text_sentence_feature"]) < 1e-4
+
+
+def test_full_config_matches_reference(gpu_model, golden):
+    """BASELINE config: Swin-T, T=8, 360x640."""
+    g = golden("full_forward.npz")
+    out = run_cfg(gpu_model, g["cfg"])
+    idx, masks = P.select_trajectory(out)
+    assert int(idx) == int(g["selected_query"])
+    d = maxdiff(masks, g["selected_masks"])
+    dsub = maxdiff(sub(out["pred_masks"], 1 << 17), g["pred_masks_sub"])
+    print("full: max|dlogit| selected", d, "all(sub)", dsub, "of", g["pred_masks_stats"][2])
+    assert d < 1e-3 and dsub < 1e-3
+    bits = np.packbits((out["pred_masks"] > 0).cpu().numpy().reshape(-1))
+    flips = int(np.unpackbits(bits ^ g["pred_masks_signbits"]).sum())
+    assert flips == 0, f"{flips} thresholded-mask pixels differ from the reference"
+    assert maxdiff(out["pred_cls"], g["pred_cls"]) < 1e-4
+    assert maxdiff(out["pred_boxes"], g["pred_boxes"]) < 1e-5
+    assert maxdiff(out["pred_logit"], g["pred_logit"]) < 1e-4
+
+
+def test_t10_temporal_shift_matches_reference(gpu_model, golden):
+    g = golden("t10_forward.npz")
+    out = run_cfg(gpu_model, g["cfg"])
+    assert maxdiff(sub(out["pred_masks"], 65536), g["pred_masks_sub"]) < 1e-3
+    assert maxdiff(out["pred_cls"], g["pred_cls"]) < 1e-4
+
+
+def test_forward_repeatable_and_input_mutation_tolerated(gpu_model, golden):
+    """Two runs agree to rounding (library GEMM/conv algorithm selection may differ between the
+    first and later calls, so not bitwise); bitwise repeatability of the four HIP kernels
+    themselves is asserted in test_gpu_kernels.py::test_kernels_bitwise_repeatable."""
+    g = golden("tiny_forward.npz")
+    a = run_cfg(gpu_model, g["cfg"])["pred_masks"]
+    b = run_cfg(gpu_model, g["cfg"])["pred_masks"]
+    assert maxdiff(a, b.cpu()) < 5e-4
+    assert torch.equal(a > 0, b > 0)
+
+
+def test_upsample_threshold_on_device(gpu_model, golden):
+    g = golden("full_forward.npz")
+    m = t(g["selected_masks"]).cuda()
+    up = P.upsample_and_threshold(m, (720, 1280))
+    ref = P.upsample_and_threshold(m.cpu(), (720, 1280))
+    assert float((up.cpu() != ref).float().mean()) < 1e-5

@@ -188,3 +188,24 @@ def test_dynamic_mask_vs_oracle(ops, T, Q, h, w):
     ref = O.dynamic_mask_core(feats, params, refs, (4 * h, 4 * w))
     out = ops.dynamic_mask(dev(feats), dev(params), dev(refs), (4 * h, 4 * w))
     assert maxdiff(out, ref) < 1e-5 * max(1.0, float(ref.abs().max()))
+
+
+def test_kernels_bitwise_repeatable(ops):
+    """No atomics / no launch-order dependence in any of the four kernels."""
+    g = torch.Generator().manual_seed(0)
+    qkv = dev(torch.randn(1, 8, 23, 40, 3 * 96, generator=g))
+    bias, table = dev(torch.randn(288, generator=g)), dev(torch.randn(2535, 3, generator=g))
+    a = ops.window_attention3d(qkv, bias, table, 3, O.WINDOW, (4, 3, 3))
+    b = ops.window_attention3d(qkv, bias, table, 3, O.WINDOW, (4, 3, 3))
+    assert torch.equal(a, b)
+    q, k, v = (dev(torch.randn(L, 1, 256, generator=g)) for L in (10, 1920, 1920))
+    assert torch.equal(ops.mha_core(q, k, v, 8), ops.mha_core(q, k, v, 8))
+    shapes = torch.tensor([[12, 20], [6, 10]])
+    lsi = torch.tensor([0, 240])
+    value = dev(torch.randn(2, 300, 8, 32, generator=g))
+    loc = dev(torch.rand(2, 50, 8, 2, 4, 2, generator=g))
+    w = dev(torch.rand(2, 50, 8, 2, 4, generator=g))
+    assert torch.equal(ops.msda_forward(value, dev(shapes), dev(lsi), loc, w),
+                       ops.msda_forward(value, dev(shapes), dev(lsi), loc, w))
+    f, p, r = dev(torch.randn(2, 8, 9, 11, generator=g)), dev(torch.randn(6, 169, generator=g)), dev(torch.rand(6, 2, generator=g))
+    assert torch.equal(ops.dynamic_mask(f, p, r, (36, 44)), ops.dynamic_mask(f, p, r, (36, 44)))

@@ -129,3 +129,14 @@ def test_select_query_matches_reference_driver(tiny_run):
     ref_scores = torch.from_numpy(g["pred_cls"])[:, 0].sigmoid().mean(0).max(-1)[0]
     assert qi == int(ref_scores.argmax())
     assert masks.shape == (g["pred_masks"].shape[0],) + g["pred_masks"].shape[-2:]
+
+
+# ------------------------------------------------------------------ plain-C restatement of MSDA
+@pytest.mark.parametrize("tag,tol", [("a64", 1e-12), ("a32", 1e-7), ("b", 2e-5)])
+def test_c_msda_known_answers(golden, tag, tol):
+    from oracle import c_oracle
+    g = golden("msda_cases.npz")
+    dt = np.float64 if tag == "a64" else np.float32
+    out = c_oracle.msda(g[f"{tag}_value"].astype(dt), g[f"{tag}_shapes"], g[f"{tag}_lsi"],
+                        g[f"{tag}_loc"].astype(dt), g[f"{tag}_w"].astype(dt))
+    assert float(np.abs(out.astype(np.float64) - g[f"{tag}_out"].astype(np.float64)).max()) < tol
