@@ -43,9 +43,9 @@ def gather_results(local: torch.Tensor) -> torch.Tensor:
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return local[None]
     world = dist.get_world_size()
-    out = local.new_empty((world,) + tuple(local.shape))
+    out = local.new_empty((world * local.shape[0],) + tuple(local.shape[1:]))  # concat layout
     dist.all_gather_into_tensor(out, local.contiguous())
-    return out
+    return out.view((world,) + tuple(local.shape))
 
 
 def interleave(gathered: torch.Tensor, n_clips: int) -> torch.Tensor:

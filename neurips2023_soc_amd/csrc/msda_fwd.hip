@@ -6,8 +6,9 @@
 // h = y*H - 0.5, w = x*W - 0.5; a point contributes only when -1 < h < H and -1 < w < W.
 //
 // MI355X mapping (HBM/L2-bound gather):
-//   * fast path D == 32, f32: 8 lanes x float4 cover one (query, head) row of 32 channels, so a
-//     64-lane wave covers 8 heads of one query and every tap is one fully used 128-B line;
+//   * fast path D == 32, P == 4, f32: 8 lanes x float4 cover one (query, head) row of 32
+//     channels, so a 64-lane wave covers 8 heads of one query and every tap is one fully used
+//     128-B line; all 16 taps of a level are in flight together;
 //   * the block -> frame mapping is round-robin (frame = block % N), which is how the dispatcher
 //     deals blocks to the 8 XCDs: with N = 8 frames each XCD's private 4 MiB L2 only ever sees
 //     one frame's 4.9 MB value map (speed only, never correctness);
@@ -20,13 +21,22 @@ template <typename T>
 __device__ __forceinline__ T ldg(const T* p) { return *p; }
 
 // ---------------------------------------------------------------------------------------------
-// fast path: D = 32, float, one lane = 4 channels
+// fast path: D = 32, P = 4, float.  One lane = 4 channels; per level the lane fetches the 4
+// points' locations + weights with three 16-B loads, derives all 16 tap addresses (clamped into
+// the map so every load is unconditional) and issues the 16 float4 tap loads back to back --
+// 16 independent 128-B-line requests in flight per 8-lane group instead of a dependent
+// load -> branch -> load chain per point.  Out-of-range taps keep their (clamped) load but get
+// weight 0, which is the reference's zero padding.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void msda_fwd_d32_kernel(
+__device__ __forceinline__ void fma4(float4& a, float w, const float4& v) {
+    a.x += w * v.x; a.y += w * v.y; a.z += w * v.z; a.w += w * v.w;
+}
+
+__global__ __launch_bounds__(256) void msda_fwd_d32p4_kernel(
     const float* __restrict__ value, const int64_t* __restrict__ shapes,
     const int64_t* __restrict__ lsi, const float* __restrict__ loc,
     const float* __restrict__ attw, float* __restrict__ out, int N, int S, int M, int L, int Lq,
-    int P, int groups_per_frame /* = Lq*M */, int blocks_per_frame) {
+    int groups_per_frame /* = Lq*M */) {
     const int n = blockIdx.x % N;        // XCD-friendly: blocks b, b+8, ... share an XCD
     const int chunk = blockIdx.x / N;
     const int sub = threadIdx.x >> 3;    // 32 (query, head) groups per block
@@ -35,8 +45,8 @@ __global__ __launch_bounds__(256) void msda_fwd_d32_kernel(
     if (g >= groups_per_frame) return;
     const int m = g % M;
     const long gi = (long)n * groups_per_frame + g;          // (n, q, m) flat
-    const float* lp = loc + gi * (long)(L * P * 2);
-    const float* wp = attw + gi * (long)(L * P);
+    const float4* lp = reinterpret_cast<const float4*>(loc + gi * (long)(L * 8));
+    const float4* wp = reinterpret_cast<const float4*>(attw + gi * (long)(L * 4));
     const float* vbase = value + (long)n * S * M * 32 + m * 32 + c4 * 4;
     const int rstride = M * 32;  // floats between consecutive spatial positions
 
@@ -44,31 +54,47 @@ __global__ __launch_bounds__(256) void msda_fwd_d32_kernel(
     for (int l = 0; l < L; ++l) {
         const int Hl = (int)shapes[2 * l], Wl = (int)shapes[2 * l + 1];
         const float* vl = vbase + (long)lsi[l] * rstride;
-        for (int p = 0; p < P; ++p) {
-            const float2 xy = *reinterpret_cast<const float2*>(lp + (l * P + p) * 2);
-            const float wgt = wp[l * P + p];
-            const float him = xy.y * Hl - 0.5f;
-            const float wim = xy.x * Wl - 0.5f;
-            if (him > -1.f && wim > -1.f && him < Hl && wim < Wl) {
-                const int h0 = (int)floorf(him), w0 = (int)floorf(wim);
-                const float lh = him - h0, lw = wim - w0;
-                const float hh = 1.f - lh, hw = 1.f - lw;
-                const bool h0ok = h0 >= 0, h1ok = h0 + 1 <= Hl - 1;
-                const bool w0ok = w0 >= 0, w1ok = w0 + 1 <= Wl - 1;
-                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-                const float* r0 = vl + ((long)h0 * Wl + w0) * rstride;
-                const float* r1 = r0 + (long)Wl * rstride;
-                const float4 v1 = (h0ok && w0ok) ? *reinterpret_cast<const float4*>(r0) : z;
-                const float4 v2 = (h0ok && w1ok) ? *reinterpret_cast<const float4*>(r0 + rstride) : z;
-                const float4 v3 = (h1ok && w0ok) ? *reinterpret_cast<const float4*>(r1) : z;
-                const float4 v4 = (h1ok && w1ok) ? *reinterpret_cast<const float4*>(r1 + rstride) : z;
-                const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
-                acc.x += (w1 * v1.x + w2 * v2.x + w3 * v3.x + w4 * v4.x) * wgt;
-                acc.y += (w1 * v1.y + w2 * v2.y + w3 * v3.y + w4 * v4.y) * wgt;
-                acc.z += (w1 * v1.z + w2 * v2.z + w3 * v3.z + w4 * v4.z) * wgt;
-                acc.w += (w1 * v1.w + w2 * v2.w + w3 * v3.w + w4 * v4.w) * wgt;
-            }
+        const float4 la = lp[2 * l], lb = lp[2 * l + 1];
+        const float4 wv = wp[l];
+        const float xs[4] = {la.x, la.z, lb.x, lb.z};
+        const float ys[4] = {la.y, la.w, lb.y, lb.w};
+        const float ws[4] = {wv.x, wv.y, wv.z, wv.w};
+        float tw[4][4];
+        const float* ptr[4][4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const float him = ys[p] * Hl - 0.5f;
+            const float wim = xs[p] * Wl - 0.5f;
+            const bool ok = him > -1.f && wim > -1.f && him < Hl && wim < Wl;
+            const float hf = floorf(him), wf = floorf(wim);
+            const float lh = him - hf, lw = wim - wf;
+            const float hh = 1.f - lh, hw = 1.f - lw;
+            // clamp BEFORE the int conversion so wild locations cannot overflow
+            const int h0 = (int)fminf(fmaxf(hf, -1.f), (float)Hl);
+            const int w0 = (int)fminf(fmaxf(wf, -1.f), (float)Wl);
+            const bool h0ok = ok && h0 >= 0, h1ok = ok && h0 + 1 <= Hl - 1;
+            const bool w0ok = w0 >= 0, w1ok = w0 + 1 <= Wl - 1;
+            const int h0c = min(max(h0, 0), Hl - 1), h1c = min(max(h0 + 1, 0), Hl - 1);
+            const int w0c = min(max(w0, 0), Wl - 1), w1c = min(max(w0 + 1, 0), Wl - 1);
+            const float wgt = ws[p];
+            tw[p][0] = (h0ok && w0ok) ? hh * hw * wgt : 0.f;
+            tw[p][1] = (h0ok && w1ok) ? hh * lw * wgt : 0.f;
+            tw[p][2] = (h1ok && w0ok) ? lh * hw * wgt : 0.f;
+            tw[p][3] = (h1ok && w1ok) ? lh * lw * wgt : 0.f;
+            ptr[p][0] = vl + (long)(h0c * Wl + w0c) * rstride;
+            ptr[p][1] = vl + (long)(h0c * Wl + w1c) * rstride;
+            ptr[p][2] = vl + (long)(h1c * Wl + w0c) * rstride;
+            ptr[p][3] = vl + (long)(h1c * Wl + w1c) * rstride;
         }
+        float4 tv[4][4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) tv[p][k] = *reinterpret_cast<const float4*>(ptr[p][k]);
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) fma4(acc, tw[p][k], tv[p][k]);
     }
     *reinterpret_cast<float4*>(out + gi * 32 + c4 * 4) = acc;
 }
@@ -145,12 +171,12 @@ extern "C" int soc_msda_fwd_f32(const float* value, const int64_t* spatial_shape
                  M, D, L, Lq, P))
         return SOC_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    if (D == 32) {
+    if (D == 32 && P == 4) {
         const int gpf = Lq * M;
         const int bpf = soc_ceil_div(gpf, 32);
-        hipLaunchKernelGGL(msda_fwd_d32_kernel, dim3(bpf * N), dim3(256), 0, st, value,
+        hipLaunchKernelGGL(msda_fwd_d32p4_kernel, dim3(bpf * N), dim3(256), 0, st, value,
                            spatial_shapes, level_start_index, sampling_loc, attn_weight, out, N,
-                           S, M, L, Lq, P, gpf, bpf);
+                           S, M, L, Lq, gpf);
         return soc_check_launch();
     }
     return launch_generic<float>(value, spatial_shapes, level_start_index, sampling_loc,

@@ -52,15 +52,17 @@ __device__ __forceinline__ int region1d(int c, int P, int w, int s) {
     return c < P - w ? 0 : (c < P - s ? 1 : 2);
 }
 
+template <int NT, int NT_PREV, bool SHIFTED>
 __global__ __launch_bounds__(THREADS, 2) void win_attn3d_kernel(
     const float* __restrict__ qkv, const float* __restrict__ qkv_bias,
     const float* __restrict__ table, float* __restrict__ out, const WinParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int NP = NT * 16;
     float* Ks = reinterpret_cast<float*>(smem_raw);           // [NP][RS]
-    float* Vs = Ks + NP_MAX * RS;                              // [NP][RS]
-    float* Tb = Vs + NP_MAX * RS;                              // [table_len]
+    float* Vs = Ks + NP * RS;                                  // [NP][RS]
+    float* Tb = Vs + NP * RS;                                  // [table_len]
     int* src = reinterpret_cast<int*>(Tb + ((p.table_len + 3) & ~3));  // [NP] token offset or <0
-    int* code = src + NP_MAX;                                  // [NP] e(i) | region << 16
+    int* code = src + NP;                                      // [NP] e(i) | region << 16
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -72,7 +74,6 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_kernel(
     const int wy = bid % p.nwh; bid /= p.nwh;
     const int wz = bid % p.nwd; bid /= p.nwd;
     const int b = bid;
-    const int NP = p.NT * 16;
     const int C3 = 3 * p.C;
 
     // ---- stage 0: token metadata ------------------------------------------------------------
@@ -105,20 +106,30 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_kernel(
         const int part = tid & 7;
         const float4 kbias = *reinterpret_cast<const float4*>(qkv_bias + p.C + head * HD + part * 4);
         const float4 vbias = *reinterpret_cast<const float4*>(qkv_bias + 2 * p.C + head * HD + part * 4);
-        for (int i = tid >> 3; i < NP; i += THREADS / 8) {
-            const int s = src[i];
-            float4 kv, vv;
+        constexpr int ROWS = THREADS / 8;                 // 64 token rows per pass
+        constexpr int PASSES = (NP + ROWS - 1) / ROWS;
+        float4 kv[PASSES], vv[PASSES];
+#pragma unroll
+        for (int it = 0; it < PASSES; ++it) {             // issue every global load first
+            const int i = it * ROWS + (tid >> 3);
+            const int s = i < NP ? src[i] : -2;
             if (s >= 0) {
                 const float* row = qkv + (long)s * C3 + head * HD + part * 4;
-                kv = *reinterpret_cast<const float4*>(row + p.C);
-                vv = *reinterpret_cast<const float4*>(row + 2 * p.C);
+                kv[it] = *reinterpret_cast<const float4*>(row + p.C);
+                vv[it] = *reinterpret_cast<const float4*>(row + 2 * p.C);
             } else if (s == -1) {
-                kv = kbias; vv = vbias;
+                kv[it] = kbias; vv[it] = vbias;
             } else {
-                kv = make_float4(0.f, 0.f, 0.f, 0.f); vv = kv;
+                kv[it] = make_float4(0.f, 0.f, 0.f, 0.f); vv[it] = kv[it];
             }
-            *reinterpret_cast<float4*>(Ks + i * RS + part * 4) = kv;
-            *reinterpret_cast<float4*>(Vs + i * RS + part * 4) = vv;
+        }
+#pragma unroll
+        for (int it = 0; it < PASSES; ++it) {
+            const int i = it * ROWS + (tid >> 3);
+            if (i < NP) {
+                *reinterpret_cast<float4*>(Ks + i * RS + part * 4) = kv[it];
+                *reinterpret_cast<float4*>(Vs + i * RS + part * 4) = vv[it];
+            }
         }
     }
     __syncthreads();
@@ -127,8 +138,11 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_kernel(
     const int r = lane & 15;   // MFMA column: query inside the tile (also A-operand row)
     const int g = lane >> 4;   // MFMA k index / C row group
     const float scale = 0.17677669529663687f;  // 32^-0.5
+    const float LOG2E = 1.4426950408889634f;
     const int E0 = ((p.td - 1) * (2 * p.th - 1) + (p.th - 1)) * (2 * p.tw - 1) + (p.tw - 1);
     const int nwaves_total = (THREADS / 64) * p.qsplit;
+    const float* kbase = Ks + r * RS + g;          // + 16t*RS + 4kk
+    const float* vbase = Vs + (4 * g) * RS + r;    // + (16t + s)*RS (+16)
 
     for (int qt = qpart * (THREADS / 64) + wave; qt < p.NT; qt += nwaves_total) {
         const int qtok = qt * 16 + r;
@@ -150,48 +164,60 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_kernel(
         const int qe = (qcode & 0xFFFF) + E0;
         const int qreg = qcode >> 16;
 
-        // S^T tiles: acc[t][i] = S[query r][key 16t + 4g + i]
-        f32x4 acc[NT_MAX];
+        // S^T tiles: acc[t][i] = S[query r][key 16t + 4g + i].  k-step outermost: the NT MFMAs of
+        // one k-step hit NT independent accumulators (no dependent-issue stalls) and the LDS reads
+        // of the next k-step overlap them.
+        f32x4 acc[NT];
 #pragma unroll
-        for (int t = 0; t < NT_MAX; ++t) {
-            acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (t < p.NT) {
-                const float* kp = Ks + (16 * t + r) * RS + g;
+        for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        {
+            float a0[NT], a1[NT];  // K fragments, double-buffered across k-steps
 #pragma unroll
-                for (int kk = 0; kk < 8; ++kk)
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kp[4 * kk], qf[kk], acc[t], 0, 0, 0);
+            for (int t = 0; t < NT; ++t) a0[t] = kbase[16 * t * RS];
+#pragma unroll
+            for (int kk = 0; kk < 8; kk += 2) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) a1[t] = kbase[16 * t * RS + 4 * (kk + 1)];
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[t], qf[kk], acc[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kk + 2 < 8) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) a0[t] = kbase[16 * t * RS + 4 * (kk + 2)];
+                }
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[t], qf[kk + 1], acc[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
-        // bias + mask + row max
+        // bias + mask + row max (scores kept in log2 units so exp is a bare v_exp_f32)
         float mx = -INFINITY;
 #pragma unroll
-        for (int t = 0; t < NT_MAX; ++t) {
-            if (t < p.NT) {
-                const int4 kc = *reinterpret_cast<const int4*>(code + 16 * t + 4 * g);
-                const int kcs[4] = {kc.x, kc.y, kc.z, kc.w};
+        for (int t = 0; t < NT; ++t) {
+            const int4 kc = *reinterpret_cast<const int4*>(code + 16 * t + 4 * g);
+            const int kcs[4] = {kc.x, kc.y, kc.z, kc.w};
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int key = 16 * t + 4 * g + i;
-                    float s = acc[t][i] + Tb[qe - (kcs[i] & 0xFFFF)];
-                    if (p.shifted && (kcs[i] >> 16) != qreg) s += -100.0f;
-                    if (key >= p.N) s = -INFINITY;
-                    acc[t][i] = s;
-                    mx = fmaxf(mx, s);
-                }
+            for (int i = 0; i < 4; ++i) {
+                float s = acc[t][i] + Tb[qe - (kcs[i] & 0xFFFF)];
+                if (SHIFTED) s += ((kcs[i] >> 16) != qreg) ? -100.0f : 0.f;
+                if (t >= NT_PREV && 16 * t + 4 * g + i >= p.N) s = -INFINITY;  // only tiles that can hold surplus keys
+                acc[t][i] = s;
+                mx = fmaxf(mx, s);
             }
         }
         mx = fmaxf(mx, __shfl_xor(mx, 16));
         mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float mxl = mx * LOG2E;
         float sum = 0.f;
 #pragma unroll
-        for (int t = 0; t < NT_MAX; ++t) {
-            if (t < p.NT) {
+        for (int t = 0; t < NT; ++t) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float e = __expf(acc[t][i] - mx);
-                    acc[t][i] = e;
-                    sum += e;
-                }
+            for (int i = 0; i < 4; ++i) {
+                const float e = __builtin_amdgcn_exp2f(acc[t][i] * LOG2E - mxl);
+                acc[t][i] = e;
+                sum += e;
             }
         }
         sum += __shfl_xor(sum, 16);
@@ -199,14 +225,39 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_kernel(
 
         // O^T = V^T . P^T : A = V[key 16t+4g+s][dim 16*dt + r], B = acc[t][s]
         f32x4 o0 = (f32x4){0.f, 0.f, 0.f, 0.f}, o1 = o0;
+        {
+            float va[8], vb[8];  // V fragments of tile t / t+1: [s] dims 0-15, [4+s] dims 16-31
 #pragma unroll
-        for (int t = 0; t < NT_MAX; ++t) {
-            if (t < p.NT) {
-                const float* vp = Vs + (16 * t + 4 * g) * RS + r;
+            for (int s = 0; s < 4; ++s) { va[s] = vbase[s * RS]; va[4 + s] = vbase[s * RS + 16]; }
+#pragma unroll
+            for (int t = 0; t < NT; t += 2) {
+                if (t + 1 < NT) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        vb[s] = vbase[(16 * (t + 1) + s) * RS];
+                        vb[4 + s] = vbase[(16 * (t + 1) + s) * RS + 16];
+                    }
+                }
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-                    o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[s * RS], acc[t][s], o0, 0, 0, 0);
-                    o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[s * RS + 16], acc[t][s], o1, 0, 0, 0);
+                    o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(va[s], acc[t][s], o0, 0, 0, 0);
+                    o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(va[4 + s], acc[t][s], o1, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (t + 1 < NT) {
+                    if (t + 2 < NT) {
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) {
+                            va[s] = vbase[(16 * (t + 2) + s) * RS];
+                            va[4 + s] = vbase[(16 * (t + 2) + s) * RS + 16];
+                        }
+                    }
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(vb[s], acc[t + 1][s], o0, 0, 0, 0);
+                        o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(vb[4 + s], acc[t + 1][s], o1, 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
@@ -218,6 +269,30 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_kernel(
             *reinterpret_cast<float4*>(orow + 16) = make_float4(o1[0] * inv, o1[1] * inv, o1[2] * inv, o1[3] * inv);
         }
     }
+}
+
+template <int NT, int NT_PREV>
+int launch_nt(const float* qkv, const float* qkv_bias, const float* table, float* out,
+              const WinParams& p, long blocks, hipStream_t st) {
+    const size_t lds = (size_t)(2 * NT * 16 * RS + ((p.table_len + 3) & ~3)) * sizeof(float) +
+                       2 * NT * 16 * sizeof(int);
+    if (lds > 160 * 1024) return SOC_EUNSUPPORTED;
+    static bool attr_set = false;  // per instantiation
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(win_attn3d_kernel<NT, NT_PREV, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(win_attn3d_kernel<NT, NT_PREV, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return SOC_ELAUNCH;
+        attr_set = true;
+    }
+    if (p.shifted)
+        hipLaunchKernelGGL((win_attn3d_kernel<NT, NT_PREV, true>), dim3((unsigned)blocks), dim3(THREADS), lds, st,
+                           qkv, qkv_bias, table, out, p);
+    else
+        hipLaunchKernelGGL((win_attn3d_kernel<NT, NT_PREV, false>), dim3((unsigned)blocks), dim3(THREADS), lds, st,
+                           qkv, qkv_bias, table, out, p);
+    return soc_check_launch();
 }
 
 }  // namespace
@@ -251,16 +326,13 @@ extern "C" int soc_win_attn3d_f32(const float* qkv, const float* qkv_bias, const
     p.qsplit = 1;
     while (pairs * p.qsplit < 512 && p.qsplit < 4 && (p.NT + (THREADS / 64) * p.qsplit - 1) / ((THREADS / 64) * p.qsplit) > 1)
         p.qsplit *= 2;
-    const size_t lds = (size_t)(2 * NP_MAX * RS + ((p.table_len + 3) & ~3)) * sizeof(float) + 2 * NP_MAX * sizeof(int);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(win_attn3d_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return SOC_ELAUNCH;
-        attr_set = true;
-    }
-    if (lds > 160 * 1024) return SOC_EUNSUPPORTED;
-    hipLaunchKernelGGL(win_attn3d_kernel, dim3((unsigned)(pairs * p.qsplit)), dim3(THREADS), lds,
-                       (hipStream_t)stream, qkv, qkv_bias, bias_table, out, p);
-    return soc_check_launch();
+    const long blocks = pairs * p.qsplit;
+    hipStream_t st = (hipStream_t)stream;
+    // key/query tiles are a compile-time constant (fully unrolled MFMA schedule); a window with
+    // fewer tokens runs on the next larger instantiation with the surplus keys masked out.
+    if (p.NT <= 7) return launch_nt<7, 0>(qkv, qkv_bias, bias_table, out, p, blocks, st);
+    if (p.NT <= 10) return launch_nt<10, 7>(qkv, qkv_bias, bias_table, out, p, blocks, st);
+    if (p.NT <= 13) return launch_nt<13, 10>(qkv, qkv_bias, bias_table, out, p, blocks, st);
+    if (p.NT <= 19) return launch_nt<19, 13>(qkv, qkv_bias, bias_table, out, p, blocks, st);
+    return launch_nt<25, 19>(qkv, qkv_bias, bias_table, out, p, blocks, st);
 }

@@ -9,8 +9,8 @@
 //     K and V through the scalar cache and the FMAs take them as SGPR operands -- no LDS at all;
 //   * exact two-pass softmax per key chunk (max first, then exp/accumulate), which mirrors
 //     torch.softmax as used by torch.nn.functional.multi_head_attention_forward;
-//   * few queries x many keys (lvf) are split over keys across blocks; partial (max, sum, acc)
-//     triples go to a workspace and a second kernel merges them.
+//   * few queries (decoder self-attention, VOC, lvf: L words x thousands of pixel keys) use a
+//     second mapping: one workgroup per (query, head) row, keys spread over the 256 threads.
 // q is pre-scaled by 1/sqrt(d) and padded keys get weight 0 (-inf logit), as in PyTorch.
 #include "soc_common.h"
 #include <math.h>
@@ -19,43 +19,23 @@ namespace {
 
 constexpr int HD = 32;
 
-struct Split {
-    int nsplit;
-    int keys_per_split;
-};
+// (query, b, head) rows below this count use the block-per-row mapping (few queries, any Lk)
+constexpr long ROWS_BLOCK_PATH = 8192;
 
-__host__ __device__ inline Split choose_split(int Lq, int Lk, int B, int n_heads) {
-    const long waves = (long)((Lq + 63) / 64) * B * n_heads;
-    Split s{1, Lk};
-    if (Lk >= 256 && waves < 512) {
-        int want = (int)((1024 + waves - 1) / waves);
-        int maxs = (Lk + 63) / 64;
-        int ns = want < maxs ? want : maxs;
-        if (ns < 1) ns = 1;
-        s.keys_per_split = ((Lk + ns - 1) / ns + 3) & ~3;
-        s.nsplit = (Lk + s.keys_per_split - 1) / s.keys_per_split;
-    }
-    return s;
-}
-
-// PARTIAL = false: writes normalised output.  PARTIAL = true: writes (m, l, acc[32]) per
-// (split, query, b, head) into ws.
-template <bool PARTIAL>
+// many queries: lane = query row, wave = 64 queries x one head, K/V wave-uniform (scalar cache)
 __global__ __launch_bounds__(256) void xattn_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
-    const uint8_t* __restrict__ kpm, float* __restrict__ out, float* __restrict__ ws, int Lq,
-    int Lk, int B, int H, float scale, int keys_per_split) {
+    const uint8_t* __restrict__ kpm, float* __restrict__ out, int Lq, int Lk, int B, int H,
+    float scale) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int h = blockIdx.y % H;
     const int b = blockIdx.y / H;
-    const int split = blockIdx.z;
     const int qi = (blockIdx.x * 4 + wave) * 64 + lane;
     const bool live = qi < Lq;
     const int qc = live ? qi : Lq - 1;
     const int E = H * HD;
-    const int k0 = split * keys_per_split;
-    const int k1 = min(Lk, k0 + keys_per_split);
+    const int k0 = 0, k1 = Lk;
 
     float qr[HD];
     {
@@ -100,73 +80,123 @@ __global__ __launch_bounds__(256) void xattn_kernel(
         for (int d = 0; d < HD; ++d) acc[d] += p * vr[d];
     }
     if (!live) return;
-    if (PARTIAL) {
-        float* w = ws + ((((long)split * Lq + qi) * B + b) * H + h) * (HD + 2);
-        w[0] = mx;
-        w[1] = l;
+    const float inv = 1.f / l;  // l == 0 (all keys padded) -> NaN, as torch.softmax gives
+    float4* op = reinterpret_cast<float4*>(out + ((long)qi * B + b) * E + h * HD);
 #pragma unroll
-        for (int d = 0; d < HD; ++d) w[2 + d] = acc[d];
-    } else {
-        const float inv = 1.f / l;  // l == 0 (all keys padded) -> NaN, as torch.softmax gives
-        float4* op = reinterpret_cast<float4*>(out + ((long)qi * B + b) * E + h * HD);
-#pragma unroll
-        for (int i = 0; i < HD / 4; ++i)
-            op[i] = make_float4(acc[4 * i] * inv, acc[4 * i + 1] * inv, acc[4 * i + 2] * inv,
-                                acc[4 * i + 3] * inv);
-    }
+    for (int i = 0; i < HD / 4; ++i)
+        op[i] = make_float4(acc[4 * i] * inv, acc[4 * i + 1] * inv, acc[4 * i + 2] * inv,
+                            acc[4 * i + 3] * inv);
 }
 
-// merge the per-split partials: one thread per (query, b, head, dim)
-__global__ __launch_bounds__(256) void xattn_merge_kernel(const float* __restrict__ ws,
-                                                          float* __restrict__ out, long rows,
-                                                          int nsplit) {
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= rows * HD) return;
-    const long row = idx / HD;  // (query, b, head) flat == out row of 32
-    const int d = (int)(idx % HD);
-    float mx = -INFINITY;
-    for (int s = 0; s < nsplit; ++s) mx = fmaxf(mx, ws[((long)s * rows + row) * (HD + 2)]);
-    float l = 0.f, a = 0.f;
-    for (int s = 0; s < nsplit; ++s) {
-        const float* w = ws + ((long)s * rows + row) * (HD + 2);
-        const float f = (w[0] == -INFINITY) ? 0.f : __expf(w[0] - mx);
-        l += w[1] * f;
-        a += w[2 + d] * f;
+// few queries (decoder / VOC / lvf): one 256-thread workgroup per (query, b, head) row.
+//   phase A  thread j scores keys j, j+256, ... (q broadcast, K rows read as 8 x float4) -> LDS
+//   phase B  block max / sum, p = exp(s - max) in place
+//   phase C  32 key slots x 8 lanes(float4 of V): acc4 += p[j] * V[j]; slots reduced through LDS
+__global__ __launch_bounds__(256) void xattn_row_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+    const uint8_t* __restrict__ kpm, float* __restrict__ out, int Lq, int Lk, int B, int H,
+    float scale) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* sc = lds;                       // [Lk] scores -> probabilities
+    float* red = lds + ((Lk + 3) & ~3);    // [32 slots][32 dims] partial outputs / 8 reduce words
+    const int tid = threadIdx.x;
+    const int row = blockIdx.x;            // (qi, b, h) flat, h fastest
+    const int h = row % H;
+    const int b = (row / H) % B;
+    const int qi = row / (H * B);
+    const int E = H * HD;
+    const long kstride = (long)B * E;
+    const float* kb = k + (long)b * E + h * HD;
+    const float* vb = v + (long)b * E + h * HD;
+    const uint8_t* mp = kpm ? kpm + (long)b * Lk : nullptr;
+
+    float qr[HD];
+    {
+        const float4* qp = reinterpret_cast<const float4*>(q + ((long)qi * B + b) * E + h * HD);
+#pragma unroll
+        for (int i = 0; i < HD / 4; ++i) {
+            const float4 t = qp[i];
+            qr[4 * i] = t.x * scale; qr[4 * i + 1] = t.y * scale;
+            qr[4 * i + 2] = t.z * scale; qr[4 * i + 3] = t.w * scale;
+        }
     }
-    out[row * HD + d] = a / l;
+    float mx = -INFINITY;
+    for (int j = tid; j < Lk; j += 256) {
+        float s = -INFINITY;
+        if (!(mp && mp[j])) {
+            const float4* kr = reinterpret_cast<const float4*>(kb + j * kstride);
+            s = 0.f;
+#pragma unroll
+            for (int i = 0; i < HD / 4; ++i) {
+                const float4 t = kr[i];
+                s += qr[4 * i] * t.x + qr[4 * i + 1] * t.y + qr[4 * i + 2] * t.z + qr[4 * i + 3] * t.w;
+            }
+        }
+        sc[j] = s;
+        mx = fmaxf(mx, s);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+    for (int j = tid; j < Lk; j += 256) {
+        const float s = sc[j];
+        const float e = (s == -INFINITY) ? 0.f : __expf(s - mx);
+        sc[j] = e;
+        sum += e;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if ((tid & 63) == 0) red[4 + (tid >> 6)] = sum;
+    __syncthreads();
+    sum = red[4] + red[5] + red[6] + red[7];
+    __syncthreads();  // red is reused below
+
+    const int d4 = tid & 7, slot = tid >> 3;  // 32 slots
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = slot; j < Lk; j += 32) {
+        const float p = sc[j];
+        const float4 t = *reinterpret_cast<const float4*>(vb + j * kstride + d4 * 4);
+        acc.x += p * t.x; acc.y += p * t.y; acc.z += p * t.z; acc.w += p * t.w;
+    }
+    *reinterpret_cast<float4*>(red + slot * HD + d4 * 4) = acc;
+    __syncthreads();
+    if (tid < HD) {
+        float a = 0.f;
+#pragma unroll
+        for (int s2 = 0; s2 < 32; ++s2) a += red[s2 * HD + tid];
+        out[((long)qi * B + b) * E + h * HD + tid] = a / sum;
+    }
 }
 
 }  // namespace
 
 extern "C" size_t soc_xattn_workspace_bytes(int Lq, int Lk, int B, int n_heads, int head_dim) {
-    if (Lq <= 0 || Lk <= 0 || B <= 0 || n_heads <= 0 || head_dim != HD) return 0;
-    const Split s = choose_split(Lq, Lk, B, n_heads);
-    if (s.nsplit <= 1) return 0;
-    return (size_t)s.nsplit * Lq * B * n_heads * (HD + 2) * sizeof(float);
+    (void)Lq; (void)Lk; (void)B; (void)n_heads; (void)head_dim;
+    return 0;  // ABI v1 keeps the query; no mapping of the current build needs scratch memory
 }
 
 extern "C" int soc_xattn_f32(const float* q, const float* k, const float* v,
                              const uint8_t* key_pad_mask, float* out, int Lq, int Lk, int B,
                              int n_heads, int head_dim, void* workspace, size_t workspace_bytes,
                              void* stream) {
+    (void)workspace; (void)workspace_bytes;
     if (!q || !k || !v || !out || Lq < 0 || Lk <= 0 || B <= 0 || n_heads <= 0) return SOC_EINVAL;
     if (head_dim != HD) return SOC_EUNSUPPORTED;
     if (Lq == 0) return SOC_OK;
     hipStream_t st = (hipStream_t)stream;
-    const Split s = choose_split(Lq, Lk, B, n_heads);
     const float scale = (float)sqrt(1.0 / (double)head_dim);
-    dim3 grid(soc_ceil_div(Lq, 256), B * n_heads, s.nsplit);
-    if (s.nsplit <= 1) {
-        hipLaunchKernelGGL(xattn_kernel<false>, grid, dim3(256), 0, st, q, k, v, key_pad_mask, out,
-                           (float*)nullptr, Lq, Lk, B, n_heads, scale, s.keys_per_split);
+    const long rows = (long)Lq * B * n_heads;
+    const size_t row_lds = (size_t)(((Lk + 3) & ~3) + 32 * HD) * sizeof(float);
+    if (rows <= ROWS_BLOCK_PATH && row_lds <= 64 * 1024) {
+        hipLaunchKernelGGL(xattn_row_kernel, dim3((unsigned)rows), dim3(256), row_lds, st, q, k, v,
+                           key_pad_mask, out, Lq, Lk, B, n_heads, scale);
         return soc_check_launch();
     }
-    const size_t need = soc_xattn_workspace_bytes(Lq, Lk, B, n_heads, head_dim);
-    if (!workspace || workspace_bytes < need) return SOC_EWORKSPACE;
-    hipLaunchKernelGGL(xattn_kernel<true>, grid, dim3(256), 0, st, q, k, v, key_pad_mask, out,
-                       (float*)workspace, Lq, Lk, B, n_heads, scale, s.keys_per_split);
-    const long rows = (long)Lq * B * n_heads;
-    hipLaunchKernelGGL(xattn_merge_kernel, dim3(soc_ceil_div(rows * HD, 256)), dim3(256), 0, st,
-                       (const float*)workspace, out, rows, s.nsplit);
+    dim3 grid(soc_ceil_div(Lq, 256), B * n_heads);
+    hipLaunchKernelGGL(xattn_kernel, grid, dim3(256), 0, st, q, k, v, key_pad_mask, out, Lq, Lk, B,
+                       n_heads, scale);
     return soc_check_launch();
 }

@@ -140,3 +140,19 @@ def test_c_msda_known_answers(golden, tag, tol):
     out = c_oracle.msda(g[f"{tag}_value"].astype(dt), g[f"{tag}_shapes"], g[f"{tag}_lsi"],
                         g[f"{tag}_loc"].astype(dt), g[f"{tag}_w"].astype(dt))
     assert float(np.abs(out.astype(np.float64) - g[f"{tag}_out"].astype(np.float64)).max()) < tol
+
+
+# ------------------------------------------------------------------ BASELINE config (T=8, 360x640)
+def test_forward_full_config_matches_reference(golden, synthetic_sd):
+    """Whole-forward oracle vs the reference at the BASELINE.json configuration (about 15 s)."""
+    g = golden("full_forward.npz")
+    seed, T, H, Wd, L = (int(v) for v in g["cfg"])
+    out = O.soc_forward(synthetic_sd, W.synthetic_clip(seed, T, H, Wd), W.synthetic_token_ids(seed, L),
+                        torch.ones(1, L, dtype=torch.long), (H, Wd))
+    qi, masks = O.select_query(out)
+    assert qi == int(g["selected_query"])
+    assert maxdiff(masks, g["selected_masks"]) < 1e-3
+    bits = np.packbits((out["pred_masks"] > 0).numpy().reshape(-1))
+    assert int(np.unpackbits(bits ^ g["pred_masks_signbits"]).sum()) == 0
+    assert maxdiff(out["pred_cls"], g["pred_cls"]) < 1e-4
+    assert maxdiff(out["pred_boxes"], g["pred_boxes"]) < 1e-5
