@@ -21,6 +21,7 @@
 // MFMA work per (window, head): 2 * 25 * 25 * 8 = 10 000 instructions of 2048 FLOP.
 #include "soc_common.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -31,6 +32,8 @@ constexpr int NP_MAX = NT_MAX * 16;
 constexpr int THREADS = 512;    // 8 waves, 2 per SIMD
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const float lds_cfloat;  // LDS-space pointer (ds_read, 32-bit address)
 
 struct WinParams {
     int B, D, H, W, C, nH;
@@ -44,7 +47,23 @@ struct WinParams {
     int qsplit;          // blocks per (window, head)
     int table_len;
     int shifted;
+    int stagger;         // waves 4-7 start their tile loop this many x 512 cycles late
+#ifdef SOC_K1_STAMPS
+    unsigned long long* dbg;  // diagnostic build only: [block][wave][32] s_memtime stamps
+#endif
 };
+
+#ifdef SOC_K1_STAMPS
+#define STAMP(slot)                                                                      \
+    do {                                                                                 \
+        if (lane == 0 && (slot) < 32)                                                    \
+            p.dbg[((long)blockIdx.x * 8 + wave) * 32 + (slot)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+static unsigned long long* g_dbg = nullptr;
+extern "C" void soc_debug_set_buffer(void* ptr) { g_dbg = (unsigned long long*)ptr; }
+#else
+#define STAMP(slot) do {} while (0)
+#endif
 
 __device__ __forceinline__ int region1d(int c, int P, int w, int s) {
     // reference compute_mask slices: [0,P-w) -> 0, [P-w,P-s) -> 1, [P-s,P) -> 2; shift 0 -> uniform
@@ -58,12 +77,15 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_kernel(
     const float* __restrict__ table, float* __restrict__ out, const WinParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int NP = NT * 16;
-    float* Ks = reinterpret_cast<float*>(smem_raw);           // [NP][RS]
+    float* Tb = reinterpret_cast<float*>(smem_raw);           // [table_len] bias column (x log2e)
+    float* Ks = Tb + ((p.table_len + 3) & ~3);                 // [NP][RS]
     float* Vs = Ks + NP * RS;                                  // [NP][RS]
-    float* Tb = Vs + NP * RS;                                  // [table_len]
-    int* src = reinterpret_cast<int*>(Tb + ((p.table_len + 3) & ~3));  // [NP] token offset or <0
-    int* code = src + NP;                                      // [NP] e(i) | region << 16
+    int* src = reinterpret_cast<int*>(Vs + NP * RS);           // [NP] token offset or <0
+    int* e4 = src + NP;                                        // [NP] 4 * e(i): byte offset into Tb
+    int* rgn = e4 + NP;                                        // [NP] shift-mask region id
+    int* wflag = rgn + NP;                                     // [8] per-wave "window has a mask"
 
+    constexpr float LOG2E = 1.4426950408889634f;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -76,9 +98,13 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_kernel(
     const int b = bid;
     const int C3 = 3 * p.C;
 
+    STAMP(0);
     // ---- stage 0: token metadata ------------------------------------------------------------
+    int differs = 0;  // does any token of this window sit in another shift-mask region than token 0?
+    const int reg0 = (region1d(wz * p.wd, p.Dp, p.wd, p.sd) * 3 + region1d(wy * p.wh, p.Hp, p.wh, p.sh)) * 3 +
+                     region1d(wx * p.ww, p.Wp, p.ww, p.sw);
     for (int i = tid; i < NP; i += THREADS) {
-        int s = -2, cd = 0;
+        int s = -2, ecode = 0, reg = 0;
         if (i < p.N) {
             const int dz = i / (p.wh * p.ww), r = i - dz * (p.wh * p.ww);
             const int dy = r / p.ww, dx = r - dy * p.ww;
@@ -90,16 +116,31 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_kernel(
             // relative_position_index[:N,:N]: token i is decoded with the NOMINAL window dims
             const int tz = i / (p.th * p.tw), tr = i - tz * (p.th * p.tw);
             const int ty = tr / p.tw, tx = tr - ty * p.tw;
-            const int e = (tz * (2 * p.th - 1) + ty) * (2 * p.tw - 1) + tx;
-            const int reg = (region1d(zs, p.Dp, p.wd, p.sd) * 3 + region1d(ys, p.Hp, p.wh, p.sh)) * 3 +
-                            region1d(xs, p.Wp, p.ww, p.sw);
-            cd = e | (reg << 16);
+            ecode = 4 * ((tz * (2 * p.th - 1) + ty) * (2 * p.tw - 1) + tx);
+            reg = (region1d(zs, p.Dp, p.wd, p.sd) * 3 + region1d(ys, p.Hp, p.wh, p.sh)) * 3 +
+                  region1d(xs, p.Wp, p.ww, p.sw);
         }
         src[i] = s;
-        code[i] = cd;
+        e4[i] = ecode;
+        rgn[i] = reg;
+        differs |= (i < p.N && reg != reg0);
     }
-    for (int i = tid; i < p.table_len; i += THREADS) Tb[i] = table[(long)i * p.nH + head];
+    // scores are kept in log2 units (q and the bias column are pre-multiplied by log2 e) so the
+    // softmax exponent is a bare v_exp_f32
+    for (int i = tid; i < p.table_len; i += THREADS) Tb[i] = table[(long)i * p.nH + head] * LOG2E;
+    // interior windows of a shifted block have a single region: their mask is all zero and the
+    // per-element mask arithmetic is skipped (block-uniform branch)
+    if (SHIFTED && lane == 0) wflag[wave] = 0;
+    if (SHIFTED && __any(differs) && lane == 0) wflag[wave] = 1;
     __syncthreads();
+    bool has_mask = false;
+    if (SHIFTED) {
+        int f = 0;
+#pragma unroll
+        for (int w8 = 0; w8 < THREADS / 64; ++w8) f |= wflag[w8];
+        has_mask = f != 0;
+    }
+    STAMP(1);
 
     // ---- stage 1: K, V -> LDS (float4 per thread: 8 threads per token row) --------------------
     {
@@ -133,43 +174,72 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_kernel(
         }
     }
     __syncthreads();
+    STAMP(2);
+    int stamp_slot = 3;
+    (void)stamp_slot;
 
     // ---- stage 2/3: per 16-query tile ---------------------------------------------------------
     const int r = lane & 15;   // MFMA column: query inside the tile (also A-operand row)
     const int g = lane >> 4;   // MFMA k index / C row group
-    const float scale = 0.17677669529663687f;  // 32^-0.5
-    const float LOG2E = 1.4426950408889634f;
+    const float scale = 0.17677669529663687f * LOG2E;  // 32^-0.5, in log2 units
     const int E0 = ((p.td - 1) * (2 * p.th - 1) + (p.th - 1)) * (2 * p.tw - 1) + (p.tw - 1);
     const int nwaves_total = (THREADS / 64) * p.qsplit;
     const float* kbase = Ks + r * RS + g;          // + 16t*RS + 4kk
     const float* vbase = Vs + (4 * g) * RS + r;    // + (16t + s)*RS (+16)
 
-    for (int qt = qpart * (THREADS / 64) + wave; qt < p.NT; qt += nwaves_total) {
-        const int qtok = qt * 16 + r;
-        const int qsrc = src[qtok];
-        // Q^T fragment (B operand): lane (r,g) holds q[token r][dim 4*kk+g] * scale
-        float qf[8];
+    // Q^T fragment (B operand): lane (r,g) holds q[token r][dim 4*kk+g] * scale; the next tile's
+    // fragment is fetched while the current tile is in its softmax / PV phases.
+    auto load_q = [&](int qt, float (&qf)[8], int& qsrc) {
+        qsrc = src[qt * 16 + r];
         if (qsrc >= 0) {
             const float* qrow = qkv + (long)qsrc * C3 + head * HD + g;
 #pragma unroll
-            for (int kk = 0; kk < 8; ++kk) qf[kk] = qrow[4 * kk] * scale;
+            for (int kk = 0; kk < 8; ++kk) qf[kk] = qrow[4 * kk];
         } else if (qsrc == -1) {
 #pragma unroll
-            for (int kk = 0; kk < 8; ++kk) qf[kk] = qkv_bias[head * HD + 4 * kk + g] * scale;
+            for (int kk = 0; kk < 8; ++kk) qf[kk] = qkv_bias[head * HD + 4 * kk + g];
         } else {
 #pragma unroll
             for (int kk = 0; kk < 8; ++kk) qf[kk] = 0.f;
         }
-        const int qcode = code[qtok];
-        const int qe = (qcode & 0xFFFF) + E0;
-        const int qreg = qcode >> 16;
+    };
+    float qn[8];
+    int qsrc_n = -2;
+    int qt = qpart * (THREADS / 64) + wave;
+    if (qt < p.NT) load_q(qt, qn, qsrc_n);
+    // Optional stagger of the second wave of each SIMD (waves w and w+4 share a SIMD and run the
+    // same program).  Measured null on MI355X for this kernel (SOC_K1_STAGGER=0..24: +-1 %): f32
+    // MFMA and VALU time add up rather than overlap, so de-phasing the partners buys nothing.
+    if (wave >= THREADS / 128)
+        for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(8);
+
+    for (; qt < p.NT; qt += nwaves_total) {
+        const int qtok = qt * 16 + r;
+        const int qsrc = qsrc_n;
+        float qf[8];
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) qf[kk] = qn[kk] * scale;
+        const int qe = e4[qtok] + 4 * E0;
+        const int qreg = rgn[qtok];
 
         // S^T tiles: acc[t][i] = S[query r][key 16t + 4g + i].  k-step outermost: the NT MFMAs of
         // one k-step hit NT independent accumulators (no dependent-issue stalls) and the LDS reads
         // of the next k-step overlap them.
+        // accumulators start from the relative-position bias: the LDS gather lands directly in the
+        // MFMA C operand, so the bias costs no VALU add (f32 MFMA and VALU do not overlap here --
+        // every VALU instruction saved in this loop is matrix-pipe time gained)
         f32x4 acc[NT];
+        {
+            const unsigned qaddr = (unsigned)(uintptr_t)(lds_cfloat*)Tb + (unsigned)qe;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int t = 0; t < NT; ++t) {
+                const int4 ke = *reinterpret_cast<const int4*>(e4 + 16 * t + 4 * g);
+                acc[t][0] = *(lds_cfloat*)(uintptr_t)(qaddr - (unsigned)ke.x);
+                acc[t][1] = *(lds_cfloat*)(uintptr_t)(qaddr - (unsigned)ke.y);
+                acc[t][2] = *(lds_cfloat*)(uintptr_t)(qaddr - (unsigned)ke.z);
+                acc[t][3] = *(lds_cfloat*)(uintptr_t)(qaddr - (unsigned)ke.w);
+            }
+        }
         {
             float a0[NT], a1[NT];  // K fragments, double-buffered across k-steps
 #pragma unroll
@@ -192,36 +262,51 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_kernel(
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        // bias + mask + row max (scores kept in log2 units so exp is a bare v_exp_f32)
-        float mx = -INFINITY;
+        STAMP(stamp_slot); ++stamp_slot;
+        // the K fragments are done with qf: fetch the next tile's Q now (hidden by softmax + PV)
+        if (qt + nwaves_total < p.NT) load_q(qt + nwaves_total, qn, qsrc_n);
+
+        // mask + row max + exp + row sum, all in registers (log2 units)
+        if (has_mask) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int4 kr = *reinterpret_cast<const int4*>(rgn + 16 * t + 4 * g);
+                const int krs[4] = {kr.x, kr.y, kr.z, kr.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc[t][i] = (krs[i] != qreg) ? acc[t][i] - 100.0f * LOG2E : acc[t][i];
+            }
+        }
+#pragma unroll
+        for (int t = NT_PREV; t < NT; ++t)  // surplus keys of the last tile(s)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (16 * t + 4 * g + i >= p.N) acc[t][i] = -INFINITY;
+        float mx = fmaxf(acc[0][0], acc[0][1]);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const int4 kc = *reinterpret_cast<const int4*>(code + 16 * t + 4 * g);
-            const int kcs[4] = {kc.x, kc.y, kc.z, kc.w};
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float s = acc[t][i] + Tb[qe - (kcs[i] & 0xFFFF)];
-                if (SHIFTED) s += ((kcs[i] >> 16) != qreg) ? -100.0f : 0.f;
-                if (t >= NT_PREV && 16 * t + 4 * g + i >= p.N) s = -INFINITY;  // only tiles that can hold surplus keys
-                acc[t][i] = s;
-                mx = fmaxf(mx, s);
-            }
+            if (t > 0) mx = __builtin_fmaxf(mx, fmaxf(acc[t][0], acc[t][1]));  // v_max3_f32
+            mx = __builtin_fmaxf(mx, fmaxf(acc[t][2], acc[t][3]));
         }
         mx = fmaxf(mx, __shfl_xor(mx, 16));
         mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float mxl = mx * LOG2E;
-        float sum = 0.f;
+        const f32x4 mx4 = (f32x4){mx, mx, mx, mx};
+        f32x2 sum2 = (f32x2){0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
+            const f32x4 d = acc[t] - mx4;  // 2 x v_pk_add_f32
+            f32x4 e;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float e = __builtin_amdgcn_exp2f(acc[t][i] * LOG2E - mxl);
-                acc[t][i] = e;
-                sum += e;
-            }
+            for (int i = 0; i < 4; ++i) e[i] = __builtin_amdgcn_exp2f(d[i]);
+            acc[t] = e;
+            sum2 += (f32x2){e[0], e[1]};
+            sum2 += (f32x2){e[2], e[3]};
         }
+        float sum = sum2[0] + sum2[1];
         sum += __shfl_xor(sum, 16);
         sum += __shfl_xor(sum, 32);
+        __builtin_amdgcn_s_setprio(0);
+        STAMP(stamp_slot); ++stamp_slot;
 
         // O^T = V^T . P^T : A = V[key 16t+4g+s][dim 16*dt + r], B = acc[t][s]
         f32x4 o0 = (f32x4){0.f, 0.f, 0.f, 0.f}, o1 = o0;
@@ -268,6 +353,7 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_kernel(
             *reinterpret_cast<float4*>(orow) = make_float4(o0[0] * inv, o0[1] * inv, o0[2] * inv, o0[3] * inv);
             *reinterpret_cast<float4*>(orow + 16) = make_float4(o1[0] * inv, o1[1] * inv, o1[2] * inv, o1[3] * inv);
         }
+        STAMP(stamp_slot); ++stamp_slot;
     }
 }
 
@@ -275,7 +361,7 @@ template <int NT, int NT_PREV>
 int launch_nt(const float* qkv, const float* qkv_bias, const float* table, float* out,
               const WinParams& p, long blocks, hipStream_t st) {
     const size_t lds = (size_t)(2 * NT * 16 * RS + ((p.table_len + 3) & ~3)) * sizeof(float) +
-                       2 * NT * 16 * sizeof(int);
+                       (3 * NT * 16 + 8) * sizeof(int);
     if (lds > 160 * 1024) return SOC_EUNSUPPORTED;
     static bool attr_set = false;  // per instantiation
     if (!attr_set) {
@@ -319,6 +405,15 @@ extern "C" int soc_win_attn3d_f32(const float* qkv, const float* qkv_bias, const
     p.Dp = p.nwd * win_d; p.Hp = p.nwh * win_h; p.Wp = p.nww * win_w;
     p.table_len = (2 * tab_d - 1) * (2 * tab_h - 1) * (2 * tab_w - 1);
     p.shifted = (shift_d | shift_h | shift_w) != 0;
+    static const int stagger_env = [] {
+        const char* e = getenv("SOC_K1_STAGGER");
+        return e ? atoi(e) : 0;
+    }();
+    p.stagger = stagger_env;
+#ifdef SOC_K1_STAMPS
+    p.dbg = g_dbg;
+    if (!p.dbg) return SOC_EINVAL;
+#endif
     if ((long)B * D * H * W * 3 * C >= (1L << 31)) return SOC_EUNSUPPORTED;  // int token offsets
     const long pairs = (long)B * p.nwd * p.nwh * p.nww * n_heads;
     // few (window, head) pairs (late stages): split the query tiles over more workgroups so the

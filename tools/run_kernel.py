@@ -1,0 +1,50 @@
+"""Launch one hot kernel repeatedly at a BASELINE-config geometry (for rocprofv3 --pmc passes).
+usage: python tools/run_kernel.py {k1s0|k1s1|k1s2|k1s3|msda|vlf|dyn} [reps]"""
+import sys
+
+import torch
+
+sys.path.insert(0, ".")
+from neurips2023_soc_amd import hot_ops  # noqa: E402
+
+which = sys.argv[1] if len(sys.argv) > 1 else "k1s0"
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+g = torch.Generator().manual_seed(0)
+dev = "cuda"
+if which.startswith("k1s"):
+    st = int(which[-1])
+    H, W, nH = [(90, 160, 3), (45, 80, 6), (23, 40, 12), (12, 20, 24)][st]
+    C = nH * 32
+    qkv = torch.randn(1, 8, H, W, 3 * C, generator=g).to(dev)
+    bias = torch.randn(3 * C, generator=g).to(dev)
+    table = (torch.randn(2535, nH, generator=g) * 0.2).to(dev)
+    fn = lambda: hot_ops.window_attention3d(qkv, bias, table, nH, (8, 7, 7), (4, 3, 3))  # noqa: E731
+elif which == "msda":
+    shapes = torch.tensor([[45, 80], [23, 40], [12, 20], [6, 10]])
+    lsi = torch.cat((shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]))
+    S = 4820
+    value = torch.randn(8, S, 8, 32, generator=g).to(dev)
+    loc = (torch.rand(8, S, 8, 4, 4, 2, generator=g) * 0.1 + torch.rand(8, S, 1, 1, 1, 2, generator=g) * 0.9).to(dev)
+    w = torch.softmax(torch.randn(8, S, 8, 16, generator=g), -1).view(8, S, 8, 4, 4).to(dev)
+    shapes, lsi = shapes.to(dev), lsi.to(dev)
+    fn = lambda: hot_ops.msda_forward(value, shapes, lsi, loc, w)  # noqa: E731
+elif which == "vlf":
+    q = torch.randn(28800, 1, 256, generator=g).to(dev)
+    k = torch.randn(10, 1, 256, generator=g).to(dev)
+    v = torch.randn(10, 1, 256, generator=g).to(dev)
+    fn = lambda: hot_ops.mha_core(q, k, v, 8)  # noqa: E731
+else:
+    feats = torch.randn(8, 8, 90, 160, generator=g).to(dev)
+    params = torch.randn(160, 169, generator=g).to(dev)
+    refs = torch.rand(160, 2, generator=g).to(dev)
+    fn = lambda: hot_ops.dynamic_mask(feats, params, refs, (360, 640))  # noqa: E731
+for _ in range(3):
+    fn()
+torch.cuda.synchronize()
+s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+s.record()
+for _ in range(reps):
+    fn()
+e.record()
+torch.cuda.synchronize()
+print(which, "avg us", 1e3 * s.elapsed_time(e) / reps)
