@@ -141,21 +141,31 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             from oracle import soc_oracle as O
             enc = O.build_text_encoder(sd)
-            torch.set_num_threads(os.cpu_count() or 1)
-            t1 = time.perf_counter()
-            ref = O.soc_forward(sd, clips_cpu[0], ids_cpu, torch.ones_like(ids_cpu), (H, Wd),
-                                backbone=a.backbone, text_encoder=enc)
-            cpu_s = time.perf_counter() - t1
-            n_done = 1
-            if cpu_s < 8.0:  # cheap enough: time a second, warm forward and keep the better one
+            ones = torch.ones_like(ids_cpu)
+            # pick the intra-op thread count on a small proxy clip (T=3, 250x300): more threads than
+            # the pod really owns makes torch-CPU dramatically slower (256 threads: 373 s/clip)
+            avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            proxy = W.synthetic_clip(7, 3, 250, 300)
+            best_n, best_t = 1, float("inf")
+            for n in (8, 16, 32, 64):
+                if n > avail:
+                    break
+                torch.set_num_threads(n)
                 t1 = time.perf_counter()
-                O.soc_forward(sd, clips_cpu[0], ids_cpu, torch.ones_like(ids_cpu), (H, Wd),
-                              backbone=a.backbone, text_encoder=enc)
-                cpu_s = min(cpu_s, time.perf_counter() - t1)
-                n_done = 2
-            line["cpu_baseline"] = {"value": 1.0 / cpu_s, "unit": "clips/s", "cores": torch.get_num_threads(),
-                                    "kind": "port", "sample": f"{n_done} forward(s) of the same workload "
-                                    "(oracle/soc_oracle.py, torch-CPU fp32), best time"}
+                O.soc_forward(sd, proxy, ids_cpu, ones, (250, 300), backbone=a.backbone, text_encoder=enc)
+                t = time.perf_counter() - t1
+                if t < best_t:
+                    best_n, best_t = n, t
+                if t > 1.5 * best_t:
+                    break
+            torch.set_num_threads(best_n)
+            t1 = time.perf_counter()
+            ref = O.soc_forward(sd, clips_cpu[0], ids_cpu, ones, (H, Wd), backbone=a.backbone, text_encoder=enc)
+            cpu_s = time.perf_counter() - t1
+            line["cpu_baseline"] = {"value": 1.0 / cpu_s, "unit": "clips/s", "cores": best_n, "kind": "port",
+                                    "sample": "1 forward of the same workload (oracle/soc_oracle.py, torch-CPU "
+                                              f"fp32); thread count chosen on a T=3 250x300 proxy among 8..64 "
+                                              f"(host exposes {avail} logical CPUs)"}
             got = step(0)
             torch.cuda.synchronize()
             d = (got["pred_masks"].cpu() - ref["pred_masks"]).abs().max().item()
