@@ -169,10 +169,12 @@ def main():
             got = step(0)
             torch.cuda.synchronize()
             d = (got["pred_masks"].cpu() - ref["pred_masks"]).abs().max().item()
-            flips = int(((got["pred_masks"].cpu() > 0) != (ref["pred_masks"] > 0)).sum())
+            flip = (got["pred_masks"].cpu() > 0) != (ref["pred_masks"] > 0)
             line["parity"] = {"mask_logit_max_abs_diff_vs_cpu_oracle": d,
                               "max_abs_logit": ref["pred_masks"].abs().max().item(),
-                              "thresholded_mask_flips": flips}
+                              "thresholded_mask_flips": int(flip.sum()),
+                              "max_abs_ref_logit_at_flips": float(ref["pred_masks"][flip].abs().max()) if bool(flip.any()) else 0.0,
+                              "pixels": flip.numel()}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -276,6 +276,8 @@ def build(args):
     """-> (model, criterion, postprocessor) like reference models/soc.py:624-646.  The criterion is
     training-only (out of scope) and inference callers discard it (infer_refytb.py:133): None."""
     model = SOC(args)
+    from .gemm_tuning import enable_tuned_gemms
+    enable_tuned_gemms()  # no-op without a GPU / table
     return model, None, build_postprocessors(args.dataset_name)
 
 

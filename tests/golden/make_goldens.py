@@ -241,6 +241,9 @@ def gen_full(ref, model, backbone="video-swin-t"):
          "selected_query": np.array(qi), "selected_masks": pm[:, 0, qi].numpy(),
          "pred_masks_sub": sub(pm, 1 << 17), "pred_masks_stats": stats(pm),
          "pred_masks_signbits": np.packbits((pm > 0).numpy().reshape(-1)),
+         # logits within 1e-3 of the decision boundary: the only pixels allowed to flip (fp32 noise)
+         "near_zero_idx": torch.nonzero(pm.reshape(-1).abs() < 1e-3).reshape(-1).numpy().astype(np.int32),
+         "near_zero_val": pm.reshape(-1)[pm.reshape(-1).abs() < 1e-3].numpy(),
          "ref_cpu_seconds": np.array(dt), "ref_cpu_threads": np.array(torch.get_num_threads())}
     for i in range(4):
         o = taps[f"backbone{i}"][0][0].permute(1, 0, 2, 3)

