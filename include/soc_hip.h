@@ -1,6 +1,7 @@
 /*
- * soc_hip.h -- C ABI of libsoc_hip.so: the four hand-written gfx950 (MI355X / CDNA4) kernels of
- * SOC's per-clip inference hot path (SURVEY.md section 8, rows a7 / a14 / a11+a16 / a19).
+ * soc_hip.h -- C ABI of libsoc_hip.so: the hand-written gfx950 (MI355X / CDNA4) kernels of
+ * SOC's per-clip inference hot path (SURVEY.md section 8, rows a7 / a14 / a11+a16 / a19, plus
+ * the fused add+LayerNorm of the "next" row 8f-1).
  *
  * Conventions (all entry points):
  *   - plain C, no torch types; every pointer is a DEVICE pointer unless stated otherwise;
@@ -83,8 +84,8 @@ int soc_win_attn3d_f32(const float* qkv, const float* qkv_bias, const float* bia
  *   q [Lq, B, n_heads*head_dim], k / v [Lk, B, n_heads*head_dim]
  *   key_pad_mask [B, Lk] uint8, non-zero = ignore key (may be NULL)
  *   out [Lq, B, n_heads*head_dim]
- * head_dim must be 32.  Long key sets with few queries are split over keys and need a
- * workspace of soc_xattn_workspace_bytes() bytes (may be NULL when that returns 0).
+ * head_dim must be 32.  `workspace` is reserved for mappings that need scratch memory:
+ * soc_xattn_workspace_bytes() returns 0 for every shape in this build, so NULL / 0 is fine.
  */
 size_t soc_xattn_workspace_bytes(int Lq, int Lk, int B, int n_heads, int head_dim);
 int soc_xattn_f32(const float* q, const float* k, const float* v, const uint8_t* key_pad_mask,
@@ -105,6 +106,21 @@ int soc_xattn_f32(const float* q, const float* k, const float* v, const uint8_t*
 int soc_dyn_mask_f32(const float* feats, const float* params, const float* refs, float* out,
                      int T, int Q, int C, int h, int w, float img_h, float img_w, int stride,
                      void* stream);
+
+/*
+ * K5 -- fused residual add + LayerNorm over the last dimension ("next").
+ * Replaces the add + nn.LayerNorm pairs of SwinTransformerBlock3D.forward
+ * (models/video_swin_transformer.py:219,262-272), of the deformable encoder / decoder layers
+ * (models/deformable_transformer.py:247-263,324-347) and of VOC's layers (models/voc.py:44-48,
+ * 84-94,141-153).
+ *   sum = x + y (y may be NULL); out_sum (may be NULL) receives sum;
+ *   out_norm = (sum - mean) / sqrt(var + eps) * gamma + beta      (biased variance, as torch)
+ * x, y, out_sum, out_norm: [rows, C] contiguous; gamma, beta: [C].  C % 4 == 0, C <= 2048.
+ * out_sum may alias x or y; out_norm must not alias an input.
+ */
+int soc_add_layernorm_f32(const float* x, const float* y, const float* gamma, const float* beta,
+                          float* out_sum, float* out_norm, long rows, int C, float eps,
+                          void* stream);
 
 #ifdef __cplusplus
 }

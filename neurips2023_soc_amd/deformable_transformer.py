@@ -8,9 +8,15 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from . import hot_ops
 from .attention import HipMultiheadAttention
 from .ms_deform_attn import MSDeformAttn
 from .nested_tensor import inverse_sigmoid
+
+
+def _add_norm(x, y, norm: nn.LayerNorm):
+    """post-norm residual: LayerNorm(x + y) in one pass (K5)"""
+    return hot_ops.add_layernorm(x, y, norm.weight, norm.bias, norm.eps, return_sum=False)[1]
 
 
 class DeformableTransformerEncoderLayer(nn.Module):
@@ -24,8 +30,8 @@ class DeformableTransformerEncoderLayer(nn.Module):
 
     def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None):
         a, _, _ = self.self_attn(src + pos, reference_points, src, spatial_shapes, level_start_index, padding_mask)
-        src = self.norm1(src + a)
-        return self.norm2(src + self.linear2(F.relu(self.linear1(src))))
+        src = _add_norm(src, a, self.norm1)
+        return _add_norm(src, self.linear2(F.relu(self.linear1(src))), self.norm2)
 
 
 class DeformableTransformerEncoder(nn.Module):
@@ -72,11 +78,11 @@ class DeformableTransformerDecoderLayer(nn.Module):
 
     def forward(self, tgt, query_pos, reference_points, src, spatial_shapes, level_start_index, src_padding_mask=None):
         qk = (tgt + query_pos).transpose(0, 1)  # sequence-first for the attention core
-        tgt = self.norm2(tgt + self.self_attn(qk, qk, tgt.transpose(0, 1)).transpose(0, 1))
+        tgt = _add_norm(tgt, self.self_attn(qk, qk, tgt.transpose(0, 1)).transpose(0, 1), self.norm2)
         c, loc, w = self.cross_attn(tgt + query_pos, reference_points, src, spatial_shapes,
                                     level_start_index, src_padding_mask)
-        tgt = self.norm1(tgt + c)
-        tgt = self.norm3(tgt + self.linear2(F.relu(self.linear1(tgt))))
+        tgt = _add_norm(tgt, c, self.norm1)
+        tgt = _add_norm(tgt, self.linear2(F.relu(self.linear1(tgt))), self.norm3)
         return tgt, loc, w
 
 
@@ -141,6 +147,16 @@ class DeformableTransformer(nn.Module):
         nn.init.zeros_(self.reference_points.bias)
         nn.init.normal_(self.level_embed)
 
+    def _shape_tensors(self, shapes, device):
+        """[L,2] (H,W) int64 + [L] level starts on the device, cached per geometry: a host->device
+        copy per forward would also be illegal inside a HIP-graph capture."""
+        cache = self.__dict__.setdefault("_shape_cache", {})
+        key = (shapes, str(device))
+        if key not in cache:
+            ss = torch.as_tensor(shapes, dtype=torch.long, device=device)
+            cache[key] = (ss, torch.cat((ss.new_zeros(1), ss.prod(1).cumsum(0)[:-1])))
+        return cache[key]
+
     @staticmethod
     def get_valid_ratio(mask):
         _, H, W = mask.shape
@@ -158,8 +174,7 @@ class DeformableTransformer(nn.Module):
             mflat.append(m.flatten(1))
             pflat.append(pe.flatten(2).transpose(1, 2) + self.level_embed[lvl].view(1, 1, -1))
         src, mask, pos = torch.cat(flat, 1), torch.cat(mflat, 1), torch.cat(pflat, 1)
-        spatial_shapes = torch.as_tensor(shapes, dtype=torch.long, device=src.device)
-        level_start = torch.cat((spatial_shapes.new_zeros(1), spatial_shapes.prod(1).cumsum(0)[:-1]))
+        spatial_shapes, level_start = self._shape_tensors(tuple(shapes), src.device)
         ratios = torch.stack([self.get_valid_ratio(m) for m in masks], 1)
 
         memory = self.encoder(src, spatial_shapes, level_start, ratios, pos, mask, shapes_list=shapes)

@@ -1,0 +1,60 @@
+"""HIP-graph replay of the per-clip forward (fixed clip geometry / token count).
+
+An eager forward is ~1100 kernel launches; on an MI355X the GPU needs ~16 ms for them while the
+Python/launch path needs longer, so the whole forward + query selection is captured once into a
+hipGraph (torch.cuda.CUDAGraph) and replayed per clip: one launch, no host work in the loop.
+The hand-written kernels are launched through the C ABI on torch's current stream, so they are
+captured like any other node.  Shapes are static per runner; build one runner per geometry.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from . import clip_parallel as CP
+from . import hot_ops
+from . import postprocessing as P
+from .nested_tensor import NestedTensor
+
+
+class ClipGraph:
+    def __init__(self, model, T: int, H: int, W: int, L: int, device, warmup: int = 2):
+        self.model, self.T, self.H, self.W, self.L = model, T, H, W, L
+        self.device = torch.device(device)
+        self.clip = torch.zeros(T, 1, 3, H, W, device=self.device)
+        self.pad = torch.zeros(T, 1, H, W, dtype=torch.bool, device=self.device)
+        self.ids = torch.ones(1, L, dtype=torch.long, device=self.device)
+        self.attn = torch.ones(1, L, dtype=torch.long, device=self.device)
+        self.targets = [[{"size": (H, W)}] for _ in range(T)]
+        Q = model.num_queries
+        hm, wm = -(-H // 4), -(-W // 4)
+        self.record = torch.zeros(CP.record_size(T, Q, hm, wm), device=self.device)
+        self.out: Optional[Dict[str, torch.Tensor]] = None
+        self.graph = torch.cuda.CUDAGraph()
+        assert hot_ops._prof is None, "do not capture while kernel profiling is on"
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):  # warm-up off the capture: lazy inits, algorithm finds
+            for _ in range(warmup):
+                self._forward()
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        with torch.cuda.graph(self.graph):
+            self.out = self._forward()
+
+    def _forward(self):
+        samples = NestedTensor(self.clip, self.pad)
+        out = self.model(samples, None, {"input_ids": self.ids, "attention_mask": self.attn}, self.targets)
+        idx, masks = P.select_trajectory(out)
+        CP.pack_record(self.record, idx, out["pred_cls"][:, 0, :, 0], masks)
+        return out
+
+    def run(self, clip: torch.Tensor, ids: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+        """clip [T,3,H,W] or [T,1,3,H,W] on the device; returns the static output dict (valid until
+        the next run) -- `self.record` holds the packed (query, scores, selected masks) result."""
+        self.clip.copy_(clip.view(self.clip.shape), non_blocking=True)
+        if ids is not None:
+            self.ids.copy_(ids.view(self.ids.shape), non_blocking=True)
+        self.graph.replay()
+        return self.out

@@ -188,3 +188,29 @@ def dynamic_mask(feats: Tensor, params: Tensor, refs: Tensor, img_hw: Sequence[f
                                     T, Q, Cm, h, w, float(img_hw[0]), float(img_hw[1]), stride, _stream())
     _lib.check(code, "soc_dyn_mask_f32")
     return out
+
+
+def add_layernorm(x: Tensor, y: Optional[Tensor], weight: Tensor, bias: Tensor, eps: float = 1e-5,
+                  return_sum: bool = True):
+    """K5.  (x + y, LayerNorm(x + y)) over the last dim in one pass; y may be None (plain LN).
+    Returns (sum, norm) -- sum is x itself when y is None."""
+    _need_gpu(x, y, weight, bias)
+    lib = _lib.load()
+    x = _f32c(x)
+    C = x.shape[-1]
+    rows = x.numel() // C
+    out_norm = torch.empty_like(x)
+    if y is None:
+        out_sum, y_ptr, sum_ptr = x, None, None
+    else:
+        y = _f32c(y)
+        if y.shape != x.shape:
+            raise _lib.SocHipError("add_layernorm: x and y shapes differ")
+        out_sum = torch.empty_like(x) if return_sum else None
+        y_ptr, sum_ptr = y.data_ptr(), (out_sum.data_ptr() if return_sum else None)
+    n_out = 2 if (y is not None and return_sum) else 1
+    with _timed("add_layernorm", (x.numel() * (1 + (y is not None)) + n_out * x.numel()) * 4):
+        code = lib.soc_add_layernorm_f32(x.data_ptr(), y_ptr, _f32c(weight).data_ptr(), _f32c(bias).data_ptr(),
+                                         sum_ptr, out_norm.data_ptr(), rows, C, float(eps), _stream())
+    _lib.check(code, "soc_add_layernorm_f32")
+    return out_sum, out_norm

@@ -82,6 +82,7 @@ class SwinTransformerBlock3D(nn.Module):
         self.mlp = Mlp(dim, int(dim * mlp_ratio))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """Un-fused form (used only for a stand-alone block); BasicLayer runs the fused schedule."""
         x = x + self.attn(self.norm1(x), self.shift_size)
         return x + self.mlp(self.norm2(x))
 
@@ -98,8 +99,19 @@ class BasicLayer(nn.Module):
         self.downsample = None
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:  # [B,D,H,W,C] token-major throughout
-        for blk in self.blocks:
-            x = blk(x)
+        """Every residual add is fused with the LayerNorm that consumes its result (K5):
+        x += attn -> norm2, x += mlp -> next block's norm1; same values as block-by-block."""
+        blocks = self.blocks
+        _, h = hot_ops.add_layernorm(x, None, blocks[0].norm1.weight, blocks[0].norm1.bias, blocks[0].norm1.eps)
+        for i, blk in enumerate(blocks):
+            a = blk.attn(h, blk.shift_size)
+            x, h = hot_ops.add_layernorm(x, a, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
+            m = blk.mlp(h)
+            if i + 1 < len(blocks):
+                nxt = blocks[i + 1].norm1
+                x, h = hot_ops.add_layernorm(x, m, nxt.weight, nxt.bias, nxt.eps)
+            else:
+                x = x + m
         return x
 
 
@@ -114,7 +126,8 @@ class PatchMerging(nn.Module):
         if H % 2 or W % 2:
             x = F.pad(x, (0, 0, 0, W % 2, 0, H % 2))
         x = torch.cat([x[:, :, 0::2, 0::2], x[:, :, 1::2, 0::2], x[:, :, 0::2, 1::2], x[:, :, 1::2, 1::2]], -1)
-        return self.reduction(self.norm(x))
+        _, h = hot_ops.add_layernorm(x, None, self.norm.weight, self.norm.bias, self.norm.eps)
+        return self.reduction(h)
 
 
 class PatchEmbed3D(nn.Module):

@@ -10,7 +10,12 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from . import hot_ops
 from .attention import HipMultiheadAttention
+
+
+def _add_norm(x, y, norm: nn.LayerNorm):
+    return hot_ops.add_layernorm(x, y, norm.weight, norm.bias, norm.eps, return_sum=False)[1]
 
 
 class FFNLayer(nn.Module):
@@ -21,7 +26,7 @@ class FFNLayer(nn.Module):
         self.norm = nn.LayerNorm(d_model)
 
     def forward(self, tgt):
-        return self.norm(tgt + self.linear2(F.relu(self.linear1(tgt))))
+        return _add_norm(tgt, self.linear2(F.relu(self.linear1(tgt))), self.norm)
 
 
 class SelfAttentionLayer(nn.Module):
@@ -32,7 +37,7 @@ class SelfAttentionLayer(nn.Module):
 
     def forward(self, tgt, tgt_key_padding_mask=None, query_pos=None):
         qk = tgt if query_pos is None else tgt + query_pos
-        return self.norm(tgt + self.self_attn(qk, qk, tgt, tgt_key_padding_mask))
+        return _add_norm(tgt, self.self_attn(qk, qk, tgt, tgt_key_padding_mask), self.norm)
 
 
 class CrossAttentionLayer(nn.Module):
@@ -44,7 +49,7 @@ class CrossAttentionLayer(nn.Module):
     def forward(self, tgt, memory, memory_key_padding_mask=None, pos=None, query_pos=None):
         q = tgt if query_pos is None else tgt + query_pos
         k = memory if pos is None else memory + pos
-        return self.norm(tgt + self.multihead_attn(q, k, memory, memory_key_padding_mask))
+        return _add_norm(tgt, self.multihead_attn(q, k, memory, memory_key_padding_mask), self.norm)
 
 
 class VOC(nn.Module):

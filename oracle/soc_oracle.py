@@ -497,6 +497,14 @@ def dynamic_mask_core(feats: Tensor, params: Tensor, refs: Tensor, img_hw: Tuple
     return x[:, 0]
 
 
+def add_layernorm_core(x: Tensor, y: Optional[Tensor], weight: Tensor, bias: Tensor, eps: float = 1e-5,
+                       return_sum: bool = True):
+    """Kernel-boundary form of K5: (x + y, LayerNorm(x + y)); y may be None."""
+    s = x if y is None else x + y
+    n = F.layer_norm(s, (s.shape[-1],), weight, bias, eps)
+    return (s if (return_sum or y is None) else None), n
+
+
 # ----------------------------------------------------------------------------- text
 def build_text_encoder(sd: SD):
     """HF RobertaModel (third party, as in reference models/soc.py:104) loaded from text_encoder.*"""

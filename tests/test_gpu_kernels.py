@@ -209,3 +209,28 @@ def test_kernels_bitwise_repeatable(ops):
                        ops.msda_forward(value, dev(shapes), dev(lsi), loc, w))
     f, p, r = dev(torch.randn(2, 8, 9, 11, generator=g)), dev(torch.randn(6, 169, generator=g)), dev(torch.rand(6, 2, generator=g))
     assert torch.equal(ops.dynamic_mask(f, p, r, (36, 44)), ops.dynamic_mask(f, p, r, (36, 44)))
+
+
+# ------------------------------------------------------------------ K5 fused add + LayerNorm
+@pytest.mark.parametrize("rows,C,with_y", [(115200, 96, True), (115200, 96, False), (28800, 192, True),
+                                           (38560, 256, True), (7360, 384, True), (1920, 768, True),
+                                           (479, 1536, False), (33, 1024, True), (5, 2048, True), (1, 4, True),
+                                           (0, 96, True)])
+def test_add_layernorm_vs_torch(ops, rows, C, with_y):
+    g = torch.Generator().manual_seed(rows + C)
+    x = torch.randn(rows, C, generator=g) * 3 + 1
+    y = torch.randn(rows, C, generator=g) if with_y else None
+    w, b = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    s_ref, n_ref = O.add_layernorm_core(x, y, w, b, 1e-5)
+    s, n = ops.add_layernorm(dev(x), dev(y) if with_y else None, dev(w), dev(b), 1e-5)
+    assert n.shape == (rows, C)
+    if rows:
+        assert maxdiff(n, n_ref) < 2e-5
+        assert torch.equal(s.cpu(), s_ref)          # the sum is a single fp32 add: bit-exact
+    n2 = ops.add_layernorm(dev(x), dev(y) if with_y else None, dev(w), dev(b), 1e-5, return_sum=False)[1]
+    assert torch.equal(n2, n)
+
+
+def test_add_layernorm_rejects_unsupported(ops):
+    with pytest.raises(RuntimeError):
+        ops.add_layernorm(torch.zeros(4, 6).cuda(), None, torch.zeros(6).cuda(), torch.zeros(6).cuda())

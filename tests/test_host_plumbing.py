@@ -76,6 +76,7 @@ def oracle_kernels(monkeypatch):
     monkeypatch.setattr(hot_ops, "window_attention3d", O.window_attention_core)
     monkeypatch.setattr(hot_ops, "mha_core", O.mha_core)
     monkeypatch.setattr(hot_ops, "dynamic_mask", O.dynamic_mask_core)
+    monkeypatch.setattr(hot_ops, "add_layernorm", O.add_layernorm_core)
 
 
 def run_cfg(model, g):

@@ -1,0 +1,56 @@
+"""Summarize one steady-state forward from a rocprofv3 --kernel-trace CSV.
+usage: python tools/analyze_trace.py <kernel_trace.csv> [--top N]"""
+import collections
+import csv
+import sys
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+idx = [i for i, r in enumerate(rows) if "dyn_mask" in r["Kernel_Name"]]
+seg = rows[idx[-2] + 1: idx[-1] + 1]
+t0, t1 = int(seg[0]["Start_Timestamp"]), int(seg[-1]["End_Timestamp"])
+
+
+def cat(n):
+    if any(k in n for k in ("win_attn", "msda", "xattn", "dyn_mask")):
+        return "soc_hip kernels"
+    if n.startswith("Cijk"):
+        return "GEMM (hipBLASLt/rocBLAS)"
+    if "layer_norm" in n:
+        return "layer_norm"
+    if "conv" in n.lower() or "Im2d2Col" in n or "Sp3Asm" in n or "igemm" in n.lower():
+        return "conv (MIOpen)"
+    if "direct_copy" in n or "copy" in n.lower():
+        return "copy/contiguous"
+    if "CatArray" in n:
+        return "cat"
+    if "Gelu" in n:
+        return "gelu"
+    if "elementwise" in n:
+        return "elementwise other"
+    return "other"
+
+
+agg = collections.defaultdict(lambda: [0, 0])
+names = collections.defaultdict(collections.Counter)
+big = []
+for r in seg:
+    d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    c = cat(r["Kernel_Name"])
+    agg[c][0] += d
+    agg[c][1] += 1
+    names[c][r["Kernel_Name"][:110]] += d
+    big.append((d, r["Kernel_Name"][:90], r["Grid_Size_X"]))
+busy = sum(v[0] for v in agg.values())
+print(f"last forward: {len(seg)} kernels, wall {(t1 - t0) / 1e6:.2f} ms, GPU busy {busy / 1e6:.2f} ms")
+for k, (d, n) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
+    print(f"{d / 1e6:8.3f} ms {n:5d}  {k}")
+top = int(sys.argv[sys.argv.index("--top") + 1]) if "--top" in sys.argv else 0
+if top:
+    for c in ("elementwise other", "copy/contiguous", "layer_norm", "other"):
+        print("---", c)
+        for n, d in names[c].most_common(6):
+            print(f"   {d / 1e6:7.3f} ms  {n}")
+    print("--- largest single launches")
+    for d, n, gx in sorted(big, reverse=True)[:top]:
+        print(f"   {d / 1e3:8.1f} us grid {gx:>9s}  {n}")
