@@ -142,22 +142,36 @@ def main():
                        "clips_per_rank": a.steps, "parallelism": f"clip-parallel x{world}, one result all_gather",
                        "launch": "eager" if graph is None else "hipGraph replay (one graph per clip geometry)"},
         }
+        # HBM bytes per clip from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE collected
+        # separately and corrected as MI355X_MICROARCH.md prescribes): profiles/r01_hbm_traffic_pmc.json
+        traffic = {}
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic_pmc.json")) as f:
+                traffic = {k: v["hbm_total"] for k, v in json.load(f)["per_clip_bytes"].items()}
+        except (OSError, KeyError, ValueError):
+            pass
+        default_cfg = (a.backbone, T, H, Wd) == ("video-swin-t", 8, 360, 640)
         k1 = prof.get("win_attn3d")
         if k1:
             ach = k1["work"] / (k1["ms"] * 1e-3) / 1e12
             line["roofline"] = {"kernel": "soc_win_attn3d_f32 (all 12 launches of a forward)", "bound": "mfma",
                                 "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                                "frac": ach / PEAK_F32_MFMA_TFLOPS,
+                                "traffic": traffic.get("win_attn3d") if default_cfg else None,
+                                "traffic_unit": "HBM bytes per clip (12 launches), rocprofv3 PMC, profiles/r01_hbm_traffic_pmc.json",
+                                "algorithmic_flop_per_clip": k1["work"] / a.steps,
                                 "avg_launch_us": 1e3 * k1["ms"] / k1["launches"],
                                 "ms_per_clip": k1["ms"] / a.steps}
         other = {}
-        for name in ("msda_fwd", "xattn", "dyn_mask"):
+        for name in ("msda_fwd", "xattn", "dyn_mask", "add_layernorm"):
             if name in prof:
                 r = prof[name]
                 gbs = r["work"] / (r["ms"] * 1e-3) / 1e9
                 other[name] = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                "frac": gbs / PEAK_HBM_GBS, "avg_launch_us": 1e3 * r["ms"] / r["launches"],
-                               "ms_per_clip": r["ms"] / a.steps}
+                               "ms_per_clip": r["ms"] / a.steps,
+                               "algorithmic_bytes_per_clip": r["work"] / a.steps,
+                               "traffic": traffic.get(name) if default_cfg else None}
         line["roofline_other"] = other
 
         if world == 1 and not a.no_cpu_baseline:

@@ -12,7 +12,7 @@ t0, t1 = int(seg[0]["Start_Timestamp"]), int(seg[-1]["End_Timestamp"])
 
 
 def cat(n):
-    if any(k in n for k in ("win_attn", "msda", "xattn", "dyn_mask")):
+    if any(k in n for k in ("win_attn", "msda", "xattn", "dyn_mask", "add_layernorm")):
         return "soc_hip kernels"
     if n.startswith("Cijk"):
         return "GEMM (hipBLASLt/rocBLAS)"
