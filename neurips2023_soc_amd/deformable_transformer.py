@@ -9,6 +9,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import hot_ops
+from .fused import linear_relu
 from .attention import HipMultiheadAttention
 from .ms_deform_attn import MSDeformAttn
 from .nested_tensor import inverse_sigmoid
@@ -31,7 +32,7 @@ class DeformableTransformerEncoderLayer(nn.Module):
     def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None):
         a, _, _ = self.self_attn(src + pos, reference_points, src, spatial_shapes, level_start_index, padding_mask)
         src = _add_norm(src, a, self.norm1)
-        return _add_norm(src, self.linear2(F.relu(self.linear1(src))), self.norm2)
+        return _add_norm(src, self.linear2(linear_relu(src, self.linear1)), self.norm2)
 
 
 class DeformableTransformerEncoder(nn.Module):
@@ -82,7 +83,7 @@ class DeformableTransformerDecoderLayer(nn.Module):
         c, loc, w = self.cross_attn(tgt + query_pos, reference_points, src, spatial_shapes,
                                     level_start_index, src_padding_mask)
         tgt = _add_norm(tgt, c, self.norm1)
-        tgt = _add_norm(tgt, self.linear2(F.relu(self.linear1(tgt))), self.norm3)
+        tgt = _add_norm(tgt, self.linear2(linear_relu(tgt, self.linear1)), self.norm3)
         return tgt, loc, w
 
 

@@ -11,6 +11,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import hot_ops
+from .fused import linear_relu
 from .attention import HipMultiheadAttention
 
 
@@ -26,7 +27,7 @@ class FFNLayer(nn.Module):
         self.norm = nn.LayerNorm(d_model)
 
     def forward(self, tgt):
-        return _add_norm(tgt, self.linear2(F.relu(self.linear1(tgt))), self.norm)
+        return _add_norm(tgt, self.linear2(linear_relu(tgt, self.linear1)), self.norm)
 
 
 class SelfAttentionLayer(nn.Module):

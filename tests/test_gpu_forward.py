@@ -74,6 +74,31 @@ def test_full_config_matches_reference(gpu_model, golden):
     assert maxdiff(out["pred_logit"], g["pred_logit"]) < 1e-4
 
 
+@pytest.fixture(scope="module")
+def gpu_model_b(ref_shapes):
+    shapes = {k: v[0] for k, v in ref_shapes("b").items() if v[1].startswith("float")}
+    model, _, _ = S.build_model(S.default_args("video-swin-b", text_encoder_random_init=True))
+    model.load_state_dict(W.synthetic_state_dict(shapes, seed=2023), strict=False)
+    return model.cuda().eval()
+
+
+@pytest.mark.parametrize("fixture", ["full_forward_b.npz", "full_forward_b720.npz"])
+def test_swin_b_configs_match_reference(gpu_model_b, golden, fixture):
+    """BASELINE configs 4/5: Video-Swin-B at 360x640 and at 720x1280 (S = 19 160, 180x320 masks)."""
+    g = golden(fixture)
+    out = run_cfg(gpu_model_b, g["cfg"])
+    idx, masks = P.select_trajectory(out)
+    assert int(idx) == int(g["selected_query"])
+    d = maxdiff(masks, g["selected_masks"])
+    dsub = maxdiff(sub(out["pred_masks"], 1 << 17), g["pred_masks_sub"])
+    print(fixture, "max|dlogit| selected", d, "all(sub)", dsub, "of", g["pred_masks_stats"][2])
+    assert d < 1e-3 and dsub < 1e-3
+    flip = (masks.cpu().numpy() > 0) != (g["selected_masks"] > 0)
+    assert flip.sum() <= 8 and (not flip.any() or np.abs(g["selected_masks"][flip]).max() < 2.5e-4)
+    assert maxdiff(out["pred_cls"], g["pred_cls"]) < 1e-4
+    assert maxdiff(out["pred_boxes"], g["pred_boxes"]) < 1e-5
+
+
 def test_t10_temporal_shift_matches_reference(gpu_model, golden):
     g = golden("t10_forward.npz")
     out = run_cfg(gpu_model, g["cfg"])

@@ -33,6 +33,12 @@ elif which == "vlf":
     k = torch.randn(10, 1, 256, generator=g).to(dev)
     v = torch.randn(10, 1, 256, generator=g).to(dev)
     fn = lambda: hot_ops.mha_core(q, k, v, 8)  # noqa: E731
+elif which.startswith("ln"):
+    rows, C = {"ln0": (115200, 96), "ln1": (28800, 192), "lnenc": (38560, 256), "ln2": (7360, 384)}[which]
+    x = torch.randn(rows, C, generator=g).to(dev)
+    y = torch.randn(rows, C, generator=g).to(dev)
+    w, b = torch.randn(C, generator=g).to(dev), torch.randn(C, generator=g).to(dev)
+    fn = lambda: hot_ops.add_layernorm(x, y, w, b)  # noqa: E731
 else:
     feats = torch.randn(8, 8, 90, 160, generator=g).to(dev)
     params = torch.randn(160, 169, generator=g).to(dev)
