@@ -123,3 +123,29 @@ def test_upsample_threshold_on_device(gpu_model, golden):
     up = P.upsample_and_threshold(m, (720, 1280))
     ref = P.upsample_and_threshold(m.cpu(), (720, 1280))
     assert float((up.cpu() != ref).float().mean()) < 1e-5
+
+
+def test_hip_graph_replay_matches_eager(gpu_model, golden):
+    """ClipGraph (hipGraph capture of forward + query selection) reproduces the eager forward and
+    the packed result record on two different clips replayed through the same graph."""
+    from neurips2023_soc_amd import clip_parallel as CP
+    from neurips2023_soc_amd.graph_runner import ClipGraph
+    T, H, Wd, L = 3, 250, 300, 10
+    runner = ClipGraph(gpu_model, T, H, Wd, L, "cuda")
+    for seed in (7, 8):
+        clip = W.synthetic_clip(seed, T, H, Wd).cuda()
+        ids = W.synthetic_token_ids(seed, L).cuda()
+        out = runner.run(clip, ids)
+        torch.cuda.synchronize()
+        rec = runner.record.clone()
+        samples = S.nested_tensor_from_videos_list([clip])
+        eager = gpu_model(samples, None, {"input_ids": ids, "attention_mask": torch.ones_like(ids)},
+                          [[{"size": (H, Wd)}]] * T)
+        assert maxdiff(out["pred_masks"], eager["pred_masks"].cpu()) < 5e-4
+        q, cls, masks = CP.unpack_record(rec.cpu(), T, 20, 63, 75)
+        idx, emasks = P.select_trajectory(eager)
+        assert q == int(idx)
+        assert maxdiff(masks, emasks.cpu()) < 5e-4
+    g = golden("tiny_forward.npz")   # seed 7 is the tiny golden clip
+    out = runner.run(W.synthetic_clip(7, T, H, Wd).cuda(), W.synthetic_token_ids(7, L).cuda())
+    assert maxdiff(out["pred_masks"], g["pred_masks"]) < 1e-3
