@@ -56,6 +56,26 @@ int soc_msda_fwd_f64(const double* value, const int64_t* spatial_shapes,
                      int Lq, int P, void* stream);
 
 /*
+ * K2 (fused form) -- the same sampling core with the arithmetic MSDeformAttn.forward wraps around
+ * it folded in (models/ops/modules/ms_deform_attn.py:95-112): softmax over the L*P attention
+ * logits, sampling locations from reference points + raw offsets, and the value padding mask.
+ *   value          [N, S, M, D]  value_proj output, NOT yet masked
+ *   value_pad_mask [N, S] uint8 (non-zero = padded position samples as 0) and any_pad (one int32 in
+ *                  device memory, non-zero iff the mask has any padding): both NULL or both set
+ *   ref_points     [N, Lq, L, ref_dim], ref_dim 2: loc = ref + off / (W_l, H_l)
+ *                                       ref_dim 4: loc = ref_xy + off / P * ref_wh * 0.5
+ *   offsets        [N, Lq, M, L, P, 2]  raw sampling_offsets Linear output
+ *   attn_logits    [N, Lq, M, L*P]      raw attention_weights Linear output (softmax in-kernel)
+ * Built for D = 32, L = 4, P = 4 (every shipped config); other shapes: SOC_EUNSUPPORTED, use
+ * soc_msda_fwd_f32.
+ */
+int soc_msda_fused_fwd_f32(const float* value, const uint8_t* value_pad_mask, const int32_t* any_pad,
+                           const int64_t* spatial_shapes, const int64_t* level_start_index,
+                           const float* ref_points, int ref_dim, const float* offsets,
+                           const float* attn_logits, float* out, int N, int S, int M, int D, int L,
+                           int Lq, int P, void* stream);
+
+/*
  * K1 -- 3-D (shifted) window attention with relative position bias, fused with the
  * pad / cyclic-roll / window-partition / reverse / un-roll / crop index math.
  * Replaces WindowAttention3D.forward between `qkv` and `proj`

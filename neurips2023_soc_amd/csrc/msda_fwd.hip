@@ -32,11 +32,18 @@ __device__ __forceinline__ void fma4(float4& a, float w, const float4& v) {
     a.x += w * v.x; a.y += w * v.y; a.z += w * v.z; a.w += w * v.w;
 }
 
+// FUSED = true additionally folds in what MSDeformAttn.forward does around the op (reference
+// models/ops/modules/ms_deform_attn.py:95-112): `loc` then holds the RAW sampling offsets and `attw`
+// the RAW attention logits; the kernel computes softmax over the L*P = 16 logits, the sampling
+// locations ref + off / (W_l, H_l)  (2-d refs) or ref_xy + off / P * ref_wh * 0.5  (4-d refs), and
+// applies the value padding mask per tap (only when the device-side flag says padding exists).
+template <bool FUSED>
 __global__ __launch_bounds__(256) void msda_fwd_d32p4_kernel(
     const float* __restrict__ value, const int64_t* __restrict__ shapes,
     const int64_t* __restrict__ lsi, const float* __restrict__ loc,
     const float* __restrict__ attw, float* __restrict__ out, int N, int S, int M, int L, int Lq,
-    int groups_per_frame /* = Lq*M */) {
+    int groups_per_frame /* = Lq*M */, const float* __restrict__ ref, int ref_dim,
+    const uint8_t* __restrict__ pad, const int* __restrict__ any_pad) {
     const int n = blockIdx.x % N;        // XCD-friendly: blocks b, b+8, ... share an XCD
     const int chunk = blockIdx.x / N;
     const int sub = threadIdx.x >> 3;    // 32 (query, head) groups per block
@@ -50,14 +57,55 @@ __global__ __launch_bounds__(256) void msda_fwd_d32p4_kernel(
     const float* vbase = value + (long)n * S * M * 32 + m * 32 + c4 * 4;
     const int rstride = M * 32;  // floats between consecutive spatial positions
 
+    // FUSED: softmax over the 16 logits of this (query, head) -- L == 4 is enforced by the host
+    float4 sm[4];
+    bool use_pad = false;
+    const float* rp = nullptr;
+    const uint8_t* padn = nullptr;
+    if (FUSED) {
+#pragma unroll
+        for (int l = 0; l < 4; ++l) sm[l] = wp[l];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int l = 0; l < 4; ++l) mx = fmaxf(mx, fmaxf(fmaxf(sm[l].x, sm[l].y), fmaxf(sm[l].z, sm[l].w)));
+        float sum = 0.f;
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            sm[l].x = __expf(sm[l].x - mx); sm[l].y = __expf(sm[l].y - mx);
+            sm[l].z = __expf(sm[l].z - mx); sm[l].w = __expf(sm[l].w - mx);
+            sum += (sm[l].x + sm[l].y) + (sm[l].z + sm[l].w);
+        }
+        const float inv = 1.f / sum;
+#pragma unroll
+        for (int l = 0; l < 4; ++l) { sm[l].x *= inv; sm[l].y *= inv; sm[l].z *= inv; sm[l].w *= inv; }
+        rp = ref + ((long)n * Lq + g / M) * (long)(L * ref_dim);
+        use_pad = pad != nullptr && any_pad != nullptr && *any_pad != 0;  // wave-uniform
+        padn = pad + (long)n * S;
+    }
+
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int l = 0; l < L; ++l) {
         const int Hl = (int)shapes[2 * l], Wl = (int)shapes[2 * l + 1];
-        const float* vl = vbase + (long)lsi[l] * rstride;
+        const int lstart = (int)lsi[l];
+        const float* vl = vbase + (long)lstart * rstride;
         const float4 la = lp[2 * l], lb = lp[2 * l + 1];
-        const float4 wv = wp[l];
-        const float xs[4] = {la.x, la.z, lb.x, lb.z};
-        const float ys[4] = {la.y, la.w, lb.y, lb.w};
+        const float4 wv = FUSED ? sm[l & 3] : wp[l];
+        float xs[4] = {la.x, la.z, lb.x, lb.z};
+        float ys[4] = {la.y, la.w, lb.y, lb.w};
+        if (FUSED) {
+            const float rx = rp[l * ref_dim], ry = rp[l * ref_dim + 1];
+            if (ref_dim == 2) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) { xs[p] = rx + xs[p] / (float)Wl; ys[p] = ry + ys[p] / (float)Hl; }
+            } else {
+                const float rw = rp[l * ref_dim + 2], rh = rp[l * ref_dim + 3];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    xs[p] = rx + xs[p] / 4.0f * rw * 0.5f;
+                    ys[p] = ry + ys[p] / 4.0f * rh * 0.5f;
+                }
+            }
+        }
         const float ws[4] = {wv.x, wv.y, wv.z, wv.w};
         float tw[4][4];
         const float* ptr[4][4];
@@ -85,6 +133,12 @@ __global__ __launch_bounds__(256) void msda_fwd_d32p4_kernel(
             ptr[p][1] = vl + (long)(h0c * Wl + w1c) * rstride;
             ptr[p][2] = vl + (long)(h1c * Wl + w0c) * rstride;
             ptr[p][3] = vl + (long)(h1c * Wl + w1c) * rstride;
+            if (FUSED && use_pad) {  // value.masked_fill(padding_mask, 0): a padded position samples 0
+                if (padn[lstart + h0c * Wl + w0c]) tw[p][0] = 0.f;
+                if (padn[lstart + h0c * Wl + w1c]) tw[p][1] = 0.f;
+                if (padn[lstart + h1c * Wl + w0c]) tw[p][2] = 0.f;
+                if (padn[lstart + h1c * Wl + w1c]) tw[p][3] = 0.f;
+            }
         }
         float4 tv[4][4];
 #pragma unroll
@@ -174,9 +228,10 @@ extern "C" int soc_msda_fwd_f32(const float* value, const int64_t* spatial_shape
     if (D == 32 && P == 4) {
         const int gpf = Lq * M;
         const int bpf = soc_ceil_div(gpf, 32);
-        hipLaunchKernelGGL(msda_fwd_d32p4_kernel, dim3(bpf * N), dim3(256), 0, st, value,
+        hipLaunchKernelGGL(msda_fwd_d32p4_kernel<false>, dim3(bpf * N), dim3(256), 0, st, value,
                            spatial_shapes, level_start_index, sampling_loc, attn_weight, out, N,
-                           S, M, L, Lq, gpf);
+                           S, M, L, Lq, gpf, (const float*)nullptr, 0, (const uint8_t*)nullptr,
+                           (const int*)nullptr);
         return soc_check_launch();
     }
     return launch_generic<float>(value, spatial_shapes, level_start_index, sampling_loc,
@@ -193,4 +248,24 @@ extern "C" int soc_msda_fwd_f64(const double* value, const int64_t* spatial_shap
         return SOC_EINVAL;
     return launch_generic<double>(value, spatial_shapes, level_start_index, sampling_loc,
                                   attn_weight, out, N, S, M, D, L, Lq, P, (hipStream_t)stream);
+}
+
+extern "C" int soc_msda_fused_fwd_f32(const float* value, const uint8_t* value_pad_mask,
+                                      const int32_t* any_pad, const int64_t* spatial_shapes,
+                                      const int64_t* level_start_index, const float* ref_points,
+                                      int ref_dim, const float* offsets, const float* attn_logits,
+                                      float* out, int N, int S, int M, int D, int L, int Lq, int P,
+                                      void* stream) {
+    if (N == 0 || Lq == 0) return (N < 0 || Lq < 0) ? SOC_EINVAL : SOC_OK;
+    if (bad_args(value, spatial_shapes, level_start_index, offsets, attn_logits, out, N, S, M, D, L, Lq, P) ||
+        !ref_points)
+        return SOC_EINVAL;
+    if (D != 32 || P != 4 || L != 4 || (ref_dim != 2 && ref_dim != 4)) return SOC_EUNSUPPORTED;
+    if ((value_pad_mask == nullptr) != (any_pad == nullptr)) return SOC_EINVAL;
+    const int gpf = Lq * M;
+    const int bpf = soc_ceil_div(gpf, 32);
+    hipLaunchKernelGGL(msda_fwd_d32p4_kernel<true>, dim3(bpf * N), dim3(256), 0, (hipStream_t)stream, value,
+                       spatial_shapes, level_start_index, offsets, attn_logits, out, N, S, M, L, Lq, gpf,
+                       ref_points, ref_dim, value_pad_mask, (const int*)any_pad);
+    return soc_check_launch();
 }

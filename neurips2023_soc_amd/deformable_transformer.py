@@ -29,8 +29,10 @@ class DeformableTransformerEncoderLayer(nn.Module):
         self.linear2 = nn.Linear(d_ffn, d_model)
         self.norm2 = nn.LayerNorm(d_model)
 
-    def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None):
-        a, _, _ = self.self_attn(src + pos, reference_points, src, spatial_shapes, level_start_index, padding_mask)
+    def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None,
+                pad_flag=None):
+        a, _, _ = self.self_attn(src + pos, reference_points, src, spatial_shapes, level_start_index, padding_mask,
+                                 pad_flag=pad_flag, return_sampling=False)
         src = _add_norm(src, a, self.norm1)
         return _add_norm(src, self.linear2(linear_relu(src, self.linear1)), self.norm2)
 
@@ -58,11 +60,11 @@ class DeformableTransformerEncoder(nn.Module):
         return torch.cat(pts, 1)[:, :, None] * valid_ratios[:, None]
 
     def forward(self, src, spatial_shapes, level_start_index, valid_ratios, pos=None, padding_mask=None,
-                shapes_list=None):
+                shapes_list=None, pad_flag=None):
         ref = self.get_reference_points(shapes_list if shapes_list is not None else spatial_shapes,
                                         valid_ratios, src.device)
         for layer in self.layers:
-            src = layer(src, pos, ref, spatial_shapes, level_start_index, padding_mask)
+            src = layer(src, pos, ref, spatial_shapes, level_start_index, padding_mask, pad_flag)
         return src
 
 
@@ -77,11 +79,12 @@ class DeformableTransformerDecoderLayer(nn.Module):
         self.linear2 = nn.Linear(d_ffn, d_model)
         self.norm3 = nn.LayerNorm(d_model)
 
-    def forward(self, tgt, query_pos, reference_points, src, spatial_shapes, level_start_index, src_padding_mask=None):
+    def forward(self, tgt, query_pos, reference_points, src, spatial_shapes, level_start_index, src_padding_mask=None,
+                pad_flag=None):
         qk = (tgt + query_pos).transpose(0, 1)  # sequence-first for the attention core
         tgt = _add_norm(tgt, self.self_attn(qk, qk, tgt.transpose(0, 1)).transpose(0, 1), self.norm2)
         c, loc, w = self.cross_attn(tgt + query_pos, reference_points, src, spatial_shapes,
-                                    level_start_index, src_padding_mask)
+                                    level_start_index, src_padding_mask, pad_flag=pad_flag, return_sampling=False)
         tgt = _add_norm(tgt, c, self.norm1)
         tgt = _add_norm(tgt, self.linear2(linear_relu(tgt, self.linear1)), self.norm3)
         return tgt, loc, w
@@ -96,7 +99,7 @@ class DeformableTransformerDecoder(nn.Module):
         self.class_embed = None
 
     def forward(self, tgt, reference_points, src, spatial_shapes, level_start_index, valid_ratios,
-                query_pos=None, src_padding_mask=None):
+                query_pos=None, src_padding_mask=None, pad_flag=None):
         out = tgt
         inter, inter_refs = [], []
         for lid, layer in enumerate(self.layers):
@@ -104,7 +107,8 @@ class DeformableTransformerDecoder(nn.Module):
                 ref_in = reference_points[:, :, None] * torch.cat([valid_ratios, valid_ratios], -1)[:, None]
             else:
                 ref_in = reference_points[:, :, None] * valid_ratios[:, None]
-            out, _, _ = layer(out, query_pos, ref_in, src, spatial_shapes, level_start_index, src_padding_mask)
+            out, _, _ = layer(out, query_pos, ref_in, src, spatial_shapes, level_start_index, src_padding_mask,
+                              pad_flag)
             # (the reference's top-30 sample bookkeeping :383-389 feeds nothing in SOC.forward)
             if self.bbox_embed is not None:
                 delta = self.bbox_embed[lid](out)
@@ -178,13 +182,18 @@ class DeformableTransformer(nn.Module):
         spatial_shapes, level_start = self._shape_tensors(tuple(shapes), src.device)
         ratios = torch.stack([self.get_valid_ratio(m) for m in masks], 1)
 
-        memory = self.encoder(src, spatial_shapes, level_start, ratios, pos, mask, shapes_list=shapes)
+        # one device-side flag "is there any padding" lets K2 skip the per-tap mask test without a
+        # host sync (single-video batches never pad)
+        pad_flag = mask.any().to(torch.int32).reshape(1) if mask.is_cuda else None
+        memory = self.encoder(src, spatial_shapes, level_start, ratios, pos, mask, shapes_list=shapes,
+                              pad_flag=pad_flag)
 
         b, t, q, c = tgt.shape
         tgt = tgt.reshape(b * t, q, c)
         qpos = query_embed.unsqueeze(0).expand(b * t, -1, -1)
         ref = self.reference_points(qpos).sigmoid()
-        hs, inter_refs, inter_samples = self.decoder(tgt, ref, memory, spatial_shapes, level_start, ratios, qpos, mask)
+        hs, inter_refs, inter_samples = self.decoder(tgt, ref, memory, spatial_shapes, level_start, ratios, qpos, mask,
+                                                     pad_flag)
 
         maps, at = [], 0
         for (h, w) in shapes[:self.num_feature_level - 1]:

@@ -108,6 +108,35 @@ def msda_forward(value: Tensor, spatial_shapes: Tensor, level_start_index: Tenso
     return out
 
 
+def msda_fused_forward(value: Tensor, spatial_shapes: Tensor, level_start_index: Tensor,
+                       reference_points: Tensor, offsets: Tensor, logits: Tensor,
+                       pad_mask: Optional[Tensor] = None, any_pad: Optional[Tensor] = None) -> Tensor:
+    """K2 fused form.  value [N,S,M,32] (un-masked), reference_points [N,Lq,4,2|4], offsets
+    [N,Lq,M,4,4,2] raw, logits [N,Lq,M,16] raw, pad_mask [N,S] bool/uint8 + any_pad int32[1]
+    (both or neither) -> [N,Lq,M*32]."""
+    _need_gpu(value, spatial_shapes, level_start_index, reference_points, offsets, logits, pad_mask, any_pad)
+    lib = _lib.load()
+    value, reference_points, offsets, logits = (_f32c(x) for x in (value, reference_points, offsets, logits))
+    N, S, M, D = value.shape
+    Lq, L, rd = reference_points.shape[1], reference_points.shape[2], reference_points.shape[3]
+    P = offsets.shape[4]
+    out = torch.empty((N, Lq, M * D), dtype=torch.float32, device=value.device)
+    pm_ptr = ap_ptr = None
+    if pad_mask is not None:
+        pm = pad_mask.to(torch.uint8).contiguous() if pad_mask.dtype != torch.uint8 else pad_mask.contiguous()
+        if any_pad is None or any_pad.dtype != torch.int32:
+            raise _lib.SocHipError("msda_fused_forward: pad_mask needs an int32 any_pad flag tensor")
+        pm_ptr, ap_ptr = pm.data_ptr(), any_pad.data_ptr()
+    work = (value.numel() + offsets.numel() + logits.numel() + out.numel()) * 4
+    with _timed("msda_fwd", work):
+        code = lib.soc_msda_fused_fwd_f32(value.data_ptr(), pm_ptr, ap_ptr, spatial_shapes.data_ptr(),
+                                          level_start_index.data_ptr(), reference_points.data_ptr(), rd,
+                                          offsets.data_ptr(), logits.data_ptr(), out.data_ptr(),
+                                          N, S, M, D, L, Lq, P, _stream())
+    _lib.check(code, "soc_msda_fused_fwd_f32")
+    return out
+
+
 def clamp_window(size: Sequence[int], window: Sequence[int], shift: Sequence[int]):
     """get_window_size of the reference (models/video_swin_transformer.py:71-84)."""
     w, s = list(window), list(shift)

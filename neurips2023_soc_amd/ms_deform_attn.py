@@ -68,11 +68,22 @@ class MSDeformAttn(nn.Module):
         nn.init.zeros_(self.output_proj.bias)
 
     def forward(self, query, reference_points, input_flatten, input_spatial_shapes,
-                input_level_start_index, input_padding_mask=None):
+                input_level_start_index, input_padding_mask=None, pad_flag=None, return_sampling=True):
+        """Reference signature plus two optional arguments used by this package's own layers:
+        ``return_sampling=False`` (SOC never reads the sampling locations / weights) allows the fused
+        kernel, which needs ``pad_flag`` = int32[1] device tensor "the padding mask has any True"."""
         N, Lq, _ = query.shape
         _, S, _ = input_flatten.shape
         M, L, P = self.n_heads, self.n_levels, self.n_points
         value = self.value_proj(input_flatten)
+        if (not return_sampling and value.is_cuda and L == 4 and P == 4 and self.d_model // M == 32
+                and reference_points.shape[-1] in (2, 4)
+                and (input_padding_mask is None or pad_flag is not None)):
+            out = hot_ops.msda_fused_forward(
+                value.view(N, S, M, 32), input_spatial_shapes, input_level_start_index, reference_points,
+                self.sampling_offsets(query).view(N, Lq, M, L, P, 2),
+                self.attention_weights(query).view(N, Lq, M, L * P), input_padding_mask, pad_flag)
+            return self.output_proj(out), None, None
         if input_padding_mask is not None:
             value = value.masked_fill(input_padding_mask[..., None], 0.0)
         value = value.view(N, S, M, self.d_model // M)

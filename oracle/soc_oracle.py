@@ -314,6 +314,23 @@ def msda_core(value: Tensor, shapes: Tensor, level_start: Tensor, loc: Tensor, w
     return out.view(N, Lq, M * D)
 
 
+def msda_fused_core(value: Tensor, shapes: Tensor, level_start: Tensor, ref: Tensor, offsets: Tensor,
+                    logits: Tensor, pad_mask: Optional[Tensor] = None) -> Tensor:
+    """Kernel-boundary form of the fused K2 entry point: what MSDeformAttn.forward does between
+    value_proj and output_proj (reference models/ops/modules/ms_deform_attn.py:95-114)."""
+    N, S, M, D = value.shape
+    _, Lq, _, L, P, _ = offsets.shape
+    if pad_mask is not None:
+        value = value.masked_fill(pad_mask.bool()[:, :, None, None], 0.0)
+    aw = torch.softmax(logits.view(N, Lq, M, L * P), -1).view(N, Lq, M, L, P)
+    if ref.shape[-1] == 2:
+        norm = torch.stack([shapes[:, 1], shapes[:, 0]], -1).to(value.dtype)
+        loc = ref[:, :, None, :, None, :] + offsets / norm[None, None, None, :, None, :]
+    else:
+        loc = ref[:, :, None, :, None, :2] + offsets / P * ref[:, :, None, :, None, 2:] * 0.5
+    return msda_core(value.contiguous(), shapes, level_start, loc.contiguous(), aw.contiguous())
+
+
 def msda_module(sd: SD, p: str, query: Tensor, ref: Tensor, src: Tensor, shapes: Tensor,
                 level_start: Tensor, pad_mask: Optional[Tensor]) -> Tensor:
     """reference MSDeformAttn.forward models/ops/modules/ms_deform_attn.py:79-117"""

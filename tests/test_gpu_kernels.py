@@ -234,3 +234,30 @@ def test_add_layernorm_vs_torch(ops, rows, C, with_y):
 def test_add_layernorm_rejects_unsupported(ops):
     with pytest.raises(RuntimeError):
         ops.add_layernorm(torch.zeros(4, 6).cuda(), None, torch.zeros(6).cuda(), torch.zeros(6).cuda())
+
+
+# ------------------------------------------------------------------ K2 fused form
+@pytest.mark.parametrize("N,Lq,rd,padding", [(8, 4820, 2, False), (3, 77, 2, True), (2, 20, 4, True), (2, 20, 4, False)])
+def test_msda_fused_vs_oracle(ops, N, Lq, rd, padding):
+    g = torch.Generator().manual_seed(N * 100 + Lq + rd)
+    shapes = torch.tensor([[45, 80], [23, 40], [12, 20], [6, 10]]) if Lq == 4820 else torch.tensor([[9, 7], [5, 4], [3, 2], [1, 1]])
+    lsi = torch.cat((shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]))
+    S, M = int(shapes.prod(1).sum()), 8
+    value = torch.randn(N, S, M, 32, generator=g)
+    ref = torch.rand(N, Lq, 4, rd, generator=g)
+    if rd == 4:
+        ref[..., 2:] *= 0.5
+    off = torch.randn(N, Lq, M, 4, 4, 2, generator=g) * 3
+    logits = torch.randn(N, Lq, M, 16, generator=g)
+    pad = None
+    if padding:
+        pad = torch.rand(N, S, generator=g) < 0.3
+    want = O.msda_fused_core(value, shapes, lsi, ref, off, logits, pad)
+    flag = dev(pad.any().to(torch.int32).reshape(1)) if padding else None
+    got = ops.msda_fused_forward(dev(value), dev(shapes), dev(lsi), dev(ref), dev(off), dev(logits),
+                                 dev(pad) if padding else None, flag)
+    assert maxdiff(got, want) < 3e-5
+    if padding:  # flag == 0 must switch the mask off entirely
+        got0 = ops.msda_fused_forward(dev(value), dev(shapes), dev(lsi), dev(ref), dev(off), dev(logits),
+                                      dev(pad), torch.zeros(1, dtype=torch.int32).cuda())
+        assert maxdiff(got0, O.msda_fused_core(value, shapes, lsi, ref, off, logits, None)) < 3e-5
