@@ -153,6 +153,13 @@ class SOC(nn.Module):
             nn.init.xavier_uniform_(layer.weight)
         self.vl_loss, self.aux_loss = config.vl_loss, config.aux_loss
 
+    def _side_stream(self, device):
+        streams = self.__dict__.setdefault("_streams", {})
+        key = str(device)
+        if key not in streams:
+            streams[key] = torch.cuda.Stream(device=device)
+        return streams[key]
+
     # ------------------------------------------------------------------ text
     def forward_text(self, text_queries, device):
         """list[str] (needs tokenizer files) or pre-tokenised {'input_ids','attention_mask'} [B,L]."""
@@ -195,10 +202,22 @@ class SOC(nn.Module):
             raise NotImplementedError("valid_indices is only used by the A2D/JHMDB loaders "
                                       "(reference soc.py:208-215), outside the inference hot path")
         device = samples.tensors.device
-        text, sentence = self.forward_text(text_queries, device)
+        # The text branch (RoBERTa: ~150 latency-bound launches on 10 tokens) and the video backbone
+        # are independent until the first vision-language fusion: run them on two HIP streams so the
+        # small text kernels hide under the Swin kernels (also captured as a fork/join in ClipGraph).
+        side = self._side_stream(device) if device.type == "cuda" else None
+        if side is not None:
+            main = torch.cuda.current_stream(device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                text, sentence = self.forward_text(text_queries, device)
+            backbone_out, pos = self.backbone(samples)   # rewrites samples to '(b t)' like the reference
+            main.wait_stream(side)
+        else:
+            text, sentence = self.forward_text(text_queries, device)
+            backbone_out, pos = self.backbone(samples)
         words, word_pad = text.decompose()
         B = words.shape[1]
-        backbone_out, pos = self.backbone(samples)   # rewrites samples to '(b t)' like the reference
         T = pos[0].shape[0] // B
         text_pos = self.text_pos(text).permute(2, 0, 1)
 
