@@ -169,9 +169,10 @@ class DeformableTransformer(nn.Module):
         vw = (~mask[:, 0, :]).sum(1).float() / W
         return torch.stack([vw, vh], -1)
 
-    def forward(self, srcs, tgt, masks, pos_embeds, query_embed=None):
-        """srcs/masks/pos per level '(b t) c h w'; tgt [b,t,q,c]; query_embed [q,c]
-        -> hs [l,(b t),q,c], memory maps, init_ref [(b t),q,2], inter_refs [l,(b t),q,4], None, None, None"""
+    def encode(self, srcs, masks, pos_embeds):
+        """Flatten the levels and run the deformable encoder.  Returns (memory maps of the 3 finest
+        levels as '(b t) c h w', context for decode()).  Split from forward() so that SOC can run the
+        FPN spatial decoder (needs only the maps) concurrently with the query decoder."""
         flat, mflat, pflat, shapes = [], [], [], []
         for lvl, (s, m, pe) in enumerate(zip(srcs, masks, pos_embeds)):
             shapes.append(tuple(s.shape[-2:]))
@@ -181,25 +182,35 @@ class DeformableTransformer(nn.Module):
         src, mask, pos = torch.cat(flat, 1), torch.cat(mflat, 1), torch.cat(pflat, 1)
         spatial_shapes, level_start = self._shape_tensors(tuple(shapes), src.device)
         ratios = torch.stack([self.get_valid_ratio(m) for m in masks], 1)
-
         # one device-side flag "is there any padding" lets K2 skip the per-tap mask test without a
         # host sync (single-video batches never pad)
         pad_flag = mask.any().to(torch.int32).reshape(1) if mask.is_cuda else None
         memory = self.encoder(src, spatial_shapes, level_start, ratios, pos, mask, shapes_list=shapes,
                               pad_flag=pad_flag)
+        n, _, c = memory.shape
+        maps, at = [], 0
+        for (h, w) in shapes[:self.num_feature_level - 1]:
+            maps.append(memory[:, at:at + h * w].reshape(n, h, w, c).permute(0, 3, 1, 2).contiguous())
+            at += h * w
+        return maps, (memory, spatial_shapes, level_start, ratios, mask, pad_flag)
 
+    def decode(self, ctx, tgt, query_embed):
+        """tgt [b,t,q,c], query_embed [q,c] -> hs [l,(b t),q,c], init_ref [(b t),q,2], inter_refs [l,(b t),q,4]"""
+        memory, spatial_shapes, level_start, ratios, mask, pad_flag = ctx
         b, t, q, c = tgt.shape
         tgt = tgt.reshape(b * t, q, c)
         qpos = query_embed.unsqueeze(0).expand(b * t, -1, -1)
         ref = self.reference_points(qpos).sigmoid()
-        hs, inter_refs, inter_samples = self.decoder(tgt, ref, memory, spatial_shapes, level_start, ratios, qpos, mask,
-                                                     pad_flag)
+        hs, inter_refs, _ = self.decoder(tgt, ref, memory, spatial_shapes, level_start, ratios, qpos, mask, pad_flag)
+        return hs, ref, inter_refs
 
-        maps, at = [], 0
-        for (h, w) in shapes[:self.num_feature_level - 1]:
-            maps.append(memory[:, at:at + h * w].reshape(b * t, h, w, c).permute(0, 3, 1, 2).contiguous())
-            at += h * w
-        return hs, maps, ref, inter_refs, None, None, inter_samples
+    def forward(self, srcs, tgt, masks, pos_embeds, query_embed=None):
+        """srcs/masks/pos per level '(b t) c h w'; tgt [b,t,q,c]; query_embed [q,c]
+        -> hs [l,(b t),q,c], memory maps, init_ref [(b t),q,2], inter_refs [l,(b t),q,4], None, None, None
+        (return signature of the reference, models/deformable_transformer.py:132-220)"""
+        maps, ctx = self.encode(srcs, masks, pos_embeds)
+        hs, ref, inter_refs = self.decode(ctx, tgt, query_embed)
+        return hs, maps, ref, inter_refs, None, None, None
 
 
 def build_deforamble_transformer(args):  # (sic) name kept from the reference :430

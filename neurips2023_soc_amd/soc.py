@@ -248,7 +248,20 @@ class SOC(nn.Module):
 
         Q = self.num_queries
         tgt = words.new_zeros(B, T, Q, words.shape[-1])
-        hs, memory, init_ref, inter_refs, _, _, _ = self.transformer(srcs, tgt, masks, poses, self.query_embed.weight)
+        memory, ctx = self.transformer.encode(srcs, masks, poses)
+
+        # Fork again: the FPN spatial decoder (convs over the memory maps) only meets the query branch
+        # (decoder -> VOC -> heads -> controller, ~250 small latency-bound launches) at the dynamic
+        # mask head, so it runs on the side stream meanwhile.
+        feats0 = backbone_out[0].tensors
+        if side is not None:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                fpn = self.spatial_decoder(memory[-1], [memory[1], memory[0], feats0])  # '(b t) 8 h/4 w/4'
+        else:
+            fpn = self.spatial_decoder(memory[-1], [memory[1], memory[0], feats0])
+
+        hs, init_ref, inter_refs = self.transformer.decode(ctx, tgt, self.query_embed.weight)
 
         # text feature the reference reports for its vl-loss: mean over real words of lvf's output
         keep = (~word_pad).to(lang_last.dtype).transpose(0, 1)[..., None]   # [L,B,1]
@@ -262,12 +275,11 @@ class SOC(nn.Module):
         cls = self.class_embed[0](hs0)
         box = self.bbox_embed[0](hs0)
         box = torch.cat([box[..., :2] + inverse_sigmoid(init_ref).view(B, T, Q, 2), box[..., 2:]], -1).sigmoid()
-
-        feats0 = backbone_out[0].tensors
-        fpn = self.spatial_decoder(memory[-1], [memory[1], memory[0], feats0])  # '(b t) 8 h/4 w/4'
-        hm, wm = fpn.shape[-2:]
         params = self.controller(hs0)                                        # b t q 169
         refs = inter_refs[0][..., :2].reshape(B, T * Q, 2)
+        if side is not None:
+            main.wait_stream(side)
+        hm, wm = fpn.shape[-2:]
         fpn = fpn.view(B, T, fpn.shape[1], hm, wm)
         per_b = []
         for b in range(B):
