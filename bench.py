@@ -50,9 +50,10 @@ def main():
     assert torch.cuda.is_available(), "bench.py measures the HIP path; it needs an MI355X"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)  # launched by torchrun
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
 
     import neurips2023_soc_amd as S
     from neurips2023_soc_amd import clip_parallel as CP, hot_ops, postprocessing as P, weights as W
@@ -91,14 +92,14 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
     run = gstep if graph is not None else step
     for i in range(a.warmup):
         run(i, results[0])
-    if world > 1:
+    if use_dist:
         CP.gather_results(results)  # RCCL warm-up, outside the timed region
 
     fence()
@@ -109,7 +110,7 @@ def main():
         run(i, results[i])
     gathered = CP.gather_results(results)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -128,7 +129,7 @@ def main():
         prof = hot_ops.profile_end()
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     assert gathered.shape[0] == world
@@ -215,7 +216,7 @@ def main():
                               "max_abs_ref_logit_at_flips": float(ref["pred_masks"][flip].abs().max()) if bool(flip.any()) else 0.0,
                               "pixels": flip.numel()}
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

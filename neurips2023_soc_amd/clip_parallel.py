@@ -40,7 +40,7 @@ def unpack_record(rec: torch.Tensor, T: int, Q: int, h: int, w: int) -> Tuple[in
 def gather_results(local: torch.Tensor) -> torch.Tensor:
     """local [n_local, R] float32 -> [world, n_local, R] on every rank (one collective).
     Every rank must pass the same n_local (pad the last shard)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return local[None]
     world = dist.get_world_size()
     out = local.new_empty((world * local.shape[0],) + tuple(local.shape[1:]))  # concat layout
