@@ -142,6 +142,17 @@ int soc_add_layernorm_f32(const float* x, const float* y, const float* gamma, co
                           float* out_sum, float* out_norm, long rows, int C, float eps,
                           void* stream);
 
+/*
+ * K6 -- fused bilinear up-sampling (align_corners = False) + threshold of mask logits
+ * (SURVEY 8a row a21, 8f rank 3).  Replaces
+ *   F.interpolate(pred_masks, size=(H0, W0), mode='bilinear', align_corners=False) followed by
+ *   (pred_masks.sigmoid() > 0.5)       infer_refytb.py:230-231, models/postprocessing.py:222-224
+ *   logits [T, h, w] f32 -> out [T, H0, W0] uint8 (1 where the up-sampled logit > threshold_logit;
+ *   threshold_logit = 0 is sigmoid > 0.5).
+ */
+int soc_upsample_threshold_u8(const float* logits, uint8_t* out, int T, int h, int w, int H0, int W0,
+                              float threshold_logit, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

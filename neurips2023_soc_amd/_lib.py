@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_PKG, "libsoc_hip.so")
 
 EXPORTS = ("soc_hip_abi_version", "soc_hip_error_string", "soc_msda_fwd_f32", "soc_msda_fwd_f64",
            "soc_win_attn3d_f32", "soc_xattn_workspace_bytes", "soc_xattn_f32", "soc_dyn_mask_f32",
-           "soc_add_layernorm_f32", "soc_msda_fused_fwd_f32")
+           "soc_add_layernorm_f32", "soc_msda_fused_fwd_f32", "soc_upsample_threshold_u8")
 ABI_VERSION = 1
 
 _lib = None
@@ -51,6 +51,8 @@ def load() -> C.CDLL:
     lib.soc_dyn_mask_f32.argtypes = [p, p, p, p, i, i, i, i, i, f, f, i, p]
     lib.soc_msda_fused_fwd_f32.restype = i
     lib.soc_msda_fused_fwd_f32.argtypes = [p, p, p, p, p, p, i, p, p, p, i, i, i, i, i, i, i, p]
+    lib.soc_upsample_threshold_u8.restype = i
+    lib.soc_upsample_threshold_u8.argtypes = [p, p, i, i, i, i, i, f, p]
     lib.soc_add_layernorm_f32.restype = i
     lib.soc_add_layernorm_f32.argtypes = [p, p, p, p, p, p, C.c_long, i, f, p]
     if lib.soc_hip_abi_version() != ABI_VERSION:

@@ -243,3 +243,19 @@ def add_layernorm(x: Tensor, y: Optional[Tensor], weight: Tensor, bias: Tensor, 
                                          sum_ptr, out_norm.data_ptr(), rows, C, float(eps), _stream())
     _lib.check(code, "soc_add_layernorm_f32")
     return out_sum, out_norm
+
+
+def upsample_threshold(mask_logits: Tensor, size: Sequence[int], threshold_logit: float = 0.0) -> Tensor:
+    """K6.  [T,h,w] logits -> bool [T,H0,W0]: bilinear (align_corners=False) up-sampling fused with
+    the sigmoid > 0.5 threshold (as logit > 0)."""
+    _need_gpu(mask_logits)
+    lib = _lib.load()
+    x = _f32c(mask_logits)
+    T, h, w = x.shape
+    H0, W0 = int(size[0]), int(size[1])
+    out = torch.empty((T, H0, W0), dtype=torch.uint8, device=x.device)
+    with _timed("upsample_threshold", x.numel() * 4 + out.numel()):
+        code = lib.soc_upsample_threshold_u8(x.data_ptr(), out.data_ptr(), T, h, w, H0, W0, float(threshold_logit),
+                                             _stream())
+    _lib.check(code, "soc_upsample_threshold_u8")
+    return out.view(torch.bool)

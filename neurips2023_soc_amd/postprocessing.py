@@ -21,7 +21,12 @@ def select_trajectory(outputs: Dict[str, torch.Tensor]) -> Tuple[torch.Tensor, t
 
 
 def upsample_and_threshold(mask_logits: torch.Tensor, size: Sequence[int]) -> torch.Tensor:
-    """[T,h,w] logits -> bool [T,H0,W0] (bilinear, align_corners=False, sigmoid>0.5)."""
+    """[T,h,w] logits -> bool [T,H0,W0] (bilinear, align_corners=False, sigmoid>0.5).
+    On the GPU this is the fused HIP kernel K6; CPU tensors (host-side post-processing of gathered
+    results) take the two torch ops the reference uses."""
+    if mask_logits.is_cuda:
+        from . import hot_ops
+        return hot_ops.upsample_threshold(mask_logits, size)
     up = F.interpolate(mask_logits[None], size=tuple(size), mode="bilinear", align_corners=False)[0]
     return up.sigmoid() > 0.5
 

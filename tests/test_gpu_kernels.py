@@ -261,3 +261,22 @@ def test_msda_fused_vs_oracle(ops, N, Lq, rd, padding):
         got0 = ops.msda_fused_forward(dev(value), dev(shapes), dev(lsi), dev(ref), dev(off), dev(logits),
                                       dev(pad), torch.zeros(1, dtype=torch.int32).cuda())
         assert maxdiff(got0, O.msda_fused_core(value, shapes, lsi, ref, off, logits, None)) < 3e-5
+
+
+# ------------------------------------------------------------------ K6 fused upsample + threshold
+@pytest.mark.parametrize("T,h,w,H0,W0", [(8, 90, 160, 720, 1280), (3, 63, 75, 250, 300), (1, 5, 7, 33, 50),
+                                         (2, 90, 160, 360, 640), (1, 9, 9, 9, 9), (0, 4, 4, 8, 8)])
+def test_upsample_threshold_vs_torch(ops, T, h, w, H0, W0):
+    """Reference ops: F.interpolate(bilinear, align_corners=False) then sigmoid > 0.5.  Masks must be
+    identical except where the up-sampled logit is within 1e-5 of the threshold."""
+    g = torch.Generator().manual_seed(T * 100 + H0)
+    x = torch.randn(T, h, w, generator=g) * 5
+    got = ops.upsample_threshold(dev(x), (H0, W0))
+    assert got.shape == (T, H0, W0) and got.dtype == torch.bool
+    if T:
+        up = torch.nn.functional.interpolate(x[None], size=(H0, W0), mode="bilinear", align_corners=False)[0]
+        want = up.sigmoid() > 0.5
+        diff = got.cpu() != want
+        assert int(diff.sum()) <= max(2, diff.numel() // 200000)
+        if diff.any():
+            assert float(up[diff].abs().max()) < 1e-5
