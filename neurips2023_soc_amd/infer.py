@@ -1,0 +1,105 @@
+"""Clip-level inference driver: the body of the reference's per-(video, expression) loop
+(infer_refytb.py:185-231 without the disk I/O) on top of ClipGraph, plus the clip-parallel
+multi-GPU form of its `sub_processor` fan-out (infer_refytb.py:84-109).
+
+    python -m neurips2023_soc_amd.infer --clips 16            # synthetic Ref-YouTube-VOS-like stream
+    python -m torch.distributed.run --nproc-per-node 8 -m neurips2023_soc_amd.infer --clips 64
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import time
+from typing import Dict, Optional, Sequence, Tuple
+
+import torch
+
+from . import clip_parallel as CP
+from . import postprocessing as P
+from .graph_runner import ClipGraph
+
+
+class ClipInferencer:
+    """model + one hipGraph per (T, H, W, L) geometry.  `__call__` returns the reference driver's
+    per-clip products: selected query index, its mask logits, and the thresholded full-size masks."""
+
+    def __init__(self, model, device="cuda"):
+        self.model, self.device = model, torch.device(device)
+        self._graphs: Dict[Tuple[int, int, int, int], ClipGraph] = {}
+
+    def graph_for(self, T: int, H: int, W: int, L: int) -> ClipGraph:
+        key = (T, H, W, L)
+        if key not in self._graphs:
+            self._graphs[key] = ClipGraph(self.model, T, H, W, L, self.device)
+        return self._graphs[key]
+
+    @torch.no_grad()
+    def __call__(self, clip: torch.Tensor, token_ids: torch.Tensor,
+                 original_size: Optional[Sequence[int]] = None):
+        """clip [T,3,H,W] (normalised, on the device), token_ids [1,L] -> dict with
+        'query' (0-d int64 tensor), 'mask_logits' [T,H/4,W/4], 'pred_cls' [T,Q], and, when
+        original_size=(H0,W0) is given, 'masks' bool [T,H0,W0]."""
+        T, _, H, W = clip.shape
+        g = self.graph_for(T, H, W, token_ids.shape[-1])
+        out = g.run(clip, token_ids)
+        idx, masks = P.select_trajectory(out)
+        res = {"query": idx, "mask_logits": masks, "pred_cls": out["pred_cls"][:, 0, :, 0], "record": g.record}
+        if original_size is not None:
+            res["masks"] = P.upsample_and_threshold(masks, original_size)
+        return res
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--clips", type=int, default=16)
+    ap.add_argument("--backbone", default="video-swin-t")
+    ap.add_argument("--frames", type=int, default=8)
+    ap.add_argument("--height", type=int, default=360)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--orig", type=int, nargs=2, default=[720, 1280], help="original frame size for the output masks")
+    a = ap.parse_args(argv)
+    import torch.distributed as dist
+    from . import build_model, default_args
+    from . import weights as W
+
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if "MASTER_PORT" in os.environ:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    model, _, _ = build_model(default_args(a.backbone, text_encoder_random_init=True))
+    W.load_synthetic(model, 2023)
+    run = ClipInferencer(model.to(dev).eval(), dev)
+
+    T, H, Wd, L = a.frames, a.height, a.width, 10
+    mine = CP.shard_clips(a.clips, rank, world)
+    n_local = -(-a.clips // world)
+    hm, wm = -(-H // 4), -(-Wd // 4)
+    records = torch.zeros(n_local, CP.record_size(T, 20, hm, wm), device=dev)
+    fg = torch.zeros(n_local, device=dev)
+    # synthetic stream: clip i / expression i from seeds, like tests/golden (seed 1 == golden clip)
+    clips = [W.synthetic_clip(1 + i, T, H, Wd) for i in mine]
+    ids = [W.synthetic_token_ids(1 + i, L) for i in mine]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for slot, (c, t) in enumerate(zip(clips, ids)):
+        res = run(c.to(dev, non_blocking=True), t.to(dev), a.orig)   # H2D inside the loop, like the reference
+        records[slot].copy_(res["record"])
+        fg[slot] = res["masks"].float().mean()
+    gathered = CP.interleave(CP.gather_results(records), a.clips)     # the one collective
+    fgs = CP.interleave(CP.gather_results(fg[:, None]), a.clips)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if rank == 0:
+        qs = [int(gathered[i, 0].item()) for i in range(a.clips)]
+        print(json.dumps({"clips": a.clips, "world": world, "seconds": dt, "clips_per_s": a.clips / dt,
+                          "selected_queries": qs, "foreground_fraction": [round(float(v), 4) for v in fgs[:, 0]]}))
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -149,3 +149,19 @@ def test_hip_graph_replay_matches_eager(gpu_model, golden):
     g = golden("tiny_forward.npz")   # seed 7 is the tiny golden clip
     out = runner.run(W.synthetic_clip(7, T, H, Wd).cuda(), W.synthetic_token_ids(7, L).cuda())
     assert maxdiff(out["pred_masks"], g["pred_masks"]) < 1e-3
+
+
+def test_clip_inferencer_end_to_end(gpu_model, golden):
+    """infer.ClipInferencer = reference loop body: graph forward -> best query -> K6 upsample+threshold."""
+    from neurips2023_soc_amd.infer import ClipInferencer
+    g = golden("full_forward.npz")
+    seed, T, H, Wd, L = (int(v) for v in g["cfg"])
+    run = ClipInferencer(gpu_model)
+    res = run(W.synthetic_clip(seed, T, H, Wd).cuda(), W.synthetic_token_ids(seed, L).cuda(), (720, 1280))
+    assert int(res["query"]) == int(g["selected_query"])
+    assert maxdiff(res["mask_logits"], g["selected_masks"]) < 1e-3
+    want = torch.nn.functional.interpolate(t(g["selected_masks"])[None], size=(720, 1280), mode="bilinear",
+                                           align_corners=False)[0]
+    diff = res["masks"].cpu() != (want > 0)
+    assert res["masks"].shape == (T, 720, 1280)
+    assert int(diff.sum()) <= 40 and (not diff.any() or float(want[diff].abs().max()) < 1e-3)
