@@ -357,6 +357,320 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_kernel(
     }
 }
 
+// =============================================================================================
+// Fast path for FULL windows (8 x 7 x 7 = 392 tokens, the only geometry of the BASELINE configs).
+// Same algorithm as win_attn3d_kernel<25,..>, but the 392 tokens are enumerated with the TEMPORAL
+// index fastest (slot = (dy*7 + dx)*8 + dz), which makes every group of 4 consecutive keys a run
+// of 4 consecutive frames of one spatial position.  Consequences:
+//   * the bias table is staged as T'[(dy_rel, dx_rel)][dz_rel]; the 4 biases of a key group are
+//     4 consecutive LDS words -> ONE address subtraction + two ds_read2_b32 per group instead of
+//     4 subtractions + 4 gathers + a code fetch; the per-(tile, lane) group codes are
+//     query-independent and stay in 25 registers for the whole workgroup;
+//   * shift-mask regions are constant inside a group (region boundaries are multiples of 4);
+//   * the MFMA k-step kk uses head dims {8g + kk}: a lane's 8 K (and Q) operands of a key tile are
+//     8 consecutive floats -> two ds_read_b128 (two global dwordx4 for Q) instead of 8 scalar reads;
+//   * V is staged transposed ([dim][slot]) so a lane's 4 k-steps of a key tile are one ds_read_b128.
+// LDS instructions per 16-query tile drop from ~525 to ~150, VALU address arithmetic from 100 to 25.
+// =============================================================================================
+constexpr int FN = 392, FNT = 25, FNP = 400;
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr int RSV = 404;        // row stride (floats) of the transposed V image [32][RSV]
+constexpr int TBL = 169 * 15;   // 2535 entries
+
+template <bool SHIFTED>
+__global__ __launch_bounds__(THREADS, 2) void win_attn3d_full_kernel(
+    const float* __restrict__ qkv, const float* __restrict__ qkv_bias,
+    const float* __restrict__ table, float* __restrict__ out, const WinParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* Tb = reinterpret_cast<float*>(smem_raw);            // [2535 (+1 pad)] T'[(yy,xx)][zz] * log2e
+    float* Ks = Tb + 2536;                                      // [400][RS]   K, slot-major
+    float* Vt = Ks + FNP * RS;                                  // [32][RSV]   V transposed
+    int* src = reinterpret_cast<int*>(Vt + HD * RSV);           // [400] token row offset or <0
+    int* qcd = src + FNP;                                       // [400] 4*(c(q)) | region << 16
+    int* wflag = qcd + FNP;                                     // [8]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bid = blockIdx.x;
+    const int qpart = bid % p.qsplit; bid /= p.qsplit;
+    const int head = bid % p.nH; bid /= p.nH;
+    const int wx = bid % p.nww; bid /= p.nww;
+    const int wy = bid % p.nwh; bid /= p.nwh;
+    const int wz = bid % p.nwd; bid /= p.nwd;
+    const int b = bid;
+    const int C3 = 3 * p.C;
+    const int r = lane & 15, g = lane >> 4;
+
+    // ---- stage 0: slot metadata (slot = col*8 + dz, col = dy*7 + dx) --------------------------
+    auto slot_info = [&](int i, int& reg, int& ccode) -> int {
+        const int col = i >> 3, dz = i & 7;
+        const int dy = col / 7, dx = col - dy * 7;
+        const int zs = wz * 8 + dz, ys = wy * 7 + dy, xs = wx * 7 + dx;  // shifted frame
+        int z = zs + p.sd; if (z >= p.Dp) z -= p.Dp;
+        int y = ys + p.sh; if (y >= p.Hp) y -= p.Hp;
+        int x = xs + p.sw; if (x >= p.Wp) x -= p.Wp;
+        reg = (region1d(zs, p.Dp, 8, p.sd) * 3 + region1d(ys, p.Hp, 7, p.sh)) * 3 + region1d(xs, p.Wp, 7, p.sw);
+        ccode = ((dy * 13 + dx) * 15 + dz) * 4;  // byte offset of T'[(dy,dx)][dz]
+        return (z < p.D && y < p.H && x < p.W) ? ((b * p.D + z) * p.H + y) * p.W + x : -1;
+    };
+    int differs = 0;
+    int reg0, c0;
+    (void)slot_info(0, reg0, c0);
+    for (int i = tid; i < FNP; i += THREADS) {
+        int s = -2, reg = 0, cc = 0;
+        if (i < FN) {
+            s = slot_info(i, reg, cc);
+            differs |= (reg != reg0);
+        }
+        src[i] = s;
+        qcd[i] = cc | (reg << 16);
+    }
+    // bias column, re-laid-out with dz_rel fastest: T'[((yy*13)+xx)*15 + zz] = table[(zz*169 + yy*13 + xx)][head]
+    for (int i = tid; i < TBL; i += THREADS) {
+        const int yx = i / 15, zz = i - yx * 15;
+        Tb[i] = table[(long)(zz * 169 + yx) * p.nH + head] * LOG2E;
+    }
+    if (SHIFTED && lane == 0) wflag[wave] = 0;
+    if (SHIFTED && __any(differs) && lane == 0) wflag[wave] = 1;
+    __syncthreads();
+    bool has_mask = false;
+    if (SHIFTED) {
+        int f = 0;
+#pragma unroll
+        for (int w8 = 0; w8 < THREADS / 64; ++w8) f |= wflag[w8];
+        has_mask = f != 0;
+    }
+
+    // ---- stage 1: K -> [slot][36], V -> transposed [dim][404] -----------------------------------
+    {
+        const int part = tid & 7;
+        const float4 kbias = *reinterpret_cast<const float4*>(qkv_bias + p.C + head * HD + part * 4);
+        const float4 vbias = *reinterpret_cast<const float4*>(qkv_bias + 2 * p.C + head * HD + part * 4);
+        constexpr int ROWS = THREADS / 8, PASSES = (FNP + ROWS - 1) / ROWS;
+        float4 kv[PASSES], vv[PASSES];
+#pragma unroll
+        for (int it = 0; it < PASSES; ++it) {
+            const int i = it * ROWS + (tid >> 3);
+            const int s = i < FNP ? src[i] : -2;
+            if (s >= 0) {
+                const float* row = qkv + (long)s * C3 + head * HD + part * 4;
+                kv[it] = *reinterpret_cast<const float4*>(row + p.C);
+                vv[it] = *reinterpret_cast<const float4*>(row + 2 * p.C);
+            } else if (s == -1) {
+                kv[it] = kbias; vv[it] = vbias;
+            } else {
+                kv[it] = make_float4(0.f, 0.f, 0.f, 0.f); vv[it] = kv[it];
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < PASSES; ++it) {
+            const int i = it * ROWS + (tid >> 3);
+            if (i < FNP) {
+                *reinterpret_cast<float4*>(Ks + i * RS + part * 4) = kv[it];
+                Vt[(part * 4 + 0) * RSV + i] = vv[it].x;
+                Vt[(part * 4 + 1) * RSV + i] = vv[it].y;
+                Vt[(part * 4 + 2) * RSV + i] = vv[it].z;
+                Vt[(part * 4 + 3) * RSV + i] = vv[it].w;
+            }
+        }
+    }
+    // per-(tile, lane) key-group codes: group = slots 16t+4g..+3 = column 2t + (g>>1), frames 4(g&1)..+3
+    int gcode[FNT];
+#pragma unroll
+    for (int t = 0; t < FNT; ++t) {
+        const int col = 2 * t + (g >> 1);
+        const int dy = col / 7, dx = col - dy * 7;
+        int reg = 0;
+        if (SHIFTED) {
+            const int zs = wz * 8 + 4 * (g & 1), ys = wy * 7 + dy, xs = wx * 7 + dx;
+            reg = (region1d(zs, p.Dp, 8, p.sd) * 3 + region1d(ys, p.Hp, 7, p.sh)) * 3 + region1d(xs, p.Wp, 7, p.sw);
+        }
+        gcode[t] = (((dy * 13 + dx) * 15 + 4 * (g & 1)) * 4) | (reg << 16);
+    }
+    __syncthreads();
+
+    // ---- stage 2/3: per 16-query tile ---------------------------------------------------------
+    const float scale = 0.17677669529663687f * LOG2E;
+    const int C0 = ((6 * 13 + 6) * 15 + 7 - 3) * 4;  // byte offset of T'[(0,0) rel][dz_rel = 0], minus the 3-word run
+    const int nwaves_total = (THREADS / 64) * p.qsplit;
+    const float* kb = Ks + r * RS + 8 * g;           // + 16t*RS : 8 consecutive dims of key 16t + r
+    const float* vb = Vt + r * RSV + 4 * g;          // + 16t (+16*RSV): 4 consecutive keys of dim r
+    const unsigned tbase = (unsigned)(uintptr_t)(lds_cfloat*)Tb;
+
+    auto load_q = [&](int qt, float (&qf)[8], int& qsrc) {
+        qsrc = src[qt * 16 + r];
+        if (qsrc >= 0) {
+            const float4* qrow = reinterpret_cast<const float4*>(qkv + (long)qsrc * C3 + head * HD + 8 * g);
+            const float4 a = qrow[0], c = qrow[1];
+            qf[0] = a.x; qf[1] = a.y; qf[2] = a.z; qf[3] = a.w; qf[4] = c.x; qf[5] = c.y; qf[6] = c.z; qf[7] = c.w;
+        } else if (qsrc == -1) {
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) qf[kk] = qkv_bias[head * HD + 8 * g + kk];
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) qf[kk] = 0.f;
+        }
+    };
+    float qn[8];
+    int qsrc_n = -2;
+    int qt = qpart * (THREADS / 64) + wave;
+    if (qt < FNT) load_q(qt, qn, qsrc_n);
+
+    for (; qt < FNT; qt += nwaves_total) {
+        const int qtok = qt * 16 + r;
+        const int qsrc = qsrc_n;
+        float qf[8];
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) qf[kk] = qn[kk] * scale;
+        const int qc = qcd[qtok];
+        const unsigned qaddr = tbase + (unsigned)((qc & 0xFFFF) + C0);
+        const int qreg = qc >> 16;
+
+        // accumulators start from the bias: keys 16t+4g+i (i = 0..3) are frames 4(g&1)+i of one
+        // column, i.e. words qaddr - gcode + (3 - i)
+        f32x4 acc[FNT];
+#pragma unroll
+        for (int t = 0; t < FNT; ++t) {
+            lds_cfloat* bp = (lds_cfloat*)(uintptr_t)(qaddr - (unsigned)(gcode[t] & 0xFFFF));
+            acc[t][3] = bp[0]; acc[t][2] = bp[1]; acc[t][1] = bp[2]; acc[t][0] = bp[3];
+        }
+        // S^T = K . Q^T, two key tiles interleaved so consecutive MFMAs hit different accumulators;
+        // K fragments (2 x b128 per tile) double-buffered across tile pairs
+        {
+            float ka[2][8], kc[2][8];
+            auto kload = [&](int t, float (&f)[8]) {
+                const float4 a = *reinterpret_cast<const float4*>(kb + 16 * t * RS);
+                const float4 c = *reinterpret_cast<const float4*>(kb + 16 * t * RS + 4);
+                f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = c.x; f[5] = c.y; f[6] = c.z; f[7] = c.w;
+            };
+            kload(0, ka[0]); kload(1, ka[1]);
+#pragma unroll
+            for (int tp = 0; tp < FNT; tp += 4) {
+                if (tp + 2 < FNT) kload(tp + 2, kc[0]);
+                if (tp + 3 < FNT) kload(tp + 3, kc[1]);
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) {
+                    acc[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[0][kk], qf[kk], acc[tp], 0, 0, 0);
+                    if (tp + 1 < FNT)
+                        acc[tp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[1][kk], qf[kk], acc[tp + 1], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (tp + 2 < FNT) {
+                    if (tp + 4 < FNT) kload(tp + 4, ka[0]);
+                    if (tp + 5 < FNT) kload(tp + 5, ka[1]);
+#pragma unroll
+                    for (int kk = 0; kk < 8; ++kk) {
+                        acc[tp + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(kc[0][kk], qf[kk], acc[tp + 2], 0, 0, 0);
+                        if (tp + 3 < FNT)
+                            acc[tp + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(kc[1][kk], qf[kk], acc[tp + 3], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        if (qt + nwaves_total < FNT) load_q(qt + nwaves_total, qn, qsrc_n);  // next tile's Q, hidden
+
+        if (has_mask) {
+#pragma unroll
+            for (int t = 0; t < FNT; ++t) {
+                const float pen = ((gcode[t] >> 16) != qreg) ? -100.0f * LOG2E : 0.f;
+                acc[t] += (f32x4){pen, pen, pen, pen};
+            }
+        }
+        if (g >= 2) acc[FNT - 1] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};  // slots 392..399
+        float mx = fmaxf(acc[0][0], acc[0][1]);
+#pragma unroll
+        for (int t = 0; t < FNT; ++t) {
+            if (t > 0) mx = __builtin_fmaxf(mx, fmaxf(acc[t][0], acc[t][1]));
+            mx = __builtin_fmaxf(mx, fmaxf(acc[t][2], acc[t][3]));
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const f32x4 mx4 = (f32x4){mx, mx, mx, mx};
+        f32x2 sum2 = (f32x2){0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < FNT; ++t) {
+            const f32x4 d = acc[t] - mx4;
+            f32x4 e;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) e[i] = __builtin_amdgcn_exp2f(d[i]);
+            acc[t] = e;
+            sum2 += (f32x2){e[0], e[1]};
+            sum2 += (f32x2){e[2], e[3]};
+        }
+        float sum = sum2[0] + sum2[1];
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+
+        // O^T = V^T . P^T: A = V^T[dim r (+16)][keys 16t+4g .. +3] (one b128 each), B = acc[t][s]
+        f32x4 o0 = (f32x4){0.f, 0.f, 0.f, 0.f}, o1 = o0;
+        {
+            float4 va0, va1, vc0, vc1;
+            va0 = *reinterpret_cast<const float4*>(vb);
+            va1 = *reinterpret_cast<const float4*>(vb + 16 * RSV);
+#pragma unroll
+            for (int t = 0; t < FNT; t += 2) {
+                if (t + 1 < FNT) {
+                    vc0 = *reinterpret_cast<const float4*>(vb + 16 * (t + 1));
+                    vc1 = *reinterpret_cast<const float4*>(vb + 16 * (t + 1) + 16 * RSV);
+                }
+                o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(va0.x, acc[t][0], o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(va1.x, acc[t][0], o1, 0, 0, 0);
+                o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(va0.y, acc[t][1], o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(va1.y, acc[t][1], o1, 0, 0, 0);
+                o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(va0.z, acc[t][2], o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(va1.z, acc[t][2], o1, 0, 0, 0);
+                o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(va0.w, acc[t][3], o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(va1.w, acc[t][3], o1, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (t + 1 < FNT) {
+                    if (t + 2 < FNT) {
+                        va0 = *reinterpret_cast<const float4*>(vb + 16 * (t + 2));
+                        va1 = *reinterpret_cast<const float4*>(vb + 16 * (t + 2) + 16 * RSV);
+                    }
+                    o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(vc0.x, acc[t + 1][0], o0, 0, 0, 0);
+                    o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(vc1.x, acc[t + 1][0], o1, 0, 0, 0);
+                    o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(vc0.y, acc[t + 1][1], o0, 0, 0, 0);
+                    o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(vc1.y, acc[t + 1][1], o1, 0, 0, 0);
+                    o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(vc0.z, acc[t + 1][2], o0, 0, 0, 0);
+                    o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(vc1.z, acc[t + 1][2], o1, 0, 0, 0);
+                    o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(vc0.w, acc[t + 1][3], o0, 0, 0, 0);
+                    o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(vc1.w, acc[t + 1][3], o1, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        if (qsrc >= 0) {
+            const float inv = 1.f / sum;
+            float* orow = out + (long)qsrc * p.C + head * HD + 4 * g;
+            *reinterpret_cast<float4*>(orow) = make_float4(o0[0] * inv, o0[1] * inv, o0[2] * inv, o0[3] * inv);
+            *reinterpret_cast<float4*>(orow + 16) = make_float4(o1[0] * inv, o1[1] * inv, o1[2] * inv, o1[3] * inv);
+        }
+    }
+}
+
+int launch_full(const float* qkv, const float* qkv_bias, const float* table, float* out,
+                const WinParams& p, long blocks, hipStream_t st) {
+    const size_t lds = (size_t)(2536 + FNP * RS + HD * RSV) * sizeof(float) + (2 * FNP + 8) * sizeof(int);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(win_attn3d_full_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(win_attn3d_full_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return SOC_ELAUNCH;
+        attr_set = true;
+    }
+    if (p.shifted)
+        hipLaunchKernelGGL((win_attn3d_full_kernel<true>), dim3((unsigned)blocks), dim3(THREADS), lds, st, qkv,
+                           qkv_bias, table, out, p);
+    else
+        hipLaunchKernelGGL((win_attn3d_full_kernel<false>), dim3((unsigned)blocks), dim3(THREADS), lds, st, qkv,
+                           qkv_bias, table, out, p);
+    return soc_check_launch();
+}
+
 template <int NT, int NT_PREV>
 int launch_nt(const float* qkv, const float* qkv_bias, const float* table, float* out,
               const WinParams& p, long blocks, hipStream_t st) {
@@ -425,6 +739,9 @@ extern "C" int soc_win_attn3d_f32(const float* qkv, const float* qkv_bias, const
     hipStream_t st = (hipStream_t)stream;
     // key/query tiles are a compile-time constant (fully unrolled MFMA schedule); a window with
     // fewer tokens runs on the next larger instantiation with the surplus keys masked out.
+    static const bool no_full = getenv("SOC_K1_GENERIC") != nullptr;  // A/B switch for the fast path
+    if (!no_full && win_d == 8 && win_h == 7 && win_w == 7 && tab_d == 8 && tab_h == 7 && tab_w == 7)
+        return launch_full(qkv, qkv_bias, bias_table, out, p, blocks, st);
     if (p.NT <= 7) return launch_nt<7, 0>(qkv, qkv_bias, bias_table, out, p, blocks, st);
     if (p.NT <= 10) return launch_nt<10, 7>(qkv, qkv_bias, bias_table, out, p, blocks, st);
     if (p.NT <= 13) return launch_nt<13, 10>(qkv, qkv_bias, bias_table, out, p, blocks, st);
