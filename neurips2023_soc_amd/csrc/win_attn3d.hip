@@ -44,7 +44,8 @@ struct WinParams {
     int nwd, nwh, nww;   // windows per axis
     int N;               // tokens per window
     int NT;              // tiles of 16
-    int qsplit;          // blocks per (window, head)
+    int qsplit;          // blocks per (window, head) for the pairs at index >= n_main
+    int n_main;          // pairs [0, n_main) get one workgroup each; the tail pairs are split qsplit ways
     int table_len;
     int shifted;
     int stagger;         // waves 4-7 start their tile loop this many x 512 cycles late
@@ -89,8 +90,16 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_kernel(
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // the last (pairs mod #CU) pairs would leave most CUs idle in the final round of workgroups, so
+    // those tail pairs are split over several workgroups (each re-stages K/V for a slice of the tiles)
     int bid = blockIdx.x;
-    const int qpart = bid % p.qsplit; bid /= p.qsplit;
+    int qpart = 0, qsplit = 1;
+    if (bid >= p.n_main) {
+        const int rem = bid - p.n_main;
+        qsplit = p.qsplit;
+        qpart = rem % qsplit;
+        bid = p.n_main + rem / qsplit;
+    }
     const int head = bid % p.nH; bid /= p.nH;
     const int wx = bid % p.nww; bid /= p.nww;
     const int wy = bid % p.nwh; bid /= p.nwh;
@@ -183,7 +192,7 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_kernel(
     const int g = lane >> 4;   // MFMA k index / C row group
     const float scale = 0.17677669529663687f * LOG2E;  // 32^-0.5, in log2 units
     const int E0 = ((p.td - 1) * (2 * p.th - 1) + (p.th - 1)) * (2 * p.tw - 1) + (p.tw - 1);
-    const int nwaves_total = (THREADS / 64) * p.qsplit;
+    const int nwaves_total = (THREADS / 64) * qsplit;
     const float* kbase = Ks + r * RS + g;          // + 16t*RS + 4kk
     const float* vbase = Vs + (4 * g) * RS + r;    // + (16t + s)*RS (+16)
 
@@ -392,8 +401,16 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_full_kernel(
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // the last (pairs mod #CU) pairs would leave most CUs idle in the final round of workgroups, so
+    // those tail pairs are split over several workgroups (each re-stages K/V for a slice of the tiles)
     int bid = blockIdx.x;
-    const int qpart = bid % p.qsplit; bid /= p.qsplit;
+    int qpart = 0, qsplit = 1;
+    if (bid >= p.n_main) {
+        const int rem = bid - p.n_main;
+        qsplit = p.qsplit;
+        qpart = rem % qsplit;
+        bid = p.n_main + rem / qsplit;
+    }
     const int head = bid % p.nH; bid /= p.nH;
     const int wx = bid % p.nww; bid /= p.nww;
     const int wy = bid % p.nwh; bid /= p.nwh;
@@ -493,7 +510,7 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_full_kernel(
     // ---- stage 2/3: per 16-query tile ---------------------------------------------------------
     const float scale = 0.17677669529663687f * LOG2E;
     const int C0 = ((6 * 13 + 6) * 15 + 7 - 3) * 4;  // byte offset of T'[(0,0) rel][dz_rel = 0], minus the 3-word run
-    const int nwaves_total = (THREADS / 64) * p.qsplit;
+    const int nwaves_total = (THREADS / 64) * qsplit;
     const float* kb = Ks + r * RS + 8 * g;           // + 16t*RS : 8 consecutive dims of key 16t + r
     const float* vb = Vt + r * RSV + 4 * g;          // + 16t (+16*RSV): 4 consecutive keys of dim r
     const unsigned tbase = (unsigned)(uintptr_t)(lds_cfloat*)Tb;
@@ -695,6 +712,19 @@ int launch_nt(const float* qkv, const float* qkv_bias, const float* table, float
     return soc_check_launch();
 }
 
+int num_cus() {
+    static const int n = [] {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) {
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                cus = prop.multiProcessorCount;
+        }
+        return cus;
+    }();
+    return n;
+}
+
 }  // namespace
 
 extern "C" int soc_win_attn3d_f32(const float* qkv, const float* qkv_bias, const float* bias_table,
@@ -730,12 +760,26 @@ extern "C" int soc_win_attn3d_f32(const float* qkv, const float* qkv_bias, const
 #endif
     if ((long)B * D * H * W * 3 * C >= (1L << 31)) return SOC_EUNSUPPORTED;  // int token offsets
     const long pairs = (long)B * p.nwd * p.nwh * p.nww * n_heads;
-    // few (window, head) pairs (late stages): split the query tiles over more workgroups so the
-    // 256 CUs stay busy; every split re-stages K/V, so only split while the grid is small.
+    // Workgroup schedule.  One workgroup per pair is the efficient form (K/V staged once); what it
+    // leaves on the table is the last round of workgroups when pairs is not a multiple of the CU
+    // count.  So only the TAIL pairs (pairs mod #CU, when that is at most half the CUs) are split 2
+    // or 4 ways over query tiles; grids smaller than the chip are split as a whole.
+    const int cus = num_cus();
     p.qsplit = 1;
-    while (pairs * p.qsplit < 512 && p.qsplit < 4 && (p.NT + (THREADS / 64) * p.qsplit - 1) / ((THREADS / 64) * p.qsplit) > 1)
-        p.qsplit *= 2;
-    const long blocks = pairs * p.qsplit;
+    p.n_main = (int)pairs;
+    if (pairs < cus) {
+        p.n_main = 0;
+        while (pairs * p.qsplit < 2 * cus && p.qsplit < 4 &&
+               (p.NT + (THREADS / 64) * p.qsplit - 1) / ((THREADS / 64) * p.qsplit) > 1)
+            p.qsplit *= 2;
+    } else {
+        const int tail = (int)(pairs % cus);
+        if (tail > 0 && tail <= cus / 2) {
+            p.qsplit = tail <= cus / 4 ? 4 : 2;
+            p.n_main = (int)pairs - tail;
+        }
+    }
+    const long blocks = p.n_main + (pairs - p.n_main) * p.qsplit;
     hipStream_t st = (hipStream_t)stream;
     // key/query tiles are a compile-time constant (fully unrolled MFMA schedule); a window with
     // fewer tokens runs on the next larger instantiation with the surplus keys masked out.

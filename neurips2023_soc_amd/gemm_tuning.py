@@ -34,10 +34,13 @@ def enable_tuned_gemms() -> bool:
         return False  # a tuning session (tools/tune_gemms.py) is in charge
     tunable.enable(True)
     tunable.tuning_enable(False)
-    tunable.set_filename(TABLE)
     try:
         ok = bool(tunable.read_file(TABLE))
     except Exception:
         ok = False
+    # whatever TunableOp may ever want to write goes to a per-process scratch file, never to the
+    # shipped table (N ranks share the package directory)
+    import tempfile
+    tunable.set_filename(os.path.join(tempfile.gettempdir(), f"soc_tunableop_{os.getpid()}.csv"))
     _done = ok
     return ok
