@@ -381,6 +381,23 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_kernel(
 //   * V is staged transposed ([dim][slot]) so a lane's 4 k-steps of a key tile are one ds_read_b128.
 // LDS instructions per 16-query tile drop from ~525 to ~150, VALU address arithmetic from 100 to 25.
 // =============================================================================================
+// f32 MFMA executes on the FP32 vector lanes: while a wave streams v_mfma_f32_16x16x4_f32 back to
+// back, a VALU-only wave on the same SIMD makes NO progress (tools/microbench/mfma_valu_overlap.hip:
+// 32.0 cycles per MFMA alone and together; the VALU wave finishes exactly its stand-alone time
+// later).  Every VALU instruction in the tile loop is therefore matrix time lost, so the softmax is
+// written with the fewest possible vector instructions: 3-input max and packed subtract via
+// inline asm (the compiler emits a canonicalising v_max per MFMA result and scalar subtracts).
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
 constexpr int FN = 392, FNT = 25, FNP = 400;
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr int RSV = 404;        // row stride (floats) of the transposed V image [32][RSV]
@@ -596,22 +613,24 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_full_kernel(
             }
         }
         if (g >= 2) acc[FNT - 1] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};  // slots 392..399
-        float mx = fmaxf(acc[0][0], acc[0][1]);
+        float mx = vmax3(acc[0][0], acc[0][1], acc[0][2]);
+        mx = fmaxf(mx, acc[0][3]);
 #pragma unroll
-        for (int t = 0; t < FNT; ++t) {
-            if (t > 0) mx = __builtin_fmaxf(mx, fmaxf(acc[t][0], acc[t][1]));
-            mx = __builtin_fmaxf(mx, fmaxf(acc[t][2], acc[t][3]));
+        for (int t = 1; t < FNT; ++t) {
+            mx = vmax3(mx, acc[t][0], acc[t][1]);
+            mx = vmax3(mx, acc[t][2], acc[t][3]);
         }
         mx = fmaxf(mx, __shfl_xor(mx, 16));
         mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const f32x4 mx4 = (f32x4){mx, mx, mx, mx};
+        const f32x2 mx2 = (f32x2){mx, mx};
         f32x2 sum2 = (f32x2){0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < FNT; ++t) {
-            const f32x4 d = acc[t] - mx4;
+            const f32x2 d0 = pk_sub((f32x2){acc[t][0], acc[t][1]}, mx2);
+            const f32x2 d1 = pk_sub((f32x2){acc[t][2], acc[t][3]}, mx2);
             f32x4 e;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) e[i] = __builtin_amdgcn_exp2f(d[i]);
+            e[0] = __builtin_amdgcn_exp2f(d0[0]); e[1] = __builtin_amdgcn_exp2f(d0[1]);
+            e[2] = __builtin_amdgcn_exp2f(d1[0]); e[3] = __builtin_amdgcn_exp2f(d1[1]);
             acc[t] = e;
             sum2 += (f32x2){e[0], e[1]};
             sum2 += (f32x2){e[2], e[3]};
