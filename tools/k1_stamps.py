@@ -32,7 +32,7 @@ for _ in range(2):
     assert rc == 0, rc
 torch.cuda.synchronize()
 d = dbg.cpu().view(nblk, 8, 32)
-for blk in (0, 300, 600):
+for blk in (0, 300):
     for w in (0, 4, 1):
         s = d[blk, w]
         n = int((s > 0).sum())
