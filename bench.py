@@ -74,7 +74,7 @@ def main():
     results = torch.zeros(a.steps, CP.record_size(T, Q, hm, wm), device=dev)
 
     def step(i, record=None):  # eager launches
-        samples = S.NestedTensor(clips[i % n_pool][:, None], pad)
+        samples = S.NestedTensor(clips[i % n_pool][:, None], pad, unpadded=True)
         out = model(samples, None, text, targets)
         idx, masks = P.select_trajectory(out)
         if record is not None:

@@ -44,7 +44,7 @@ class ClipGraph:
             self.out = self._forward()
 
     def _forward(self):
-        samples = NestedTensor(self.clip, self.pad)
+        samples = NestedTensor(self.clip, self.pad, unpadded=True)  # static all-False pad mask
         out = self.model(samples, None, {"input_ids": self.ids, "attention_mask": self.attn}, self.targets)
         idx, masks = P.select_trajectory(out)
         CP.pack_record(self.record, idx, out["pred_cls"][:, 0, :, 0], masks)

@@ -16,13 +16,16 @@ Tensor = torch.Tensor
 class NestedTensor:
     """``tensors`` plus a bool ``mask`` that is True on padding."""
 
-    def __init__(self, tensors: Tensor, mask: Optional[Tensor]):
+    def __init__(self, tensors: Tensor, mask: Optional[Tensor], unpadded: bool = False):
         self.tensors = tensors
         self.mask = mask
+        # host-side knowledge "mask is all False" (set by nested_tensor_from_videos_list for batches of
+        # equal-sized videos): lets the model reuse geometry-only constants without a device sync
+        self.unpadded = unpadded
 
     def to(self, device) -> "NestedTensor":
         m = self.mask.to(device) if self.mask is not None else None
-        return NestedTensor(self.tensors.to(device), m)
+        return NestedTensor(self.tensors.to(device), m, self.unpadded)
 
     def decompose(self):
         return self.tensors, self.mask
@@ -41,7 +44,8 @@ def nested_tensor_from_videos_list(videos: List[Tensor]) -> NestedTensor:
     for i, v in enumerate(videos):
         out[i, :v.shape[0], :, :v.shape[2], :v.shape[3]] = v
         mask[i, :v.shape[0], :v.shape[2], :v.shape[3]] = False
-    return NestedTensor(out.transpose(0, 1), mask.transpose(0, 1))
+    same = all(tuple(v.shape) == tuple(videos[0].shape) for v in videos)
+    return NestedTensor(out.transpose(0, 1), mask.transpose(0, 1), unpadded=same)
 
 
 def inverse_sigmoid(x: Tensor, eps: float = 1e-5) -> Tensor:

@@ -218,7 +218,7 @@ class SOC(nn.Module):
             backbone_out, pos = self.backbone(samples)
         words, word_pad = text.decompose()
         B = words.shape[1]
-        T = pos[0].shape[0] // B
+        T = pos[-1].shape[0] // B
         text_pos = self.text_pos(text).permute(2, 0, 1)
 
         srcs, masks, poses, lang_last = [], [], [], None
@@ -239,7 +239,7 @@ class SOC(nn.Module):
         for l in range(len(levels), self.num_feature_levels):
             src = self.input_proj[l](backbone_out[-1].tensors if l == len(levels) else srcs[-1])
             mask = resize_pad_mask(samples.mask, src.shape[-2:])
-            pos_l = self.backbone[1](NestedTensor(src, mask)).to(src.dtype)
+            pos_l = self.backbone.position_encoding(NestedTensor(src, mask), bool(getattr(samples, "unpadded", False)))
             h, w = src.shape[-2:]
             fused = self.vlf(tgt=self._seq(src, B, T), memory=words, memory_key_padding_mask=word_pad, pos=text_pos)
             srcs.append(self._unseq(fused, B, T, h, w))

@@ -10,7 +10,7 @@ that exists here.  Module / parameter names follow the reference so its checkpoi
 """
 from __future__ import annotations
 
-from typing import Dict, List, Sequence
+from typing import Dict, List, Optional, Sequence
 
 import torch
 import torch.nn.functional as F
@@ -207,8 +207,24 @@ class Joiner(nn.Sequential):
         tensor_list.mask = tensor_list.mask.transpose(0, 1).flatten(0, 1)
         xs = self[0](tensor_list, num_frames=t)
         out: List[NestedTensor] = [xs[k] for k in sorted(xs)]
-        pos = [self[1](x).to(x.tensors.dtype) for x in out]
+        # The stride-4 level's encoding ([T,256,H/4,W/4] = 118 MB at 360x640) is never read by
+        # SOC.forward (it uses pos[-3:], reference models/soc.py:226); only the last three are built.
+        # For un-padded batches (every single-video batch) the encodings depend on the geometry
+        # alone and are cached, like the reference caches compute_mask with lru_cache.
+        unpadded = bool(getattr(tensor_list, "unpadded", False))
+        pos: List[Optional[torch.Tensor]] = [None]
+        for x in out[1:]:
+            pos.append(self.position_encoding(x, unpadded))
         return out, pos
+
+    def position_encoding(self, x: NestedTensor, unpadded: bool = False) -> torch.Tensor:
+        if not unpadded:
+            return self[1](x).to(x.tensors.dtype)
+        cache = self.__dict__.setdefault("_pos_cache", {})
+        key = (tuple(x.mask.shape), str(x.mask.device))
+        if key not in cache:
+            cache[key] = self[1](NestedTensor(x.tensors, torch.zeros_like(x.mask))).to(x.tensors.dtype)
+        return cache[key]
 
 
 def build_video_swin_backbone(args) -> Joiner:
