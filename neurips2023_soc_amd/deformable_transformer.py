@@ -169,14 +169,16 @@ class DeformableTransformer(nn.Module):
         vw = (~mask[:, 0, :]).sum(1).float() / W
         return torch.stack([vw, vh], -1)
 
-    def encode(self, srcs, masks, pos_embeds):
+    def encode(self, srcs, masks, pos_embeds, token_major=False):
         """Flatten the levels and run the deformable encoder.  Returns (memory maps of the 3 finest
         levels as '(b t) c h w', context for decode()).  Split from forward() so that SOC can run the
-        FPN spatial decoder (needs only the maps) concurrently with the query decoder."""
+        FPN spatial decoder (needs only the maps) concurrently with the query decoder.
+        ``token_major=True``: srcs are already '(b t) (h w) c' (what the fusion produces), which saves a
+        layout round trip per level; masks / pos_embeds stay '(b t) [c] h w'."""
         flat, mflat, pflat, shapes = [], [], [], []
         for lvl, (s, m, pe) in enumerate(zip(srcs, masks, pos_embeds)):
-            shapes.append(tuple(s.shape[-2:]))
-            flat.append(s.flatten(2).transpose(1, 2))
+            shapes.append(tuple(m.shape[-2:]))
+            flat.append(s if token_major else s.flatten(2).transpose(1, 2))
             mflat.append(m.flatten(1))
             pflat.append(pe.flatten(2).transpose(1, 2) + self.level_embed[lvl].view(1, 1, -1))
         src, mask, pos = torch.cat(flat, 1), torch.cat(mflat, 1), torch.cat(pflat, 1)

@@ -185,6 +185,12 @@ class SOC(nn.Module):
         return x.view(B, T, c, h, w).permute(1, 3, 4, 0, 2).reshape(T * h * w, B, c)
 
     @staticmethod
+    def _tokens(x, B, T, h, w):
+        """'(t h w) b c -> (b t) (h w) c' -- a free view for B = 1"""
+        c = x.shape[-1]
+        return x.view(T, h * w, B, c).permute(2, 0, 1, 3).reshape(B * T, h * w, c)
+
+    @staticmethod
     def _unseq(x, B, T, h, w):
         """'(t h w) b c -> (b t) c h w'"""
         c = x.shape[-1]
@@ -233,22 +239,24 @@ class SOC(nn.Module):
                 lang_last = self.lvf(tgt=words, memory=seq,
                                      memory_key_padding_mask=mask.view(B, T, h, w).reshape(B, -1),
                                      pos=self._seq(pos_l, B, T))
-            srcs.append(self._unseq(fused, B, T, h, w))
+            srcs.append(self._tokens(fused, B, T, h, w))
             masks.append(mask)
             poses.append(pos_l)
         for l in range(len(levels), self.num_feature_levels):
-            src = self.input_proj[l](backbone_out[-1].tensors if l == len(levels) else srcs[-1])
+            if l > len(levels):
+                raise NotImplementedError("more than one extra feature level is not used by any shipped config")
+            src = self.input_proj[l](backbone_out[-1].tensors)
             mask = resize_pad_mask(samples.mask, src.shape[-2:])
             pos_l = self.backbone.position_encoding(NestedTensor(src, mask), bool(getattr(samples, "unpadded", False)))
             h, w = src.shape[-2:]
             fused = self.vlf(tgt=self._seq(src, B, T), memory=words, memory_key_padding_mask=word_pad, pos=text_pos)
-            srcs.append(self._unseq(fused, B, T, h, w))
+            srcs.append(self._tokens(fused, B, T, h, w))
             masks.append(mask)
             poses.append(pos_l)
 
         Q = self.num_queries
         tgt = words.new_zeros(B, T, Q, words.shape[-1])
-        memory, ctx = self.transformer.encode(srcs, masks, poses)
+        memory, ctx = self.transformer.encode(srcs, masks, poses, token_major=True)
 
         # Fork again: the FPN spatial decoder (convs over the memory maps) only meets the query branch
         # (decoder -> VOC -> heads -> controller, ~250 small latency-bound launches) at the dynamic

@@ -146,7 +146,7 @@ class PatchEmbed3D(nn.Module):
         f = x.transpose(1, 2).reshape(B * T, 3, x.shape[-2], x.shape[-1])
         f = F.conv2d(f, self.proj.weight[:, :, 0], self.proj.bias, stride=4)
         f = f.permute(0, 2, 3, 1).reshape(B, T, f.shape[-2], f.shape[-1], -1)
-        return self.norm(f)
+        return hot_ops.add_layernorm(f, None, self.norm.weight, self.norm.bias, self.norm.eps)[1]
 
 
 class VideoSwinTransformerBackbone(nn.Module):
