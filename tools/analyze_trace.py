@@ -4,7 +4,7 @@ import collections
 import csv
 import sys
 
-rows = list(csv.DictReader(open(sys.argv[1])))
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if "spin_kernel" not in r["Kernel_Name"]]  # drop torch.cuda._sleep
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(rows) if "dyn_mask" in r["Kernel_Name"]]
 seg = rows[idx[-2] + 1: idx[-1] + 1]
