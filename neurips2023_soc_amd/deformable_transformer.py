@@ -5,7 +5,6 @@ from __future__ import annotations
 import copy
 
 import torch
-import torch.nn.functional as F
 from torch import nn
 
 from . import hot_ops

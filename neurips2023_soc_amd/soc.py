@@ -14,7 +14,6 @@ from __future__ import annotations
 
 import copy
 import math
-from typing import Dict, List, Optional, Sequence, Union
 
 import torch
 import torch.nn.functional as F
@@ -189,12 +188,6 @@ class SOC(nn.Module):
         """'(t h w) b c -> (b t) (h w) c' -- a free view for B = 1"""
         c = x.shape[-1]
         return x.view(T, h * w, B, c).permute(2, 0, 1, 3).reshape(B * T, h * w, c)
-
-    @staticmethod
-    def _unseq(x, B, T, h, w):
-        """'(t h w) b c -> (b t) c h w'"""
-        c = x.shape[-1]
-        return x.view(T, h, w, B, c).permute(3, 0, 4, 1, 2).reshape(B * T, c, h, w)
 
     @torch.no_grad()
     def forward(self, samples: NestedTensor, valid_indices, text_queries, targets):

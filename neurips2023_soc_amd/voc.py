@@ -7,7 +7,6 @@ attention core is the HIP kernel K3; post-norm throughout (pre_norm=False in eve
 from __future__ import annotations
 
 import torch
-import torch.nn.functional as F
 from torch import nn
 
 from . import hot_ops
