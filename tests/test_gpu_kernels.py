@@ -96,6 +96,7 @@ def _win_case(ops, B, D, H, W, nH, shift, seed):
     (10, 9, 8, 2, (4, 3, 3)),       # T>8: temporal shift 4, D padded to 16
     (10, 9, 8, 2, (0, 0, 0)),
     (2, 5, 6, 1, (4, 3, 3)),        # every axis clamped: single window, no shift at all
+    (36, 8, 9, 1, (4, 3, 3)),       # DAVIS-style 36-frame clip: 5 temporal windows, D padded to 40
 ])
 def test_window_attention_vs_oracle(ops, D, H, W, nH, shift):
     d, scale = _win_case(ops, 1, D, H, W, nH, shift, seed=D * 100 + H)
