@@ -153,6 +153,24 @@ int soc_add_layernorm_f32(const float* x, const float* y, const float* gamma, co
 int soc_upsample_threshold_u8(const float* logits, uint8_t* out, int T, int h, int w, int H0, int W0,
                               float threshold_logit, void* stream);
 
+/*
+ * K7 -- small-M linear layer out = act((x [+ x_add]) W^T + bias)  ("next": the
+ * library-GEMM share; here the latency-bound query-side layers).  Replaces nn.Linear / F.linear on
+ * the frame-query / video-query / word tensors: DeformableTransformerDecoderLayer
+ * (models/deformable_transformer.py:308-347: MultiheadAttention in/out projections, linear1/2),
+ * MSDeformAttn.sampling_offsets / attention_weights on the decoder queries
+ * (models/ops/modules/ms_deform_attn.py:96-97), VOC's attention projections and FFNs
+ * (models/voc.py:44-48,66,123), the MLP heads (models/soc.py:552-563) and the "tensor + pos" adds
+ * in front of them (with_pos_embed, deformable_transformer.py:318-320; voc.py:84-90,141-149).
+ *   x      [M, K] contiguous         w [N, K] (nn.Linear.weight layout)    bias [N] or NULL
+ *   x_add  [add_mod, K] or NULL: row m of the input is x[m] + x_add[(m / add_div) % add_mod]
+ *   out    [M, N];  relu != 0 applies max(., 0)
+ * K % 16 == 0, M <= 4096, 16-byte aligned x / x_add / w; otherwise SOC_EUNSUPPORTED (use the
+ * library GEMM).  fp32 MFMA accumulation, K split 4-ways per output tile.
+ */
+int soc_linear_small_f32(const float* x, const float* x_add, int add_div, int add_mod, const float* w,
+                         const float* bias, float* out, int M, int N, int K, int relu, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

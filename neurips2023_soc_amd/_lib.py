@@ -12,7 +12,8 @@ LIB_PATH = os.path.join(_PKG, "libsoc_hip.so")
 
 EXPORTS = ("soc_hip_abi_version", "soc_hip_error_string", "soc_msda_fwd_f32", "soc_msda_fwd_f64",
            "soc_win_attn3d_f32", "soc_xattn_workspace_bytes", "soc_xattn_f32", "soc_dyn_mask_f32",
-           "soc_add_layernorm_f32", "soc_msda_fused_fwd_f32", "soc_upsample_threshold_u8")
+           "soc_add_layernorm_f32", "soc_msda_fused_fwd_f32", "soc_upsample_threshold_u8",
+           "soc_linear_small_f32")
 ABI_VERSION = 1
 
 _lib = None
@@ -55,6 +56,8 @@ def load() -> C.CDLL:
     lib.soc_upsample_threshold_u8.argtypes = [p, p, i, i, i, i, i, f, p]
     lib.soc_add_layernorm_f32.restype = i
     lib.soc_add_layernorm_f32.argtypes = [p, p, p, p, p, p, C.c_long, i, f, p]
+    lib.soc_linear_small_f32.restype = i
+    lib.soc_linear_small_f32.argtypes = [p, p, i, i, p, p, p, i, i, i, i, p]
     if lib.soc_hip_abi_version() != ABI_VERSION:
         raise SocHipError("libsoc_hip.so ABI version mismatch; rebuild it")
     _lib = lib

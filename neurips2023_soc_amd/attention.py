@@ -3,7 +3,8 @@
 Parameter names match torch.nn.MultiheadAttention (in_proj_weight, in_proj_bias, out_proj.*) so
 reference checkpoints load unchanged (vlf/lvf: models/vla.py:11; VOC: models/voc.py:66,123;
 decoder self-attention: models/deformable_transformer.py:308).  Sequence-first layout [L,B,E].
-The input/output projections are plain fp32 GEMMs (hipBLASLt through torch).
+The input/output projections go through fused.linear: library GEMM for pixel-sized inputs, K7 for
+query / word-sized ones, where the positional add in front (`query_add`, `key_add`) is folded in.
 """
 from __future__ import annotations
 
@@ -13,7 +14,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from . import hot_ops
+from . import fused, hot_ops
 
 
 class HipMultiheadAttention(nn.Module):
@@ -28,18 +29,21 @@ class HipMultiheadAttention(nn.Module):
         nn.init.zeros_(self.out_proj.bias)
 
     def forward(self, query: torch.Tensor, key: torch.Tensor, value: torch.Tensor,
-                key_padding_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+                key_padding_mask: Optional[torch.Tensor] = None, query_add: Optional[torch.Tensor] = None,
+                key_add: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """attention(query + query_add, key + key_add, value): the *_add terms are the positional
+        embeddings the reference adds before calling nn.MultiheadAttention (with_pos_embed)."""
         if self.training:
             raise RuntimeError("HipMultiheadAttention is inference-only (no backward kernel)")
         E = self.embed_dim
         w, b = self.in_proj_weight, self.in_proj_bias
-        if query is key:
-            qk = F.linear(query, w[:2 * E], b[:2 * E])
-            q, k = qk[..., :E], qk[..., E:]
-            q, k = q.contiguous(), k.contiguous()
+        if query is key and query_add is key_add and not fused.is_small(query):
+            x = query if query_add is None else query + query_add
+            qk = F.linear(x, w[:2 * E], b[:2 * E])
+            q, k = qk[..., :E].contiguous(), qk[..., E:].contiguous()
         else:
-            q = F.linear(query, w[:E], b[:E])
-            k = F.linear(key, w[E:2 * E], b[E:2 * E])
-        v = F.linear(value, w[2 * E:], b[2 * E:])
+            q = fused.linear(query, w[:E], b[:E], add=query_add)
+            k = fused.linear(key, w[E:2 * E], b[E:2 * E], add=key_add)
+        v = fused.linear(value, w[2 * E:], b[2 * E:])
         o = hot_ops.mha_core(q, k, v, self.num_heads, key_padding_mask)
-        return self.out_proj(o)
+        return fused.apply(self.out_proj, o)

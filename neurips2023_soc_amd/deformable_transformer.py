@@ -7,7 +7,7 @@ import copy
 import torch
 from torch import nn
 
-from . import hot_ops
+from . import fused, hot_ops
 from .fused import linear_relu
 from .attention import HipMultiheadAttention
 from .ms_deform_attn import MSDeformAttn
@@ -33,7 +33,7 @@ class DeformableTransformerEncoderLayer(nn.Module):
         a, _, _ = self.self_attn(src + pos, reference_points, src, spatial_shapes, level_start_index, padding_mask,
                                  pad_flag=pad_flag, return_sampling=False)
         src = _add_norm(src, a, self.norm1)
-        return _add_norm(src, self.linear2(linear_relu(src, self.linear1)), self.norm2)
+        return _add_norm(src, fused.apply(self.linear2, linear_relu(src, self.linear1)), self.norm2)
 
 
 class DeformableTransformerEncoder(nn.Module):
@@ -80,12 +80,14 @@ class DeformableTransformerDecoderLayer(nn.Module):
 
     def forward(self, tgt, query_pos, reference_points, src, spatial_shapes, level_start_index, src_padding_mask=None,
                 pad_flag=None):
-        qk = (tgt + query_pos).transpose(0, 1)  # sequence-first for the attention core
-        tgt = _add_norm(tgt, self.self_attn(qk, qk, tgt.transpose(0, 1)).transpose(0, 1), self.norm2)
-        c, loc, w = self.cross_attn(tgt + query_pos, reference_points, src, spatial_shapes,
-                                    level_start_index, src_padding_mask, pad_flag=pad_flag, return_sampling=False)
+        x = tgt.transpose(0, 1).contiguous()    # sequence-first for the attention core
+        pos = query_pos.transpose(0, 1)
+        tgt = _add_norm(tgt, self.self_attn(x, x, x, query_add=pos, key_add=pos).transpose(0, 1), self.norm2)
+        c, loc, w = self.cross_attn(tgt, reference_points, src, spatial_shapes, level_start_index,
+                                    src_padding_mask, pad_flag=pad_flag, return_sampling=False,
+                                    query_pos=query_pos)
         tgt = _add_norm(tgt, c, self.norm1)
-        tgt = _add_norm(tgt, self.linear2(linear_relu(tgt, self.linear1)), self.norm3)
+        tgt = _add_norm(tgt, fused.apply(self.linear2, linear_relu(tgt, self.linear1)), self.norm3)
         return tgt, loc, w
 
 
@@ -201,7 +203,7 @@ class DeformableTransformer(nn.Module):
         b, t, q, c = tgt.shape
         tgt = tgt.reshape(b * t, q, c)
         qpos = query_embed.unsqueeze(0).expand(b * t, -1, -1)
-        ref = self.reference_points(qpos).sigmoid()
+        ref = self.reference_points(query_embed).sigmoid().unsqueeze(0).expand(b * t, -1, -1)
         hs, inter_refs, _ = self.decoder(tgt, ref, memory, spatial_shapes, level_start, ratios, qpos, mask, pad_flag)
         return hs, ref, inter_refs
 

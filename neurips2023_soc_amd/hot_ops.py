@@ -259,3 +259,55 @@ def upsample_threshold(mask_logits: Tensor, size: Sequence[int], threshold_logit
                                              _stream())
     _lib.check(code, "soc_upsample_threshold_u8")
     return out.view(torch.bool)
+
+
+SMALL_LINEAR_MAX_ROWS = 512
+
+
+def _broadcast_rows(add: Tensor, lead: Sequence[int], K: int):
+    """How a positional term broadcasts over the flattened rows of x: returns (base [R,K] contiguous,
+    div, mod) with row m of x + add == x[m] + base[(m // div) % mod], or None if it is not of that form."""
+    if add.dim() != len(lead) + 1 or add.shape[-1] != K or add.stride(-1) != 1:
+        return None
+    if tuple(add.shape[:-1]) != tuple(lead):
+        return None
+    live = [d for d in range(len(lead)) if lead[d] > 1 and add.stride(d) != 0]
+    if len(live) > 1:
+        # every leading dim varies: must be a plain contiguous [M,K]
+        return (add.reshape(-1, K), 1, int(add.numel() // K)) if add.is_contiguous() else None
+    if not live:
+        return add.as_strided((1, K), (K, 1)), 1, 1
+    d = live[0]
+    if add.stride(d) != K:
+        return None
+    inner = 1
+    for e in lead[d + 1:]:
+        inner *= int(e)
+    return add.as_strided((lead[d], K), (K, 1)), inner, int(lead[d])
+
+
+def linear_small(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, add: Optional[Tensor] = None,
+                 relu: bool = False) -> Tensor:
+    """K7.  act((x [+ add]) @ weight.T + bias) for few rows (x.numel() / K <= SMALL_LINEAR_MAX_ROWS is
+    what callers use it for).  `add` must have x's shape, possibly as an expanded (stride-0) view."""
+    _need_gpu(x, weight)
+    lib = _lib.load()
+    x = _f32c(x)
+    K = x.shape[-1]
+    M, N = x.numel() // K, weight.shape[0]
+    add_ptr, div, mod = None, 1, 1
+    if add is not None:
+        form = _broadcast_rows(add, x.shape[:-1], K) if add.dtype == torch.float32 else None
+        if form is None:
+            x = x + add
+        else:
+            base, div, mod = form
+            add_ptr = base.data_ptr()
+    w = _f32c(weight)
+    out = torch.empty(*x.shape[:-1], N, dtype=torch.float32, device=x.device)
+    with _timed("linear_small", (M * K + N * K + M * N) * 4):
+        code = lib.soc_linear_small_f32(x.data_ptr(), add_ptr, div, mod, w.data_ptr(),
+                                        None if bias is None else _f32c(bias).data_ptr(), out.data_ptr(),
+                                        M, N, K, int(bool(relu)), _stream())
+    _lib.check(code, "soc_linear_small_f32")
+    return out

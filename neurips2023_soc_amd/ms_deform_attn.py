@@ -14,7 +14,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from . import hot_ops
+from . import fused, hot_ops
 
 
 def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
@@ -68,27 +68,31 @@ class MSDeformAttn(nn.Module):
         nn.init.zeros_(self.output_proj.bias)
 
     def forward(self, query, reference_points, input_flatten, input_spatial_shapes,
-                input_level_start_index, input_padding_mask=None, pad_flag=None, return_sampling=True):
-        """Reference signature plus two optional arguments used by this package's own layers:
+                input_level_start_index, input_padding_mask=None, pad_flag=None, return_sampling=True,
+                query_pos=None):
+        """Reference signature plus optional arguments used by this package's own layers
+        (``query_pos``: added to ``query`` inside the offset / weight projections):
         ``return_sampling=False`` (SOC never reads the sampling locations / weights) allows the fused
         kernel, which needs ``pad_flag`` = int32[1] device tensor "the padding mask has any True"."""
         N, Lq, _ = query.shape
         _, S, _ = input_flatten.shape
         M, L, P = self.n_heads, self.n_levels, self.n_points
         value = self.value_proj(input_flatten)
+        offsets_raw = fused.apply(self.sampling_offsets, query, add=query_pos)
+        logits_raw = fused.apply(self.attention_weights, query, add=query_pos)
         if (not return_sampling and value.is_cuda and L == 4 and P == 4 and self.d_model // M == 32
                 and reference_points.shape[-1] in (2, 4)
                 and (input_padding_mask is None or pad_flag is not None)):
             out = hot_ops.msda_fused_forward(
                 value.view(N, S, M, 32), input_spatial_shapes, input_level_start_index, reference_points,
-                self.sampling_offsets(query).view(N, Lq, M, L, P, 2),
-                self.attention_weights(query).view(N, Lq, M, L * P), input_padding_mask, pad_flag)
-            return self.output_proj(out), None, None
+                offsets_raw.view(N, Lq, M, L, P, 2), logits_raw.view(N, Lq, M, L * P), input_padding_mask,
+                pad_flag)
+            return fused.apply(self.output_proj, out), None, None
         if input_padding_mask is not None:
             value = value.masked_fill(input_padding_mask[..., None], 0.0)
         value = value.view(N, S, M, self.d_model // M)
-        offsets = self.sampling_offsets(query).view(N, Lq, M, L, P, 2)
-        weights = F.softmax(self.attention_weights(query).view(N, Lq, M, L * P), -1).view(N, Lq, M, L, P)
+        offsets = offsets_raw.view(N, Lq, M, L, P, 2)
+        weights = F.softmax(logits_raw.view(N, Lq, M, L * P), -1).view(N, Lq, M, L, P)
         if reference_points.shape[-1] == 2:
             normalizer = input_spatial_shapes.flip(-1).to(offsets.dtype)  # (W_l, H_l)
             loc = reference_points[:, :, None, :, None, :] + offsets / normalizer[None, None, None, :, None, :]

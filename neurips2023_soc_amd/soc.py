@@ -19,7 +19,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from . import hot_ops
+from . import fused, hot_ops
 from .deformable_transformer import build_deforamble_transformer
 from .nested_tensor import NestedTensor, inverse_sigmoid
 from .position_encoding import PositionEmbeddingSine1D
@@ -39,9 +39,7 @@ class MLP(nn.Module):
 
     def forward(self, x):
         for i, layer in enumerate(self.layers):
-            x = layer(x)
-            if i + 1 < self.num_layers:
-                x = F.relu(x)
+            x = fused.linear(x, layer.weight, layer.bias, relu=i + 1 < self.num_layers)
         return x
 
 
@@ -56,7 +54,7 @@ class FeatureResizer(nn.Module):
         self.dropout = nn.Dropout(dropout)
 
     def forward(self, x):
-        x = self.fc(x)
+        x = fused.apply(self.fc, x)
         return self.dropout(self.layer_norm(x) if self.do_ln else x)
 
 

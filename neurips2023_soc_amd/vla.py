@@ -15,6 +15,5 @@ class MMF(nn.Module):
 
     def forward(self, tgt: Tensor, memory: Tensor, memory_key_padding_mask: Optional[Tensor] = None,
                 pos: Optional[Tensor] = None, query_pos: Optional[Tensor] = None) -> Tensor:
-        q = tgt if query_pos is None else tgt + query_pos
-        k = memory if pos is None else memory + pos
-        return tgt * self.multihead_attn(q, k, memory, memory_key_padding_mask)
+        return tgt * self.multihead_attn(tgt, memory, memory, memory_key_padding_mask, query_add=query_pos,
+                                         key_add=pos)

@@ -10,6 +10,7 @@ import torch
 from torch import nn
 
 from . import hot_ops
+from . import fused
 from .fused import linear_relu
 from .attention import HipMultiheadAttention
 
@@ -26,7 +27,7 @@ class FFNLayer(nn.Module):
         self.norm = nn.LayerNorm(d_model)
 
     def forward(self, tgt):
-        return _add_norm(tgt, self.linear2(linear_relu(tgt, self.linear1)), self.norm)
+        return _add_norm(tgt, fused.apply(self.linear2, linear_relu(tgt, self.linear1)), self.norm)
 
 
 class SelfAttentionLayer(nn.Module):
@@ -36,8 +37,8 @@ class SelfAttentionLayer(nn.Module):
         self.norm = nn.LayerNorm(d_model)
 
     def forward(self, tgt, tgt_key_padding_mask=None, query_pos=None):
-        qk = tgt if query_pos is None else tgt + query_pos
-        return _add_norm(tgt, self.self_attn(qk, qk, tgt, tgt_key_padding_mask), self.norm)
+        return _add_norm(tgt, self.self_attn(tgt, tgt, tgt, tgt_key_padding_mask, query_add=query_pos,
+                                             key_add=query_pos), self.norm)
 
 
 class CrossAttentionLayer(nn.Module):
@@ -47,9 +48,8 @@ class CrossAttentionLayer(nn.Module):
         self.norm = nn.LayerNorm(d_model)
 
     def forward(self, tgt, memory, memory_key_padding_mask=None, pos=None, query_pos=None):
-        q = tgt if query_pos is None else tgt + query_pos
-        k = memory if pos is None else memory + pos
-        return _add_norm(tgt, self.multihead_attn(q, k, memory, memory_key_padding_mask), self.norm)
+        return _add_norm(tgt, self.multihead_attn(tgt, memory, memory, memory_key_padding_mask,
+                                                  query_add=query_pos, key_add=pos), self.norm)
 
 
 class VOC(nn.Module):

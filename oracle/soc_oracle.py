@@ -522,6 +522,14 @@ def add_layernorm_core(x: Tensor, y: Optional[Tensor], weight: Tensor, bias: Ten
     return (s if (return_sum or y is None) else None), n
 
 
+def linear_core(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, add: Optional[Tensor] = None,
+                relu: bool = False) -> Tensor:
+    """Kernel-boundary form of K7: act((x + add) W^T + b), i.e. with_pos_embed + nn.Linear (+ ReLU) as
+    in reference models/deformable_transformer.py:318-347 and models/voc.py:44-48,84-90."""
+    y = F.linear(x if add is None else x + add, weight, bias)
+    return F.relu(y) if relu else y
+
+
 # ----------------------------------------------------------------------------- text
 def build_text_encoder(sd: SD):
     """HF RobertaModel (third party, as in reference models/soc.py:104) loaded from text_encoder.*"""

@@ -281,3 +281,59 @@ def test_upsample_threshold_vs_torch(ops, T, h, w, H0, W0):
         assert int(diff.sum()) <= max(2, diff.numel() // 200000)
         if diff.any():
             assert float(up[diff].abs().max()) < 1e-5
+
+
+# ------------------------------------------------------------------ K7 small-M linear
+@pytest.mark.parametrize("lead,N,K,add,relu,bias", [
+    ((160,), 256, 256, None, False, True),        # decoder / VOC projections
+    ((8, 20), 256, 256, "mod", False, True),      # tgt + query_pos, batch-first (pos per query)
+    ((20, 8), 512, 256, "div", False, True),      # sequence-first: pos row = m // 8
+    ((160,), 2048, 256, None, True, True),        # FFN up-projection + ReLU
+    ((160,), 256, 2048, None, False, True),       # FFN down-projection (long K loop)
+    ((8, 20), 169, 256, None, False, True),       # controller: N not a multiple of 16
+    ((20,), 2, 256, None, False, True),           # reference_points: N < 16
+    ((10, 1), 256, 768, "full", False, True),     # text resizer, M < 16
+    ((1,), 768, 3072, None, False, False),        # single row, no bias
+    ((3, 7, 5), 48, 16, "full", True, True),      # one K step
+    ((0,), 32, 64, None, False, True),            # empty
+])
+def test_linear_small_vs_oracle(ops, lead, N, K, add, relu, bias):
+    g = torch.Generator().manual_seed(N * 7 + K)
+    x = torch.randn(*lead, K, generator=g)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g) if bias else None
+    a = None
+    if add == "full":
+        a = torch.randn(*lead, K, generator=g)
+    elif add == "mod":       # [Q,K] broadcast over the leading (frame) dim
+        a = torch.randn(lead[1], K, generator=g)[None].expand(*lead, K)
+    elif add == "div":       # [Q,K] broadcast over the trailing (frame) dim
+        a = torch.randn(lead[0], K, generator=g)[:, None].expand(*lead, K)
+    want = O.linear_core(x.double(), w.double(), None if b is None else b.double(),
+                         None if a is None else a.double(), relu).float()
+    ad = None
+    if a is not None:        # keep the stride-0 structure on the device
+        ad = dev(a) if add == "full" else (dev(a[0])[None].expand(*lead, K) if add == "mod"
+                                           else dev(a[:, 0].contiguous())[:, None].expand(*lead, K))
+    got = ops.linear_small(dev(x), dev(w), None if b is None else dev(b), ad, relu)
+    assert got.shape == (*lead, N)
+    if got.numel():
+        assert maxdiff(got, want) < 2e-5 * max(1.0, float(want.abs().max()))
+
+
+def test_linear_small_rejects_unsupported(ops):
+    with pytest.raises(RuntimeError):       # K not a multiple of 16
+        ops.linear_small(torch.zeros(4, 10).cuda(), torch.zeros(8, 10).cuda())
+
+
+def test_fused_linear_dispatch(ops):
+    """fused.linear: K7 for few rows, library GEMM (+ReLU epilogue) for many -- same numbers."""
+    from neurips2023_soc_amd import fused
+    g = torch.Generator().manual_seed(5)
+    w, b = dev(torch.randn(64, 32, generator=g)), dev(torch.randn(64, generator=g))
+    for rows in (40, 5000):
+        x = dev(torch.randn(rows, 32, generator=g))
+        p = dev(torch.randn(rows, 32, generator=g))
+        want = O.linear_core(x.cpu().double(), w.cpu().double(), b.cpu().double(), p.cpu().double(), True).float()
+        assert fused.is_small(x) == (rows == 40)
+        assert maxdiff(fused.linear(x, w, b, add=p, relu=True), want) < 3e-5
