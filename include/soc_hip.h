@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SOC_HIP_ABI_VERSION 1
+#define SOC_HIP_ABI_VERSION 2
 
 #define SOC_OK 0
 #define SOC_EINVAL (-1)       /* null pointer / non-positive dimension */
@@ -104,13 +104,15 @@ int soc_win_attn3d_f32(const float* qkv, const float* qkv_bias, const float* bia
  *   q [Lq, B, n_heads*head_dim], k / v [Lk, B, n_heads*head_dim]
  *   key_pad_mask [B, Lk] uint8, non-zero = ignore key (may be NULL)
  *   out [Lq, B, n_heads*head_dim]
+ * batch_first != 0: q / out are [B, Lq, E] and k / v [B, Lk, E] instead (the decoder's native layout,
+ * which the reference transposes around nn.MultiheadAttention, deformable_transformer.py:333).
  * head_dim must be 32.  `workspace` is reserved for mappings that need scratch memory:
  * soc_xattn_workspace_bytes() returns 0 for every shape in this build, so NULL / 0 is fine.
  */
 size_t soc_xattn_workspace_bytes(int Lq, int Lk, int B, int n_heads, int head_dim);
 int soc_xattn_f32(const float* q, const float* k, const float* v, const uint8_t* key_pad_mask,
-                  float* out, int Lq, int Lk, int B, int n_heads, int head_dim, void* workspace,
-                  size_t workspace_bytes, void* stream);
+                  float* out, int Lq, int Lk, int B, int n_heads, int head_dim, int batch_first,
+                  void* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * K4 -- per-instance dynamic mask head (3 dynamic 1x1 conv layers over
@@ -170,6 +172,28 @@ int soc_upsample_threshold_u8(const float* logits, uint8_t* out, int T, int h, i
  */
 int soc_linear_small_f32(const float* x, const float* x_add, int add_div, int add_mod, const float* w,
                          const float* bias, float* out, int M, int N, int K, int relu, void* stream);
+/*
+ * The same for nseg <= 4 layers that read the same input (q / k / v of one attention:
+ * torch.nn.MultiheadAttention's in_proj; MSDeformAttn's sampling_offsets + attention_weights) in ONE
+ * launch.  w / bias / out / N / use_add are HOST arrays of length nseg (bias and use_add may be NULL;
+ * bias[i] may be NULL); segment i computes out[i] [M, N[i]] from x (+ x_add iff use_add[i] != 0).
+ */
+int soc_linear_small_multi_f32(const float* x, const float* x_add, int add_div, int add_mod, int nseg,
+                               const float* const* w, const float* const* bias, float* const* out,
+                               const int* N, const int* use_add, int M, int K, int relu, void* stream);
+
+/*
+ * K8 -- iterative box refinement between decoder layers, one launch.  Replaces
+ * DeformableTransformerDecoder.forward's `new = (tmp + inverse_sigmoid(reference_points)).sigmoid()`
+ * and the next layer's `reference_points_input` (models/deformable_transformer.py:358-381,
+ * inverse_sigmoid: util/misc.py) and the box head of SOC.forward (models/soc.py:330-340).
+ *   delta [N*Q, 4]  bbox_embed output     ref [N*Q, ref_dim], ref_dim 2 (only x, y are refined) or 4
+ *   new_ref [N*Q, 4]
+ *   ref_in  [N*Q, L, 4] = new_ref * (vr_x, vr_y, vr_x, vr_y) with valid_ratios [N, L, 2]; ref_in and
+ *   valid_ratios may both be NULL.
+ */
+int soc_box_refine_f32(const float* delta, const float* ref, int ref_dim, const float* valid_ratios,
+                       float* new_ref, float* ref_in, int N, int Q, int L, void* stream);
 
 #ifdef __cplusplus
 }

@@ -13,8 +13,8 @@ LIB_PATH = os.path.join(_PKG, "libsoc_hip.so")
 EXPORTS = ("soc_hip_abi_version", "soc_hip_error_string", "soc_msda_fwd_f32", "soc_msda_fwd_f64",
            "soc_win_attn3d_f32", "soc_xattn_workspace_bytes", "soc_xattn_f32", "soc_dyn_mask_f32",
            "soc_add_layernorm_f32", "soc_msda_fused_fwd_f32", "soc_upsample_threshold_u8",
-           "soc_linear_small_f32")
-ABI_VERSION = 1
+           "soc_linear_small_f32", "soc_linear_small_multi_f32", "soc_box_refine_f32")
+ABI_VERSION = 2
 
 _lib = None
 
@@ -47,7 +47,7 @@ def load() -> C.CDLL:
     lib.soc_xattn_workspace_bytes.restype = C.c_size_t
     lib.soc_xattn_workspace_bytes.argtypes = [i] * 5
     lib.soc_xattn_f32.restype = i
-    lib.soc_xattn_f32.argtypes = [p, p, p, p, p, i, i, i, i, i, p, C.c_size_t, p]
+    lib.soc_xattn_f32.argtypes = [p, p, p, p, p, i, i, i, i, i, i, p, C.c_size_t, p]
     lib.soc_dyn_mask_f32.restype = i
     lib.soc_dyn_mask_f32.argtypes = [p, p, p, p, i, i, i, i, i, f, f, i, p]
     lib.soc_msda_fused_fwd_f32.restype = i
@@ -58,6 +58,10 @@ def load() -> C.CDLL:
     lib.soc_add_layernorm_f32.argtypes = [p, p, p, p, p, p, C.c_long, i, f, p]
     lib.soc_linear_small_f32.restype = i
     lib.soc_linear_small_f32.argtypes = [p, p, i, i, p, p, p, i, i, i, i, p]
+    lib.soc_linear_small_multi_f32.restype = i
+    lib.soc_linear_small_multi_f32.argtypes = [p, p, i, i, i, p, p, p, p, p, i, i, i, p]
+    lib.soc_box_refine_f32.restype = i
+    lib.soc_box_refine_f32.argtypes = [p, p, i, p, p, p, i, i, i, p]
     if lib.soc_hip_abi_version() != ABI_VERSION:
         raise SocHipError("libsoc_hip.so ABI version mismatch; rebuild it")
     _lib = lib

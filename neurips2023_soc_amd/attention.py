@@ -30,20 +30,33 @@ class HipMultiheadAttention(nn.Module):
 
     def forward(self, query: torch.Tensor, key: torch.Tensor, value: torch.Tensor,
                 key_padding_mask: Optional[torch.Tensor] = None, query_add: Optional[torch.Tensor] = None,
-                key_add: Optional[torch.Tensor] = None) -> torch.Tensor:
+                key_add: Optional[torch.Tensor] = None, batch_first: bool = False) -> torch.Tensor:
         """attention(query + query_add, key + key_add, value): the *_add terms are the positional
-        embeddings the reference adds before calling nn.MultiheadAttention (with_pos_embed)."""
+        embeddings the reference adds before calling nn.MultiheadAttention (with_pos_embed).
+        batch_first: tensors are [B,L,E] instead of nn.MultiheadAttention's [L,B,E]."""
         if self.training:
             raise RuntimeError("HipMultiheadAttention is inference-only (no backward kernel)")
         E = self.embed_dim
         w, b = self.in_proj_weight, self.in_proj_bias
-        if query is key and query_add is key_add and not fused.is_small(query):
-            x = query if query_add is None else query + query_add
-            qk = F.linear(x, w[:2 * E], b[:2 * E])
-            q, k = qk[..., :E].contiguous(), qk[..., E:].contiguous()
+        wq, wk, wv = (w[:E], b[:E]), (w[E:2 * E], b[E:2 * E]), (w[2 * E:], b[2 * E:])
+        if query is key and query_add is key_add:
+            if fused.is_small(query):
+                if value is query:       # self-attention: q, k, v in one launch (v without the pos add)
+                    q, k, v = fused.linear_multi(query, [(*wq, True), (*wk, True), (*wv, False)], query_add)
+                else:
+                    q, k = fused.linear_multi(query, [(*wq, True), (*wk, True)], query_add)
+                    v = fused.linear(value, *wv)
+            else:
+                x = query if query_add is None else query + query_add
+                qk = F.linear(x, w[:2 * E], b[:2 * E])
+                q, k = qk[..., :E].contiguous(), qk[..., E:].contiguous()
+                v = fused.linear(value, *wv)
         else:
-            q = fused.linear(query, w[:E], b[:E], add=query_add)
-            k = fused.linear(key, w[E:2 * E], b[E:2 * E], add=key_add)
-        v = fused.linear(value, w[2 * E:], b[2 * E:])
-        o = hot_ops.mha_core(q, k, v, self.num_heads, key_padding_mask)
+            q = fused.linear(query, *wq, add=query_add)
+            if value is key and fused.is_small(key):
+                k, v = fused.linear_multi(key, [(*wk, True), (*wv, False)], key_add)
+            else:
+                k = fused.linear(key, *wk, add=key_add)
+                v = fused.linear(value, *wv)
+        o = hot_ops.mha_core(q, k, v, self.num_heads, key_padding_mask, batch_first=batch_first)
         return fused.apply(self.out_proj, o)

@@ -26,7 +26,7 @@ constexpr long ROWS_BLOCK_PATH = 8192;
 __global__ __launch_bounds__(256) void xattn_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
     const uint8_t* __restrict__ kpm, float* __restrict__ out, int Lq, int Lk, int B, int H,
-    float scale) {
+    float scale, int batch_first) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int h = blockIdx.y % H;
@@ -36,10 +36,13 @@ __global__ __launch_bounds__(256) void xattn_kernel(
     const int qc = live ? qi : Lq - 1;
     const int E = H * HD;
     const int k0 = 0, k1 = Lk;
+    // element offset of row (l, b): sequence-first (l*B + b)*E, batch-first (b*L + l)*E
+    const long q_ls = batch_first ? E : (long)B * E, q_bs = batch_first ? (long)Lq * E : E;
+    const long kstride = batch_first ? E : (long)B * E, k_bs = batch_first ? (long)Lk * E : E;
 
     float qr[HD];
     {
-        const float4* qp = reinterpret_cast<const float4*>(q + ((long)qc * B + b) * E + h * HD);
+        const float4* qp = reinterpret_cast<const float4*>(q + qc * q_ls + b * q_bs + h * HD);
 #pragma unroll
         for (int i = 0; i < HD / 4; ++i) {
             const float4 t = qp[i];
@@ -47,9 +50,8 @@ __global__ __launch_bounds__(256) void xattn_kernel(
             qr[4 * i + 2] = t.z * scale; qr[4 * i + 3] = t.w * scale;
         }
     }
-    const float* kb = k + (long)b * E + h * HD;  // + j*B*E, wave-uniform
-    const float* vb = v + (long)b * E + h * HD;
-    const long kstride = (long)B * E;
+    const float* kb = k + b * k_bs + h * HD;  // + j*kstride, wave-uniform
+    const float* vb = v + b * k_bs + h * HD;
     const uint8_t* mp = kpm ? kpm + (long)b * Lk : nullptr;
 
     // pass 1: row maximum over this block's keys
@@ -81,7 +83,7 @@ __global__ __launch_bounds__(256) void xattn_kernel(
     }
     if (!live) return;
     const float inv = 1.f / l;  // l == 0 (all keys padded) -> NaN, as torch.softmax gives
-    float4* op = reinterpret_cast<float4*>(out + ((long)qi * B + b) * E + h * HD);
+    float4* op = reinterpret_cast<float4*>(out + qi * q_ls + b * q_bs + h * HD);
 #pragma unroll
     for (int i = 0; i < HD / 4; ++i)
         op[i] = make_float4(acc[4 * i] * inv, acc[4 * i + 1] * inv, acc[4 * i + 2] * inv,
@@ -95,7 +97,7 @@ __global__ __launch_bounds__(256) void xattn_kernel(
 __global__ __launch_bounds__(256) void xattn_row_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
     const uint8_t* __restrict__ kpm, float* __restrict__ out, int Lq, int Lk, int B, int H,
-    float scale) {
+    float scale, int batch_first) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* sc = lds;                       // [Lk] scores -> probabilities
     float* red = lds + ((Lk + 3) & ~3);    // [32 slots][32 dims] partial outputs / 8 reduce words
@@ -105,14 +107,15 @@ __global__ __launch_bounds__(256) void xattn_row_kernel(
     const int b = (row / H) % B;
     const int qi = row / (H * B);
     const int E = H * HD;
-    const long kstride = (long)B * E;
-    const float* kb = k + (long)b * E + h * HD;
-    const float* vb = v + (long)b * E + h * HD;
+    const long q_ls = batch_first ? E : (long)B * E, q_bs = batch_first ? (long)Lq * E : E;
+    const long kstride = batch_first ? E : (long)B * E, k_bs = batch_first ? (long)Lk * E : E;
+    const float* kb = k + b * k_bs + h * HD;
+    const float* vb = v + b * k_bs + h * HD;
     const uint8_t* mp = kpm ? kpm + (long)b * Lk : nullptr;
 
     float qr[HD];
     {
-        const float4* qp = reinterpret_cast<const float4*>(q + ((long)qi * B + b) * E + h * HD);
+        const float4* qp = reinterpret_cast<const float4*>(q + qi * q_ls + b * q_bs + h * HD);
 #pragma unroll
         for (int i = 0; i < HD / 4; ++i) {
             const float4 t = qp[i];
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(256) void xattn_row_kernel(
         float a = 0.f;
 #pragma unroll
         for (int s2 = 0; s2 < 32; ++s2) a += red[s2 * HD + tid];
-        out[((long)qi * B + b) * E + h * HD + tid] = a / sum;
+        out[qi * q_ls + b * q_bs + h * HD + tid] = a / sum;
     }
 }
 
@@ -180,8 +183,8 @@ extern "C" size_t soc_xattn_workspace_bytes(int Lq, int Lk, int B, int n_heads, 
 
 extern "C" int soc_xattn_f32(const float* q, const float* k, const float* v,
                              const uint8_t* key_pad_mask, float* out, int Lq, int Lk, int B,
-                             int n_heads, int head_dim, void* workspace, size_t workspace_bytes,
-                             void* stream) {
+                             int n_heads, int head_dim, int batch_first, void* workspace,
+                             size_t workspace_bytes, void* stream) {
     (void)workspace; (void)workspace_bytes;
     if (!q || !k || !v || !out || Lq < 0 || Lk <= 0 || B <= 0 || n_heads <= 0) return SOC_EINVAL;
     if (head_dim != HD) return SOC_EUNSUPPORTED;
@@ -192,11 +195,11 @@ extern "C" int soc_xattn_f32(const float* q, const float* k, const float* v,
     const size_t row_lds = (size_t)(((Lk + 3) & ~3) + 32 * HD) * sizeof(float);
     if (rows <= ROWS_BLOCK_PATH && row_lds <= 64 * 1024) {
         hipLaunchKernelGGL(xattn_row_kernel, dim3((unsigned)rows), dim3(256), row_lds, st, q, k, v,
-                           key_pad_mask, out, Lq, Lk, B, n_heads, scale);
+                           key_pad_mask, out, Lq, Lk, B, n_heads, scale, batch_first);
         return soc_check_launch();
     }
     dim3 grid(soc_ceil_div(Lq, 256), B * n_heads);
     hipLaunchKernelGGL(xattn_kernel, grid, dim3(256), 0, st, q, k, v, key_pad_mask, out, Lq, Lk, B,
-                       n_heads, scale);
+                       n_heads, scale, batch_first);
     return soc_check_launch();
 }

@@ -11,7 +11,6 @@ from . import fused, hot_ops
 from .fused import linear_relu
 from .attention import HipMultiheadAttention
 from .ms_deform_attn import MSDeformAttn
-from .nested_tensor import inverse_sigmoid
 
 
 def _add_norm(x, y, norm: nn.LayerNorm):
@@ -80,9 +79,8 @@ class DeformableTransformerDecoderLayer(nn.Module):
 
     def forward(self, tgt, query_pos, reference_points, src, spatial_shapes, level_start_index, src_padding_mask=None,
                 pad_flag=None):
-        x = tgt.transpose(0, 1).contiguous()    # sequence-first for the attention core
-        pos = query_pos.transpose(0, 1)
-        tgt = _add_norm(tgt, self.self_attn(x, x, x, query_add=pos, key_add=pos).transpose(0, 1), self.norm2)
+        tgt = _add_norm(tgt, self.self_attn(tgt, tgt, tgt, query_add=query_pos, key_add=query_pos,
+                                            batch_first=True), self.norm2)
         c, loc, w = self.cross_attn(tgt, reference_points, src, spatial_shapes, level_start_index,
                                     src_padding_mask, pad_flag=pad_flag, return_sampling=False,
                                     query_pos=query_pos)
@@ -103,22 +101,21 @@ class DeformableTransformerDecoder(nn.Module):
                 query_pos=None, src_padding_mask=None, pad_flag=None):
         out = tgt
         inter, inter_refs = [], []
+        ref_in = None
         for lid, layer in enumerate(self.layers):
-            if reference_points.shape[-1] == 4:
-                ref_in = reference_points[:, :, None] * torch.cat([valid_ratios, valid_ratios], -1)[:, None]
-            else:
-                ref_in = reference_points[:, :, None] * valid_ratios[:, None]
+            if ref_in is None:           # first layer, or no box refinement: scale by the valid ratios here
+                if reference_points.shape[-1] == 4:
+                    ref_in = reference_points[:, :, None] * torch.cat([valid_ratios, valid_ratios], -1)[:, None]
+                else:
+                    ref_in = reference_points[:, :, None] * valid_ratios[:, None]
             out, _, _ = layer(out, query_pos, ref_in, src, spatial_shapes, level_start_index, src_padding_mask,
                               pad_flag)
+            ref_in = None
             # (the reference's top-30 sample bookkeeping :383-389 feeds nothing in SOC.forward)
             if self.bbox_embed is not None:
-                delta = self.bbox_embed[lid](out)
-                if reference_points.shape[-1] == 4:
-                    new_ref = (delta + inverse_sigmoid(reference_points)).sigmoid()
-                else:
-                    xy = delta[..., :2] + inverse_sigmoid(reference_points)
-                    new_ref = torch.cat([xy, delta[..., 2:]], -1).sigmoid()
-                reference_points = new_ref.detach()
+                # K8: sigmoid(delta + inverse_sigmoid(ref)) and the next layer's ref_in in one launch
+                reference_points, ref_in = hot_ops.box_refine(self.bbox_embed[lid](out), reference_points,
+                                                              valid_ratios)
             if self.return_intermediate:
                 inter.append(out)
                 inter_refs.append(reference_points)

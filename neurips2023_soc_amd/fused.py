@@ -41,6 +41,15 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     return F.relu(y) if relu else y
 
 
+def linear_multi(x: torch.Tensor, layers, add: Optional[torch.Tensor] = None):
+    """[(x + add if use_add else x) @ W.T + b for (W, b, use_add) in layers]: one K7 launch for few rows,
+    one library GEMM per layer otherwise."""
+    if is_small(x) and len(layers) <= 4:
+        return hot_ops.linear_small_multi(x, layers, add)
+    xa = x + add if (add is not None and any(u for _, _, u in layers)) else x
+    return [F.linear(xa if u else x, w, b) for w, b, u in layers]
+
+
 def linear_relu(x: torch.Tensor, lin: nn.Linear) -> torch.Tensor:
     """relu(x @ W^T + b).  Many rows: the ReLU runs in the GEMM epilogue (hipBLASLt RELU_BIAS),
     bit-identical to F.relu(lin(x)) and one read+write pass over the activation less (316 MB per

@@ -6,7 +6,8 @@ tensors or a missing library raise.
 """
 from __future__ import annotations
 
-from typing import Optional, Sequence
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
 
 import torch
 
@@ -171,13 +172,18 @@ _ws_cache = {}
 
 
 def mha_core(q: Tensor, k: Tensor, v: Tensor, n_heads: int,
-             key_padding_mask: Optional[Tensor] = None) -> Tensor:
-    """K3.  q [Lq,B,E], k/v [Lk,B,E] projected, key_padding_mask [B,Lk] bool -> [Lq,B,E]."""
+             key_padding_mask: Optional[Tensor] = None, batch_first: bool = False) -> Tensor:
+    """K3.  q [Lq,B,E], k/v [Lk,B,E] projected, key_padding_mask [B,Lk] bool -> [Lq,B,E]
+    (batch_first: q [B,Lq,E], k/v [B,Lk,E] -> [B,Lq,E])."""
     _need_gpu(q, k, v, key_padding_mask)
     lib = _lib.load()
     q, k, v = _f32c(q), _f32c(k), _f32c(v)
-    Lq, B, E = q.shape
-    Lk = k.shape[0]
+    if batch_first:
+        B, Lq, E = q.shape
+        Lk = k.shape[1]
+    else:
+        Lq, B, E = q.shape
+        Lk = k.shape[0]
     hd = E // n_heads
     out = torch.empty_like(q)
     kpm_ptr = None
@@ -195,7 +201,7 @@ def mha_core(q: Tensor, k: Tensor, v: Tensor, n_heads: int,
         ws_ptr = ws.data_ptr()
     with _timed("xattn", (2 * q.numel() + k.numel() + v.numel()) * 4):
         code = lib.soc_xattn_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), kpm_ptr, out.data_ptr(),
-                                 Lq, Lk, B, n_heads, hd, ws_ptr, need, _stream())
+                                 Lq, Lk, B, n_heads, hd, int(bool(batch_first)), ws_ptr, need, _stream())
     _lib.check(code, "soc_xattn_f32")
     return out
 
@@ -286,28 +292,66 @@ def _broadcast_rows(add: Tensor, lead: Sequence[int], K: int):
     return add.as_strided((lead[d], K), (K, 1)), inner, int(lead[d])
 
 
-def linear_small(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, add: Optional[Tensor] = None,
-                 relu: bool = False) -> Tensor:
-    """K7.  act((x [+ add]) @ weight.T + bias) for few rows (x.numel() / K <= SMALL_LINEAR_MAX_ROWS is
-    what callers use it for).  `add` must have x's shape, possibly as an expanded (stride-0) view."""
-    _need_gpu(x, weight)
+def linear_small_multi(x: Tensor, layers: Sequence[Tuple[Tensor, Optional[Tensor], bool]],
+                       add: Optional[Tensor] = None, relu: bool = False) -> List[Tensor]:
+    """K7.  Several linear layers over the same few-row input in one launch.
+    layers = [(weight [N_i,K], bias [N_i] | None, use_add), ...] (at most 4); returns
+    [act((x + add if use_add else x) @ weight.T + bias) for each layer].  `add` must have x's shape,
+    possibly as an expanded (stride-0) view."""
+    _need_gpu(x, *(w for w, _, _ in layers))
     lib = _lib.load()
     x = _f32c(x)
     K = x.shape[-1]
-    M, N = x.numel() // K, weight.shape[0]
+    M = x.numel() // K
     add_ptr, div, mod = None, 1, 1
-    if add is not None:
+    if add is not None and any(u for _, _, u in layers):
         form = _broadcast_rows(add, x.shape[:-1], K) if add.dtype == torch.float32 else None
         if form is None:
-            x = x + add
+            base, div, mod = _f32c(add.expand_as(x)).reshape(-1, K), 1, max(M, 1)
         else:
             base, div, mod = form
-            add_ptr = base.data_ptr()
-    w = _f32c(weight)
-    out = torch.empty(*x.shape[:-1], N, dtype=torch.float32, device=x.device)
-    with _timed("linear_small", (M * K + N * K + M * N) * 4):
-        code = lib.soc_linear_small_f32(x.data_ptr(), add_ptr, div, mod, w.data_ptr(),
-                                        None if bias is None else _f32c(bias).data_ptr(), out.data_ptr(),
-                                        M, N, K, int(bool(relu)), _stream())
-    _lib.check(code, "soc_linear_small_f32")
-    return out
+        add_ptr = base.data_ptr()
+    n = len(layers)
+    ws = [_f32c(w) for w, _, _ in layers]
+    bs = [None if b is None else _f32c(b) for _, b, _ in layers]
+    outs = [torch.empty(*x.shape[:-1], w.shape[0], dtype=torch.float32, device=x.device) for w in ws]
+    vp = C.c_void_p * n
+    w_arr = vp(*(w.data_ptr() for w in ws))
+    b_arr = vp(*(None if b is None else b.data_ptr() for b in bs))
+    o_arr = vp(*(o.data_ptr() for o in outs))
+    n_arr = (C.c_int * n)(*(w.shape[0] for w in ws))
+    u_arr = (C.c_int * n)(*(int(bool(u)) for _, _, u in layers))
+    with _timed("linear_small", (M * K + sum(w.numel() + M * w.shape[0] for w in ws)) * 4):
+        code = lib.soc_linear_small_multi_f32(x.data_ptr(), add_ptr, div, mod, n, w_arr, b_arr, o_arr, n_arr, u_arr,
+                                              M, K, int(bool(relu)), _stream())
+    _lib.check(code, "soc_linear_small_multi_f32")
+    return outs
+
+
+def linear_small(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, add: Optional[Tensor] = None,
+                 relu: bool = False) -> Tensor:
+    """K7.  act((x [+ add]) @ weight.T + bias) for few rows (x.numel() / K <= SMALL_LINEAR_MAX_ROWS is
+    what callers use it for)."""
+    return linear_small_multi(x, [(weight, bias, add is not None)], add, relu)[0]
+
+
+def box_refine(delta: Tensor, ref: Tensor, valid_ratios: Optional[Tensor] = None):
+    """K8.  delta [N,Q,4], ref [N,Q,2|4], valid_ratios [N,L,2] | None ->
+    (new_ref [N,Q,4] = sigmoid(delta + inverse_sigmoid(ref)) (only x, y refined when ref has 2 columns),
+     ref_in [N,Q,L,4] = new_ref[:, :, None] * cat(valid_ratios, valid_ratios)[:, None], or None)."""
+    _need_gpu(delta, ref, valid_ratios)
+    lib = _lib.load()
+    delta, ref = _f32c(delta), _f32c(ref)
+    N, Q = delta.shape[:2]
+    new_ref = torch.empty(N, Q, 4, dtype=torch.float32, device=delta.device)
+    ref_in, vr_ptr, in_ptr, L = None, None, None, 0
+    if valid_ratios is not None:
+        vr = _f32c(valid_ratios)
+        L = vr.shape[1]
+        ref_in = torch.empty(N, Q, L, 4, dtype=torch.float32, device=delta.device)
+        vr_ptr, in_ptr = vr.data_ptr(), ref_in.data_ptr()
+    with _timed("box_refine", (delta.numel() + ref.numel() + new_ref.numel() * (1 + L)) * 4):
+        code = lib.soc_box_refine_f32(delta.data_ptr(), ref.data_ptr(), ref.shape[-1], vr_ptr, new_ref.data_ptr(),
+                                      in_ptr, N, Q, L, _stream())
+    _lib.check(code, "soc_box_refine_f32")
+    return new_ref, ref_in

@@ -78,8 +78,9 @@ class MSDeformAttn(nn.Module):
         _, S, _ = input_flatten.shape
         M, L, P = self.n_heads, self.n_levels, self.n_points
         value = self.value_proj(input_flatten)
-        offsets_raw = fused.apply(self.sampling_offsets, query, add=query_pos)
-        logits_raw = fused.apply(self.attention_weights, query, add=query_pos)
+        offsets_raw, logits_raw = fused.linear_multi(
+            query, [(self.sampling_offsets.weight, self.sampling_offsets.bias, True),
+                    (self.attention_weights.weight, self.attention_weights.bias, True)], query_pos)
         if (not return_sampling and value.is_cuda and L == 4 and P == 4 and self.d_model // M == 32
                 and reference_points.shape[-1] in (2, 4)
                 and (input_padding_mask is None or pad_flag is not None)):

@@ -21,7 +21,7 @@ from torch import nn
 
 from . import fused, hot_ops
 from .deformable_transformer import build_deforamble_transformer
-from .nested_tensor import NestedTensor, inverse_sigmoid
+from .nested_tensor import NestedTensor
 from .position_encoding import PositionEmbeddingSine1D
 from .postprocessing import build_postprocessors
 from .spatial_decoder import FPNSpatialDecoder
@@ -273,7 +273,7 @@ class SOC(nn.Module):
 
         cls = self.class_embed[0](hs0)
         box = self.bbox_embed[0](hs0)
-        box = torch.cat([box[..., :2] + inverse_sigmoid(init_ref).view(B, T, Q, 2), box[..., 2:]], -1).sigmoid()
+        box = hot_ops.box_refine(box.view(B * T, Q, 4), init_ref)[0].view(B, T, Q, 4)
         params = self.controller(hs0)                                        # b t q 169
         refs = inter_refs[0][..., :2].reshape(B, T * Q, 2)
         if side is not None:

@@ -99,14 +99,17 @@ def sine_pos_1d(mask: Tensor, num_pos_feats: int = 256, temperature: float = 100
 
 # ----------------------------------------------------------------------------- hot op 3: MHA core
 def mha_core(q: Tensor, k: Tensor, v: Tensor, n_heads: int,
-             key_padding_mask: Optional[Tensor] = None) -> Tensor:
-    """softmax(q k^T / sqrt(d)) v per head, seq-first layout.
+             key_padding_mask: Optional[Tensor] = None, batch_first: bool = False) -> Tensor:
+    """softmax(q k^T / sqrt(d)) v per head, seq-first layout ([B,L,E] tensors when batch_first).
 
     q [Lq,B,E], k/v [Lk,B,E] are the *projected* tensors; key_padding_mask [B,Lk] bool, True =
     ignore.  Follows torch.nn.functional.multi_head_attention_forward (q is pre-scaled by
     1/sqrt(d), padded keys get -inf) as invoked by reference models/vla.py:20-23,
     models/voc.py:89-90,146-149 and models/deformable_transformer.py:333.
     """
+    if batch_first:
+        return mha_core(q.transpose(0, 1), k.transpose(0, 1), v.transpose(0, 1), n_heads,
+                        key_padding_mask).transpose(0, 1)
     Lq, B, E = q.shape
     Lk = k.shape[0]
     hd = E // n_heads
@@ -528,6 +531,19 @@ def linear_core(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, add: O
     in reference models/deformable_transformer.py:318-347 and models/voc.py:44-48,84-90."""
     y = F.linear(x if add is None else x + add, weight, bias)
     return F.relu(y) if relu else y
+
+
+def box_refine_core(delta: Tensor, ref: Tensor, valid_ratios: Optional[Tensor] = None):
+    """Kernel-boundary form of K8: the iterative box refinement of reference
+    models/deformable_transformer.py:369-381 plus the next layer's reference_points_input (:358-364)."""
+    if ref.shape[-1] == 4:
+        new = (delta + inverse_sigmoid(ref)).sigmoid()
+    else:
+        new = torch.cat([delta[..., :2] + inverse_sigmoid(ref), delta[..., 2:]], -1).sigmoid()
+    ref_in = None
+    if valid_ratios is not None:
+        ref_in = new[:, :, None] * torch.cat([valid_ratios, valid_ratios], -1)[:, None]
+    return new, ref_in
 
 
 # ----------------------------------------------------------------------------- text

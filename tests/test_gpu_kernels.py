@@ -337,3 +337,53 @@ def test_fused_linear_dispatch(ops):
         want = O.linear_core(x.cpu().double(), w.cpu().double(), b.cpu().double(), p.cpu().double(), True).float()
         assert fused.is_small(x) == (rows == 40)
         assert maxdiff(fused.linear(x, w, b, add=p, relu=True), want) < 3e-5
+
+
+def test_linear_small_multi_segments(ops):
+    """q / k / v style: three layers over one input in one launch, the positional add only on two."""
+    g = torch.Generator().manual_seed(11)
+    x, pos = torch.randn(8, 20, 256, generator=g), torch.randn(20, 256, generator=g)
+    ws = [torch.randn(n, 256, generator=g) / 16 for n in (256, 256, 256, 40)]
+    bs = [torch.randn(n, generator=g) for n in (256, 256, 256)] + [None]
+    use = [True, True, False, True]
+    layers = [(dev(w), None if b is None else dev(b), u) for w, b, u in zip(ws, bs, use)]
+    got = ops.linear_small_multi(dev(x), layers, dev(pos)[None].expand(8, -1, -1))
+    for o, w, b, u in zip(got, ws, bs, use):
+        want = O.linear_core(x.double(), w.double(), None if b is None else b.double(),
+                             pos.double()[None].expand(8, -1, -1) if u else None).float()
+        assert o.shape == want.shape and maxdiff(o, want) < 2e-5 * max(1.0, float(want.abs().max()))
+    with pytest.raises(RuntimeError):   # more than 4 segments
+        ops.linear_small_multi(dev(x), layers + layers[:1], None)
+
+
+@pytest.mark.parametrize("Lq,Lk,B,pad", [(20, 20, 8, 0), (300, 7, 3, 2), (5, 600, 2, 100)])
+def test_mha_core_batch_first(ops, Lq, Lk, B, pad):
+    g = torch.Generator().manual_seed(Lq + Lk)
+    q, k, v = (torch.randn(B, n, 256, generator=g) for n in (Lq, Lk, Lk))
+    kpm = None
+    if pad:
+        kpm = torch.zeros(B, Lk, dtype=torch.bool)
+        kpm[:, -pad:] = True
+    want = O.mha_core(q, k, v, 8, kpm, batch_first=True)
+    got = ops.mha_core(dev(q), dev(k), dev(v), 8, None if kpm is None else dev(kpm), batch_first=True)
+    assert maxdiff(got, want) < 2e-5
+    seq = ops.mha_core(dev(q.transpose(0, 1).contiguous()), dev(k.transpose(0, 1).contiguous()),
+                       dev(v.transpose(0, 1).contiguous()), 8, None if kpm is None else dev(kpm))
+    assert torch.equal(seq.transpose(0, 1), got)      # same kernel, same arithmetic, other strides
+
+
+@pytest.mark.parametrize("rd,with_vr", [(2, True), (4, True), (2, False), (4, False)])
+def test_box_refine_vs_oracle(ops, rd, with_vr):
+    g = torch.Generator().manual_seed(rd)
+    N, Q, L = 8, 20, 4
+    delta = torch.randn(N, Q, 4, generator=g) * 2
+    ref = torch.rand(N, Q, rd, generator=g)
+    ref[0, 0, 0], ref[0, 1, 0], ref[0, 2, 1] = 0.0, 1.0, 1e-7       # clamp / eps branches of inverse_sigmoid
+    vr = torch.rand(N, L, 2, generator=g) * 0.5 + 0.5 if with_vr else None
+    want_new, want_in = O.box_refine_core(delta, ref, vr)
+    new, ref_in = ops.box_refine(dev(delta), dev(ref), None if vr is None else dev(vr))
+    assert maxdiff(new, want_new) < 1e-6
+    if with_vr:
+        assert maxdiff(ref_in, want_in) < 1e-6
+    else:
+        assert ref_in is None

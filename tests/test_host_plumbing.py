@@ -77,6 +77,7 @@ def oracle_kernels(monkeypatch):
     monkeypatch.setattr(hot_ops, "mha_core", O.mha_core)
     monkeypatch.setattr(hot_ops, "dynamic_mask", O.dynamic_mask_core)
     monkeypatch.setattr(hot_ops, "add_layernorm", O.add_layernorm_core)
+    monkeypatch.setattr(hot_ops, "box_refine", O.box_refine_core)
 
 
 def run_cfg(model, g):
@@ -156,6 +157,6 @@ def test_c_abi_library_exports_every_declared_symbol():
     assert declared == set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.soc_hip_abi_version() == 1
+    assert lib.soc_hip_abi_version() == _lib.ABI_VERSION == 2
     assert lib.soc_xattn_workspace_bytes(240, 10, 1, 8, 32) == 0
     assert lib.soc_xattn_workspace_bytes(10, 1920, 1, 8, 32) == 0
