@@ -58,9 +58,11 @@ class DeformableTransformerEncoder(nn.Module):
         return torch.cat(pts, 1)[:, :, None] * valid_ratios[:, None]
 
     def forward(self, src, spatial_shapes, level_start_index, valid_ratios, pos=None, padding_mask=None,
-                shapes_list=None, pad_flag=None):
-        ref = self.get_reference_points(shapes_list if shapes_list is not None else spatial_shapes,
-                                        valid_ratios, src.device)
+                shapes_list=None, pad_flag=None, reference_points=None):
+        ref = reference_points
+        if ref is None:
+            ref = self.get_reference_points(shapes_list if shapes_list is not None else spatial_shapes,
+                                            valid_ratios, src.device)
         for layer in self.layers:
             src = layer(src, pos, ref, spatial_shapes, level_start_index, padding_mask, pad_flag)
         return src
@@ -167,26 +169,53 @@ class DeformableTransformer(nn.Module):
         vw = (~mask[:, 0, :]).sum(1).float() / W
         return torch.stack([vw, vh], -1)
 
-    def encode(self, srcs, masks, pos_embeds, token_major=False):
+    def _unpadded_constants(self, shapes, n, pos_embeds, device):
+        """Everything encode() derives from the geometry alone when no frame is padded (~95 tiny
+        launches, 0.45 ms at the BASELINE config): the all-False mask, valid ratios = 1, the K2 pad flag
+        = 0, the encoder reference points and pos + level_embed.  Cached per (geometry, level_embed
+        version), like the reference caches compute_mask per geometry (video_swin_transformer.py:316)."""
+        cache = self.__dict__.setdefault("_unpadded_cache", {})
+        key = (shapes, n, str(device), self.level_embed.data_ptr(), self.level_embed._version,
+               tuple(p.data_ptr() for p in pos_embeds))
+        if key not in cache:
+            if len(cache) > 16:
+                cache.clear()
+            S = sum(h * w for h, w in shapes)
+            ratios = torch.ones(n, len(shapes), 2, dtype=torch.float32, device=device)
+            cache[key] = {
+                "mask": torch.zeros(n, S, dtype=torch.bool, device=device),
+                "ratios": ratios,
+                "pad_flag": torch.zeros(1, dtype=torch.int32, device=device) if device.type == "cuda" else None,
+                "ref": DeformableTransformerEncoder.get_reference_points(list(shapes), ratios, device),
+                "pos": torch.cat([pe.flatten(2).transpose(1, 2) + self.level_embed[lvl].view(1, 1, -1)
+                                  for lvl, pe in enumerate(pos_embeds)], 1),
+            }
+        return cache[key]
+
+    def encode(self, srcs, masks, pos_embeds, token_major=False, unpadded=False):
         """Flatten the levels and run the deformable encoder.  Returns (memory maps of the 3 finest
         levels as '(b t) c h w', context for decode()).  Split from forward() so that SOC can run the
         FPN spatial decoder (needs only the maps) concurrently with the query decoder.
         ``token_major=True``: srcs are already '(b t) (h w) c' (what the fusion produces), which saves a
-        layout round trip per level; masks / pos_embeds stay '(b t) [c] h w'."""
-        flat, mflat, pflat, shapes = [], [], [], []
-        for lvl, (s, m, pe) in enumerate(zip(srcs, masks, pos_embeds)):
-            shapes.append(tuple(m.shape[-2:]))
-            flat.append(s if token_major else s.flatten(2).transpose(1, 2))
-            mflat.append(m.flatten(1))
-            pflat.append(pe.flatten(2).transpose(1, 2) + self.level_embed[lvl].view(1, 1, -1))
-        src, mask, pos = torch.cat(flat, 1), torch.cat(mflat, 1), torch.cat(pflat, 1)
+        layout round trip per level; masks / pos_embeds stay '(b t) [c] h w'.
+        ``unpadded=True``: the caller vouches (host side) that every mask is all-False."""
+        shapes = [tuple(m.shape[-2:]) for m in masks]
+        src = torch.cat([s if token_major else s.flatten(2).transpose(1, 2) for s in srcs], 1)
         spatial_shapes, level_start = self._shape_tensors(tuple(shapes), src.device)
-        ratios = torch.stack([self.get_valid_ratio(m) for m in masks], 1)
-        # one device-side flag "is there any padding" lets K2 skip the per-tap mask test without a
-        # host sync (single-video batches never pad)
-        pad_flag = mask.any().to(torch.int32).reshape(1) if mask.is_cuda else None
+        if unpadded:
+            const = self._unpadded_constants(tuple(shapes), src.shape[0], pos_embeds, src.device)
+            mask, pos, ratios, pad_flag, ref = (const[k] for k in ("mask", "pos", "ratios", "pad_flag", "ref"))
+        else:
+            mask = torch.cat([m.flatten(1) for m in masks], 1)
+            pos = torch.cat([pe.flatten(2).transpose(1, 2) + self.level_embed[lvl].view(1, 1, -1)
+                             for lvl, pe in enumerate(pos_embeds)], 1)
+            ratios = torch.stack([self.get_valid_ratio(m) for m in masks], 1)
+            # one device-side flag "is there any padding" lets K2 skip the per-tap mask test without a
+            # host sync
+            pad_flag = mask.any().to(torch.int32).reshape(1) if mask.is_cuda else None
+            ref = None
         memory = self.encoder(src, spatial_shapes, level_start, ratios, pos, mask, shapes_list=shapes,
-                              pad_flag=pad_flag)
+                              pad_flag=pad_flag, reference_points=ref)
         n, _, c = memory.shape
         maps, at = [], 0
         for (h, w) in shapes[:self.num_feature_level - 1]:

@@ -124,7 +124,7 @@ def msda_fused_forward(value: Tensor, spatial_shapes: Tensor, level_start_index:
     out = torch.empty((N, Lq, M * D), dtype=torch.float32, device=value.device)
     pm_ptr = ap_ptr = None
     if pad_mask is not None:
-        pm = pad_mask.to(torch.uint8).contiguous() if pad_mask.dtype != torch.uint8 else pad_mask.contiguous()
+        pm = _as_u8(pad_mask)
         if any_pad is None or any_pad.dtype != torch.int32:
             raise _lib.SocHipError("msda_fused_forward: pad_mask needs an int32 any_pad flag tensor")
         pm_ptr, ap_ptr = pm.data_ptr(), any_pad.data_ptr()
@@ -188,7 +188,7 @@ def mha_core(q: Tensor, k: Tensor, v: Tensor, n_heads: int,
     out = torch.empty_like(q)
     kpm_ptr = None
     if key_padding_mask is not None:
-        kpm = key_padding_mask.to(torch.uint8).contiguous()
+        kpm = _as_u8(key_padding_mask)
         kpm_ptr = kpm.data_ptr()
     need = lib.soc_xattn_workspace_bytes(Lq, Lk, B, n_heads, hd)
     ws_ptr = None
@@ -290,6 +290,14 @@ def _broadcast_rows(add: Tensor, lead: Sequence[int], K: int):
     for e in lead[d + 1:]:
         inner *= int(e)
     return add.as_strided((lead[d], K), (K, 1)), inner, int(lead[d])
+
+
+def _as_u8(mask: Tensor) -> Tensor:
+    """bool / uint8 mask as contiguous uint8 without a conversion kernel (bool is stored as 0/1 bytes)."""
+    mask = mask.contiguous()
+    if mask.dtype == torch.bool:
+        return mask.view(torch.uint8)
+    return mask if mask.dtype == torch.uint8 else mask.to(torch.uint8)
 
 
 def linear_small_multi(x: Tensor, layers: Sequence[Tuple[Tensor, Optional[Tensor], bool]],

@@ -247,7 +247,8 @@ class SOC(nn.Module):
 
         Q = self.num_queries
         tgt = words.new_zeros(B, T, Q, words.shape[-1])
-        memory, ctx = self.transformer.encode(srcs, masks, poses, token_major=True)
+        memory, ctx = self.transformer.encode(srcs, masks, poses, token_major=True,
+                                              unpadded=bool(getattr(samples, "unpadded", False)))
 
         # Fork again: the FPN spatial decoder (convs over the memory maps) only meets the query branch
         # (decoder -> VOC -> heads -> controller, ~250 small latency-bound launches) at the dynamic

@@ -18,6 +18,8 @@ ids = W.synthetic_token_ids(1, 10).cuda()
 cap = {}
 dec = model.transformer.decode
 model.transformer.decode = lambda *a, **k: cap.setdefault("dec", (a, k)) and dec(*a, **k)
+enc = model.transformer.encode
+model.transformer.encode = lambda *a, **k: cap.setdefault("enc", (a, k)) and enc(*a, **k)
 model.voc.register_forward_pre_hook(lambda m, i: cap.__setitem__("voc", i))
 
 
@@ -34,6 +36,8 @@ with torch.no_grad():
     def region():
         if which == "dec":
             return dec(*a, **k)
+        if which == "enc":
+            return enc(*cap["enc"][0], **cap["enc"][1])
         return model.voc(*cap["voc"])
     for _ in range(3):
         region()
