@@ -156,6 +156,35 @@ int soc_upsample_threshold_u8(const float* logits, uint8_t* out, int T, int h, i
                               float threshold_logit, void* stream);
 
 /*
+ * K6 (DAVIS form) -- up-sample O objects' mask logits, sigmoid, zero the scores below `threshold`, put a
+ * constant `background` plane in front and take the argmax over {background, objects}: the multi-object
+ * merge of infer_davis.py:248-272 (F.interpolate + sigmoid per object, then :264-268).
+ *   logits [O, T, h, w] f32 -> out [T, H0, W0] uint8 labels (0 = background, o + 1 = object o); the
+ *   first maximum wins, as torch.argmax.  O <= 255.
+ */
+int soc_upsample_merge_labels_u8(const float* logits, uint8_t* out, int O, int T, int h, int w, int H0,
+                                 int W0, float threshold, float background, void* stream);
+
+/*
+ * K9 -- frame pre-processing (the input side of infer_refytb.py:193-201 /
+ * infer_davis.py:214-226): decoded RGB frames -> resized, normalised model input, bit-identical to
+ *   PIL.Image.resize((w, h), BILINEAR)            datasets/transforms.py:186-216 (F.resize on a PIL image)
+ *   -> ToTensor (x / 255) -> Normalize((x - mean) / std)            infer_refytb.py:33-38
+ *   frames [T, H0, W0, 3] uint8 (HWC RGB)  ->  out [T, 3, h, w] f32;  out_u8 [T, h, w, 3] (optional, may
+ *   be NULL): the resized uint8 frames as PIL would return them.
+ * bounds_* [n_out, 2] int32 (first source index, tap count) and coeffs_* [n_out, ksize_*] int32 are
+ * Pillow's resampling tables (precompute_coeffs + normalize_coeffs_8bpc, 22 fractional bits) for the
+ * horizontal (x: W0 -> w) and vertical (y: H0 -> h) pass, in DEVICE memory; mean / std are HOST
+ * pointers to 3 floats.  workspace: soc_resize_workspace_bytes() bytes of device memory (the 8-bit
+ * intermediate image of PIL's two-pass scheme).
+ */
+size_t soc_resize_workspace_bytes(int T, int H0, int W0, int h, int w);
+int soc_resize_normalize_u8_f32(const uint8_t* frames, float* out, uint8_t* out_u8, int T, int H0, int W0,
+                                int h, int w, const int* bounds_x, const int* coeffs_x, int ksize_x,
+                                const int* bounds_y, const int* coeffs_y, int ksize_y, const float* mean,
+                                const float* std, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
  * K7 -- small-M linear layer out = act((x [+ x_add]) W^T + bias)  ("next": the
  * library-GEMM share; here the latency-bound query-side layers).  Replaces nn.Linear / F.linear on
  * the frame-query / video-query / word tensors: DeformableTransformerDecoderLayer

@@ -363,3 +363,50 @@ def box_refine(delta: Tensor, ref: Tensor, valid_ratios: Optional[Tensor] = None
                                       in_ptr, N, Q, L, _stream())
     _lib.check(code, "soc_box_refine_f32")
     return new_ref, ref_in
+
+
+def upsample_merge_labels(mask_logits: Tensor, size: Sequence[int], threshold: float = 0.5,
+                          background: float = 0.1) -> Tensor:
+    """K6, DAVIS form.  [O,T,h,w] logits of O objects -> uint8 labels [T,H0,W0] (0 = background):
+    argmax over {background, sigmoid(upsampled logits) zeroed below threshold}."""
+    _need_gpu(mask_logits)
+    lib = _lib.load()
+    x = _f32c(mask_logits)
+    O, T, h, w = x.shape
+    H0, W0 = int(size[0]), int(size[1])
+    out = torch.empty((T, H0, W0), dtype=torch.uint8, device=x.device)
+    with _timed("upsample_merge_labels", x.numel() * 4 + out.numel()):
+        code = lib.soc_upsample_merge_labels_u8(x.data_ptr(), out.data_ptr(), O, T, h, w, H0, W0, float(threshold),
+                                                float(background), _stream())
+    _lib.check(code, "soc_upsample_merge_labels_u8")
+    return out
+
+
+def resize_normalize(frames: Tensor, size: Sequence[int], tables_x, tables_y, mean: Sequence[float],
+                     std: Sequence[float], return_u8: bool = False):
+    """K9.  frames [T,H0,W0,3] uint8 -> [T,3,h,w] float32 = Normalize(ToTensor(PIL bilinear resize)).
+    tables_* = (bounds int32 [n,2], coeffs int32 [n,ksize]) device tensors from clip_io.resample_tables."""
+    _need_gpu(frames, tables_x[0], tables_x[1], tables_y[0], tables_y[1])
+    lib = _lib.load()
+    if frames.dtype != torch.uint8 or frames.dim() != 4 or frames.shape[-1] != 3:
+        raise _lib.SocHipError("resize_normalize: frames must be uint8 [T,H0,W0,3]")
+    frames = frames.contiguous()
+    T, H0, W0, _ = frames.shape
+    h, w = int(size[0]), int(size[1])
+    (bx, kx), (by, ky) = tables_x, tables_y
+    for tname, t_, n in (("bounds_x", bx, w), ("coeffs_x", kx, w), ("bounds_y", by, h), ("coeffs_y", ky, h)):
+        if t_.dtype != torch.int32 or not t_.is_contiguous() or t_.shape[0] != n:
+            raise _lib.SocHipError(f"resize_normalize: {tname} must be contiguous int32 with {n} rows")
+    out = torch.empty((T, 3, h, w), dtype=torch.float32, device=frames.device)
+    out_u8 = torch.empty((T, h, w, 3), dtype=torch.uint8, device=frames.device) if return_u8 else None
+    need = lib.soc_resize_workspace_bytes(T, H0, W0, h, w)
+    ws = torch.empty(max(need, 1), dtype=torch.uint8, device=frames.device)
+    m = (C.c_float * 3)(*(float(v) for v in mean))
+    s = (C.c_float * 3)(*(float(v) for v in std))
+    with _timed("resize_normalize", frames.numel() + out.numel() * 4):
+        code = lib.soc_resize_normalize_u8_f32(frames.data_ptr(), out.data_ptr(),
+                                               None if out_u8 is None else out_u8.data_ptr(), T, H0, W0, h, w,
+                                               bx.data_ptr(), kx.data_ptr(), kx.shape[1], by.data_ptr(),
+                                               ky.data_ptr(), ky.shape[1], m, s, ws.data_ptr(), need, _stream())
+    _lib.check(code, "soc_resize_normalize_u8_f32")
+    return (out, out_u8) if return_u8 else out

@@ -1,0 +1,154 @@
+"""Input / output side of the inference drivers: PIL-exact resize + normalise (K9),
+DAVIS label merge (K6 DAVIS form), frame loading and caching."""
+import numpy as np
+import pytest
+import torch
+
+from neurips2023_soc_amd import clip_io as CI
+from oracle import resize_oracle as R
+
+GEOMETRIES = [((720, 1280), (360, 640)), ((480, 854), (360, 640)), ((100, 37), (20, 640)), ((50, 70), (50, 640)),
+              ((33, 45), (64, 640)), ((300, 250), (360, 640)), ((1080, 1920), (360, 640))]
+
+
+def _frames(T, H0, W0, seed=0):
+    rng = np.random.default_rng(seed)
+    # smooth-ish content plus noise, full 0..255 range incl. saturated patches
+    base = rng.integers(0, 256, (T, H0 // 8 + 1, W0 // 8 + 1, 3)).repeat(8, 1).repeat(8, 2)[:, :H0, :W0]
+    noise = rng.integers(-40, 41, (T, H0, W0, 3))
+    return np.clip(base + noise, 0, 255).astype(np.uint8)
+
+
+# ------------------------------------------------------------------ CPU: oracle pinned against Pillow
+@pytest.mark.parametrize("hw,rule", GEOMETRIES)
+def test_resize_oracle_equals_pillow(hw, rule):
+    from PIL import Image
+    H0, W0 = hw
+    img = _frames(1, H0, W0, seed=H0)[0]
+    oh, ow = R.size_with_aspect_ratio(W0, H0, *rule)
+    want = np.asarray(Image.fromarray(img).resize((ow, oh), Image.BILINEAR))
+    assert np.array_equal(R.resize_bilinear_u8(img, oh, ow), want)
+
+
+def test_preprocess_oracle_equals_torch_ops():
+    """ToTensor + Normalize as torchvision does them on the CPU: .div(255), .sub_(mean).div_(std)."""
+    frames = _frames(2, 96, 128)
+    clip, small = R.preprocess_clip(frames, 48, 640)
+    t = torch.from_numpy(small).permute(0, 3, 1, 2).contiguous().to(torch.float32).div(255)
+    mean = torch.as_tensor(CI.IMAGENET_MEAN, dtype=torch.float32)
+    std = torch.as_tensor(CI.IMAGENET_STD, dtype=torch.float32)
+    t.sub_(mean[None, :, None, None]).div_(std[None, :, None, None])
+    assert np.array_equal(clip, t.numpy())
+
+
+@pytest.mark.parametrize("hw,rule", GEOMETRIES)
+def test_product_tables_equal_oracle(hw, rule):
+    H0, W0 = hw
+    oh, ow = CI.target_size(W0, H0, *rule)
+    assert (oh, ow) == R.size_with_aspect_ratio(W0, H0, *rule)
+    for a, b in ((W0, ow), (H0, oh)):
+        xmin, n, k, ksize = R.coeffs_1d(a, b)
+        bounds, coeffs = CI.resample_tables(a, b)
+        assert coeffs.shape == (b, ksize) and coeffs.dtype == np.int32
+        assert np.array_equal(bounds[:, 0], xmin) and np.array_equal(bounds[:, 1], n)
+        assert np.array_equal(coeffs, k)
+
+
+def test_target_size_rule():
+    assert CI.target_size(1280, 720) == (360, 640)      # the Ref-YouTube-VOS case
+    assert CI.target_size(854, 480) == (360, 640)       # DAVIS 480p: long side capped at 640 -> 359.7 -> 360
+    assert CI.target_size(720, 1280) == (640, 360)      # portrait
+    assert CI.target_size(640, 360) == (360, 640)       # already there
+    assert CI.target_size(500, 500, 360, 640) == (360, 360)
+
+
+def test_load_frames_and_cache(tmp_path):
+    from PIL import Image
+    frames = _frames(3, 40, 56)
+    paths = []
+    for i, f in enumerate(frames):
+        p = tmp_path / f"{i:05d}.png"                   # PNG: lossless, so the round trip is exact
+        Image.fromarray(f).save(p)
+        paths.append(str(p))
+    got = CI.load_frames(paths, workers=2)
+    assert got.dtype == torch.uint8 and np.array_equal(got.numpy(), frames)
+    with pytest.raises(ValueError):
+        CI.load_frames([])
+    calls = []
+
+    class Pre:
+        def __call__(self, fr):
+            calls.append(fr.shape)
+            return torch.zeros(fr.shape[0], 3, 4, 4), (40, 56)
+    cache = CI.VideoClipCache(Pre(), workers=1)
+    a = cache.get(paths)
+    b = cache.get(paths)
+    assert a[0] is b[0] and len(calls) == 1 and (cache.hits, cache.misses) == (1, 1)
+
+
+# ------------------------------------------------------------------ GPU
+@pytest.fixture(scope="module")
+def ops():
+    from neurips2023_soc_amd import build_ext, hot_ops
+    build_ext.build(verbose=False)
+    return hot_ops
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hw,rule,T", [(g[0], g[1], 2) for g in GEOMETRIES] + [((720, 1280), (360, 640), 8)])
+def test_resize_normalize_bit_exact(ops, hw, rule, T):
+    H0, W0 = hw
+    frames = _frames(T, H0, W0, seed=W0)
+    want, want_u8 = R.preprocess_clip(frames, *rule)
+    pre = CI.FramePreprocessor("cuda", *rule)
+    h, w = CI.target_size(W0, H0, *rule)
+    got, got_u8 = ops.resize_normalize(torch.from_numpy(frames).cuda(), (h, w), pre.tables(W0, w), pre.tables(H0, h),
+                                       CI.IMAGENET_MEAN, CI.IMAGENET_STD, return_u8=True)
+    assert np.array_equal(got_u8.cpu().numpy(), want_u8)          # PIL's bytes
+    assert np.array_equal(got.cpu().numpy(), want)                # and the same fp32 bits after normalisation
+    clip, orig = pre(torch.from_numpy(frames))
+    assert orig == (H0, W0) and torch.equal(clip, got)
+
+
+@pytest.mark.gpu
+def test_frame_pipeline_from_files(ops, tmp_path):
+    """JPEG files -> device clip, against the reference recipe run with PIL + torch on the CPU."""
+    from PIL import Image
+    frames = _frames(4, 144, 256)
+    paths = []
+    for i, f in enumerate(frames):
+        p = tmp_path / f"{i:05d}.jpg"
+        Image.fromarray(f).save(p, quality=90)
+        paths.append(str(p))
+    mean = torch.as_tensor(CI.IMAGENET_MEAN)[:, None, None]
+    std = torch.as_tensor(CI.IMAGENET_STD)[:, None, None]
+    want = []
+    for p in paths:                                                # infer_refytb.py:193-201
+        img = Image.open(p).convert("RGB")
+        oh, ow = R.size_with_aspect_ratio(*img.size, 72, 128)
+        img = img.resize((ow, oh), Image.BILINEAR)
+        t = torch.from_numpy(np.array(img)).permute(2, 0, 1).contiguous().float().div(255)
+        want.append(t.sub_(mean).div_(std))
+    cache = CI.VideoClipCache(CI.FramePreprocessor("cuda", 72, 128), workers=2)
+    clip, orig = cache.get(paths)
+    assert orig == (144, 256) and torch.equal(clip.cpu(), torch.stack(want))
+    assert cache.get(paths)[0] is clip
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("O,T,h,w,H0,W0", [(3, 4, 90, 160, 480, 854), (1, 2, 9, 11, 31, 50), (5, 1, 30, 40, 30, 40)])
+def test_upsample_merge_labels_vs_torch(ops, O, T, h, w, H0, W0):
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(O + T)
+    logits = torch.randn(O, T, h, w, generator=g) * 4
+    logits[:, :, : h // 2] += 30.0                                # saturated sigmoids: exact ties between objects
+    up = F.interpolate(logits, size=(H0, W0), mode="bilinear", align_corners=False).sigmoid()
+    m = up.clone()
+    m[m < 0.5] = 0.0                                               # infer_davis.py:264-268
+    want = torch.cat([torch.full((1, T, H0, W0), 0.1), m], 0).argmax(0)
+    got = ops.upsample_merge_labels(logits.cuda(), (H0, W0)).cpu().long()
+    bad = got != want
+    if bad.any():   # only where the two best scores are closer than the fp32 noise of interpolate + exp
+        top2 = torch.cat([torch.full((1, T, H0, W0), 0.1), m], 0).topk(2, 0)[0]
+        assert float((top2[0] - top2[1])[bad].max()) < 1e-6 or float((up - 0.5).abs().min(0)[0][bad].max()) < 1e-6
+    assert float(bad.float().mean()) < 1e-4
