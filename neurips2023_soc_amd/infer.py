@@ -18,21 +18,41 @@ import torch
 from . import clip_parallel as CP
 from . import postprocessing as P
 from .graph_runner import ClipGraph
+from .nested_tensor import NestedTensor
 
 
 class ClipInferencer:
-    """model + one hipGraph per (T, H, W, L) geometry.  `__call__` returns the reference driver's
-    per-clip products: selected query index, its mask logits, and the thresholded full-size masks."""
+    """model + (optionally) one hipGraph per (T, H, W, L) geometry.  `__call__` returns the reference
+    driver's per-clip products: selected query index, its mask logits, and the thresholded full-size
+    masks.  use_graphs=True pays off on streams of one geometry (bench, DAVIS 36-frame clips); whole-video
+    clips with free-form expressions (Ref-YouTube-VOS: T and L change per call) run eagerly."""
 
-    def __init__(self, model, device="cuda"):
+    def __init__(self, model, device="cuda", use_graphs: bool = True, max_graphs: int = 4):
         self.model, self.device = model, torch.device(device)
+        self.use_graphs, self.max_graphs = use_graphs, max_graphs
         self._graphs: Dict[Tuple[int, int, int, int], ClipGraph] = {}
 
     def graph_for(self, T: int, H: int, W: int, L: int) -> ClipGraph:
         key = (T, H, W, L)
         if key not in self._graphs:
+            while len(self._graphs) >= self.max_graphs:      # a graph pins its activation pool: keep few
+                self._graphs.pop(next(iter(self._graphs)))
             self._graphs[key] = ClipGraph(self.model, T, H, W, L, self.device)
         return self._graphs[key]
+
+    @torch.no_grad()
+    def forward_clip(self, clip: torch.Tensor, token_ids: torch.Tensor):
+        """-> (reference output dict, packed record or None)"""
+        T, _, H, W = clip.shape
+        if self.use_graphs:
+            g = self.graph_for(T, H, W, token_ids.shape[-1])
+            return g.run(clip, token_ids), g.record
+        samples = NestedTensor(clip[:, None], torch.zeros(T, 1, H, W, dtype=torch.bool, device=clip.device),
+                               unpadded=True)
+        ids = token_ids.view(1, -1)
+        out = self.model(samples, None, {"input_ids": ids, "attention_mask": torch.ones_like(ids)},
+                         [[{"size": (H, W)}] for _ in range(T)])
+        return out, None
 
     @torch.no_grad()
     def __call__(self, clip: torch.Tensor, token_ids: torch.Tensor,
@@ -40,11 +60,9 @@ class ClipInferencer:
         """clip [T,3,H,W] (normalised, on the device), token_ids [1,L] -> dict with
         'query' (0-d int64 tensor), 'mask_logits' [T,H/4,W/4], 'pred_cls' [T,Q], and, when
         original_size=(H0,W0) is given, 'masks' bool [T,H0,W0]."""
-        T, _, H, W = clip.shape
-        g = self.graph_for(T, H, W, token_ids.shape[-1])
-        out = g.run(clip, token_ids)
+        out, record = self.forward_clip(clip, token_ids)
         idx, masks = P.select_trajectory(out)
-        res = {"query": idx, "mask_logits": masks, "pred_cls": out["pred_cls"][:, 0, :, 0], "record": g.record}
+        res = {"query": idx, "mask_logits": masks, "pred_cls": out["pred_cls"][:, 0, :, 0], "record": record}
         if original_size is not None:
             res["masks"] = P.upsample_and_threshold(masks, original_size)
         return res

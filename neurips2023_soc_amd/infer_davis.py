@@ -1,0 +1,101 @@
+"""Ref-DAVIS17 inference driver: the per-process body of the reference's infer_davis.py
+(`sub_processor`, :124-297) on the MI355X pipeline.
+
+    for each video, for each of the 4 annotators                        reference :173-196
+      for each object: the video in clips of <= 36 frames              :199-216  (MSDA im2col_step limit)
+        frames -> clip (cached per video chunk), forward, best query   :217-246
+      merge the objects: up-sample, sigmoid, zero < 0.5, background 0.1, argmax   :248-272   one K6 launch
+      write <out>/anno_<a>/<video>/<%05d>.png as palette PNG            :285-291
+
+Expression i belongs to object i // 4 and annotator i % 4 (:193-199).
+"""
+from __future__ import annotations
+
+import os
+import time
+from concurrent.futures import ThreadPoolExecutor
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import clip_io, hot_ops
+from .infer import ClipInferencer
+from .infer_refytb import Tokenize, load_meta, split_videos
+
+CLIP_LEN = 36
+
+
+def davis_palette() -> list:
+    """The PASCAL-VOC / DAVIS colour map (bit-interleaved label -> RGB), what the reference reads from
+    valid/Annotations/blackswan/00000.png (:168-169)."""
+    pal = []
+    for i in range(256):
+        r = g = b = 0
+        c = i
+        for j in range(8):
+            r |= ((c >> 0) & 1) << (7 - j)
+            g |= ((c >> 1) & 1) << (7 - j)
+            b |= ((c >> 2) & 1) << (7 - j)
+            c >>= 3
+        pal += [r, g, b]
+    return pal
+
+
+def save_label_map(labels: np.ndarray, path: str, palette: Sequence[int]) -> None:
+    from PIL import Image
+    img = Image.fromarray(labels.astype(np.uint8))
+    img.putpalette(list(palette))
+    img.save(path)
+
+
+@torch.no_grad()
+def run(model, tokenize: Tokenize, root: str, out_dir: str, rank: int = 0, world: int = 1, device="cuda",
+        split: str = "valid", size: int = 360, max_size: Optional[int] = 640, use_graphs: bool = False,
+        decode_workers: int = 8, writer_workers: int = 4, palette: Optional[Sequence[int]] = None,
+        videos: Optional[Sequence[str]] = None, annotators: int = 4) -> Dict:
+    img_folder, data = load_meta(root, split)
+    if palette is None:
+        ref_png = os.path.join(root, split, "Annotations", "blackswan", "00000.png")
+        if os.path.exists(ref_png):
+            from PIL import Image
+            palette = Image.open(ref_png).getpalette()
+        else:
+            palette = davis_palette()
+    todo = split_videos(sorted(data.keys()) if videos is None else list(videos), rank, world)
+    engine = ClipInferencer(model, device, use_graphs=use_graphs)
+    cache = clip_io.VideoClipCache(clip_io.FramePreprocessor(device, size, max_size), workers=decode_workers)
+    stats = {"videos": 0, "expressions": 0, "frames": 0}
+    pending = []
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=writer_workers) as writers:
+        for video in todo:
+            frames = data[video]["frames"]
+            exps = data[video]["expressions"]
+            exp_ids = list(exps.keys())
+            num_obj = len(exp_ids) // annotators
+            for anno in range(annotators):
+                per_obj = []
+                orig = None
+                for obj in range(num_obj):
+                    text = exps[exp_ids[obj * annotators + anno]]["exp"]
+                    ids = tokenize(" ".join(text.lower().split())).to(device)
+                    chunks = []
+                    for c0 in range(0, len(frames), CLIP_LEN):
+                        clip, orig = cache.get(clip_io.frame_paths(img_folder, video, frames[c0:c0 + CLIP_LEN]))
+                        chunks.append(engine(clip, ids)["mask_logits"].clone())   # [t,h,w]
+                    per_obj.append(torch.cat(chunks, 0))
+                    stats["expressions"] += 1
+                    stats["frames"] += len(frames)
+                labels = hot_ops.upsample_merge_labels(torch.stack(per_obj), orig).cpu().numpy()   # [T,H0,W0]
+                save_dir = os.path.join(out_dir, f"anno_{anno}", video)
+                os.makedirs(save_dir, exist_ok=True)
+                for f in range(labels.shape[0]):
+                    pending.append(writers.submit(save_label_map, labels[f], os.path.join(save_dir, f"{f:05d}.png"),
+                                                  palette))
+            stats["videos"] += 1
+        for f in pending:
+            f.result()
+    torch.cuda.synchronize()
+    stats.update(seconds=time.perf_counter() - t0, cache_hits=cache.hits, cache_misses=cache.misses)
+    return stats

@@ -1,0 +1,83 @@
+"""Ref-YouTube-VOS inference driver: the per-process body of the reference's infer_refytb.py
+(`sub_processor`, :112-285) on the MI355X pipeline.
+
+    for each video (this rank's share)            reference :160, split :84-109
+      for each expression of the video            :181
+        frames -> resized, normalised clip        :191-207   here: decoded once per VIDEO, K9 on the GPU
+        forward, pick the best query              :209-226   SOC.forward (K1-K5, K7, K8) + select_trajectory
+        up-sample to the original size, > 0.5     :230-231   K6
+        write <out>/<video>/<exp_id>/<frame>.png  :269-277   8-bit 'L' PNG, 0 / 255, from a writer pool
+
+Dataset layout (reference :62-82): <root>/valid/JPEGImages/<video>/<frame>.jpg and
+<root>/meta_expressions/valid/meta_expressions.json = {"videos": {video: {"frames": [...],
+"expressions": {exp_id: {"exp": str}}}}}.  Visualisation (:233-266) is not part of the hot path.
+"""
+from __future__ import annotations
+
+import json
+import os
+import time
+from concurrent.futures import ThreadPoolExecutor
+from typing import Callable, Dict, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import clip_io
+from .infer import ClipInferencer
+
+Tokenize = Callable[[str], torch.Tensor]
+
+
+def split_videos(videos: Sequence[str], rank: int, world: int):
+    """Contiguous shares, the remainder to the last rank (reference infer_refytb.py:92-99)."""
+    per = len(videos) // world
+    return list(videos[rank * per:] if rank == world - 1 else videos[rank * per:(rank + 1) * per])
+
+
+def save_binary_mask(mask: np.ndarray, path: str) -> None:
+    """bool/0-1 [H,W] -> 8-bit 'L' PNG with 0 / 255 (reference :272-277)."""
+    from PIL import Image
+    Image.fromarray(mask.astype(np.uint8) * 255, mode="L").save(path)
+
+
+def load_meta(root: str, split: str = "valid"):
+    img_folder = os.path.join(root, split, "JPEGImages")
+    with open(os.path.join(root, "meta_expressions", split, "meta_expressions.json")) as f:
+        return img_folder, json.load(f)["videos"]
+
+
+@torch.no_grad()
+def run(model, tokenize: Tokenize, root: str, out_dir: str, rank: int = 0, world: int = 1, device="cuda",
+        split: str = "valid", size: int = 360, max_size: Optional[int] = 640, use_graphs: bool = False,
+        decode_workers: int = 8, writer_workers: int = 4, videos: Optional[Sequence[str]] = None) -> Dict:
+    """Process this rank's videos; returns counters + timings.  `tokenize(expression) -> int64 [1,L]`
+    (RobertaTokenizerFast in production; no vocabulary files exist offline, so the caller supplies it)."""
+    img_folder, data = load_meta(root, split)
+    todo = split_videos(sorted(data.keys()) if videos is None else list(videos), rank, world)
+    engine = ClipInferencer(model, device, use_graphs=use_graphs)
+    cache = clip_io.VideoClipCache(clip_io.FramePreprocessor(device, size, max_size), workers=decode_workers)
+    stats = {"videos": 0, "expressions": 0, "frames": 0}
+    pending = []
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=writer_workers) as writers:
+        for video in todo:
+            frames = data[video]["frames"]
+            paths = clip_io.frame_paths(img_folder, video, frames)
+            for exp_id, item in data[video]["expressions"].items():
+                clip, orig = cache.get(paths)                                  # decoded / resized once per video
+                ids = tokenize(" ".join(item["exp"].lower().split())).to(device)
+                res = engine(clip, ids, orig)
+                masks = res["masks"].cpu().numpy()                             # [T,H0,W0] bool
+                save_dir = os.path.join(out_dir, video, exp_id)
+                os.makedirs(save_dir, exist_ok=True)
+                for j, name in enumerate(frames):
+                    pending.append(writers.submit(save_binary_mask, masks[j], os.path.join(save_dir, name + ".png")))
+                stats["expressions"] += 1
+                stats["frames"] += len(frames)
+            stats["videos"] += 1
+        for f in pending:
+            f.result()
+    torch.cuda.synchronize()
+    stats.update(seconds=time.perf_counter() - t0, cache_hits=cache.hits, cache_misses=cache.misses)
+    return stats

@@ -1,0 +1,67 @@
+"""Synthetic stand-ins for what is not available offline: a Ref-YouTube-VOS / Ref-DAVIS shaped dataset
+directory (JPEG frames + meta_expressions.json) and a vocabulary-free tokenizer.  For smoke runs,
+tests and pipeline timing only -- never a substitute for the real tokenizer or data in evaluation."""
+from __future__ import annotations
+
+import json
+import os
+from typing import Sequence
+
+import numpy as np
+import torch
+
+WORDS = ("a", "the", "person", "dog", "cat", "car", "left", "right", "walking", "running", "red", "white", "black",
+         "small", "large", "in", "on", "front", "behind", "of", "with", "holding", "riding", "standing", "jumping")
+
+
+class HashTokenizer:
+    """str -> int64 [1, L] = <s> + one id per whitespace word (FNV-1a into [3, vocab)) + </s>.
+    Deterministic and vocabulary-free; RoBERTa's real BPE needs files that cannot be fetched here."""
+
+    def __init__(self, vocab_size: int = 50265):
+        self.vocab_size = vocab_size
+
+    def __call__(self, text: str) -> torch.Tensor:
+        ids = [0]
+        for word in text.split():
+            h = 0xCBF29CE484222325
+            for ch in word.encode():
+                h = ((h ^ ch) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+            ids.append(3 + h % (self.vocab_size - 3))
+        ids.append(2)
+        return torch.tensor([ids], dtype=torch.long)
+
+
+def _frame(rng, h, w, t):
+    """blocky moving pattern + noise: compresses like a natural JPEG, differs per frame"""
+    cells = rng.integers(0, 256, (h // 16 + 5, w // 16 + 10, 3))      # margin for t <= 64
+    img = cells.repeat(16, 0).repeat(16, 1)[t:t + h, 2 * t:2 * t + w]
+    return np.clip(img + rng.integers(-12, 13, (h, w, 3)), 0, 255).astype(np.uint8)
+
+
+def make_dataset(root: str, videos: int = 2, frames: int = 8, height: int = 720, width: int = 1280,
+                 expressions: int = 2, seed: int = 0, split: str = "valid", quality: int = 90,
+                 words: Sequence[str] = WORDS) -> str:
+    """Writes <root>/<split>/JPEGImages/<video>/<%05d>.jpg and <root>/meta_expressions/<split>/meta_expressions.json."""
+    from PIL import Image
+    rng = np.random.default_rng(seed)
+    meta = {"videos": {}}
+    for v in range(videos):
+        name = f"video{v:03d}"
+        folder = os.path.join(root, split, "JPEGImages", name)
+        os.makedirs(folder, exist_ok=True)
+        names = [f"{5 * t:05d}" for t in range(frames)]
+        vr = np.random.default_rng(seed * 1000 + v)
+        for t, n in enumerate(names):
+            Image.fromarray(_frame(np.random.default_rng(seed * 1000 + v), height, width, t)).save(
+                os.path.join(folder, n + ".jpg"), quality=quality)
+        exps = {}
+        for e in range(expressions):
+            k = int(vr.integers(3, 9))
+            exps[str(e)] = {"exp": " ".join(words[int(i)] for i in rng.integers(0, len(words), k))}
+        meta["videos"][name] = {"frames": names, "expressions": exps}
+    mdir = os.path.join(root, "meta_expressions", split)
+    os.makedirs(mdir, exist_ok=True)
+    with open(os.path.join(mdir, "meta_expressions.json"), "w") as f:
+        json.dump(meta, f)
+    return root
