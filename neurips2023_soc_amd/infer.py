@@ -4,6 +4,8 @@ multi-GPU form of its `sub_processor` fan-out (infer_refytb.py:84-109, SURVEY.md
 
     python -m neurips2023_soc_amd.infer --clips 16            # synthetic Ref-YouTube-VOS-like stream
     python -m torch.distributed.run --nproc-per-node 8 -m neurips2023_soc_amd.infer --clips 64
+    python -m neurips2023_soc_amd.infer --dataset refytb --root DATA --out RUNS [--tokenizer DIR] [--checkpoint CKPT]
+    python -m neurips2023_soc_amd.infer --dataset davis --root DATA --out RUNS --make-synthetic 4   # writes DATA first
 """
 from __future__ import annotations
 
@@ -68,6 +70,50 @@ class ClipInferencer:
         return res
 
 
+def _run_dataset(a):
+    """infer_refytb.py / infer_davis.py `main`: one process per GPU over a static split of the videos
+    (reference infer_refytb.py:84-109), no collective -- every rank writes its own PNGs."""
+    from . import build_model, default_args, infer_davis, infer_refytb, synthetic_dataset
+    from . import weights as W
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if a.make_synthetic and rank == 0:
+        expressions = 8 if a.dataset == "davis" else 3
+        synthetic_dataset.make_dataset(a.root, videos=a.make_synthetic, frames=a.frames, expressions=expressions,
+                                       n_words=a.words)
+    meta = os.path.join(a.root, "meta_expressions", "valid", "meta_expressions.json")
+    for _ in range(600):                       # other ranks: the meta file is written last
+        if os.path.exists(meta):
+            break
+        time.sleep(0.2)
+    model, _, _ = build_model(default_args(a.backbone, text_encoder_random_init=a.checkpoint is None))
+    if a.checkpoint:
+        state = torch.load(a.checkpoint, map_location="cpu")["model_state_dict"]
+        missing, unexpected = model.load_state_dict(state, strict=False)        # reference :137-150
+        unexpected = [k for k in unexpected if not k.endswith(("total_params", "total_ops"))]
+        if missing or unexpected:
+            print(f"Missing Keys: {missing}\nUnexpected Keys: {unexpected}")
+    else:
+        W.load_synthetic(model, 2023)
+    if a.tokenizer:
+        from transformers import RobertaTokenizerFast
+        hf = RobertaTokenizerFast.from_pretrained(a.tokenizer)
+
+        def tokenize(text):
+            return hf(text, return_tensors="pt")["input_ids"]
+    else:
+        tokenize = synthetic_dataset.HashTokenizer()
+    driver = infer_refytb if a.dataset == "refytb" else infer_davis
+    model = model.to(dev).eval()
+    engine = ClipInferencer(model, dev, use_graphs=a.graphs)      # shared across passes: graphs stay captured
+    for _ in range(max(a.repeat, 1)):
+        stats = driver.run(model, tokenize, a.root, a.out, rank, world, dev, engine=engine)
+    stats["clips_per_s"] = stats["expressions"] / stats["seconds"]
+    print(json.dumps({"rank": rank, "world": world, **stats}))
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--clips", type=int, default=16)
@@ -76,7 +122,19 @@ def main(argv=None):
     ap.add_argument("--height", type=int, default=360)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--orig", type=int, nargs=2, default=[720, 1280], help="original frame size for the output masks")
+    ap.add_argument("--dataset", choices=["refytb", "davis"], help="run a dataset driver instead of the clip stream")
+    ap.add_argument("--root", help="dataset root (JPEGImages + meta_expressions, reference layout)")
+    ap.add_argument("--out", help="output directory for the mask PNGs")
+    ap.add_argument("--tokenizer", help="directory with RobertaTokenizerFast files (default: synthetic hash tokenizer)")
+    ap.add_argument("--checkpoint", help="reference checkpoint (.pth with 'model_state_dict'); default: synthetic weights")
+    ap.add_argument("--make-synthetic", type=int, default=0, metavar="N",
+                    help="first write an N-video synthetic dataset (720x1280 JPEGs) under --root")
+    ap.add_argument("--graphs", action="store_true", help="hipGraph replay per clip geometry in the dataset drivers")
+    ap.add_argument("--words", type=int, default=0, help="--make-synthetic: fixed number of words per expression")
+    ap.add_argument("--repeat", type=int, default=1, help="run the driver this many times, report the last (warm) pass")
     a = ap.parse_args(argv)
+    if a.dataset:
+        return _run_dataset(a)
     import torch.distributed as dist
     from . import build_model, default_args
     from . import weights as W

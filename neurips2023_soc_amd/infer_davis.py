@@ -52,8 +52,9 @@ def save_label_map(labels: np.ndarray, path: str, palette: Sequence[int]) -> Non
 @torch.no_grad()
 def run(model, tokenize: Tokenize, root: str, out_dir: str, rank: int = 0, world: int = 1, device="cuda",
         split: str = "valid", size: int = 360, max_size: Optional[int] = 640, use_graphs: bool = False,
-        decode_workers: int = 8, writer_workers: int = 4, palette: Optional[Sequence[int]] = None,
-        videos: Optional[Sequence[str]] = None, annotators: int = 4) -> Dict:
+        decode_workers: int = 8, writer_workers: int = 16, palette: Optional[Sequence[int]] = None,
+        videos: Optional[Sequence[str]] = None, annotators: int = 4,
+        engine: Optional[ClipInferencer] = None) -> Dict:
     img_folder, data = load_meta(root, split)
     if palette is None:
         ref_png = os.path.join(root, split, "Annotations", "blackswan", "00000.png")
@@ -63,15 +64,18 @@ def run(model, tokenize: Tokenize, root: str, out_dir: str, rank: int = 0, world
         else:
             palette = davis_palette()
     todo = split_videos(sorted(data.keys()) if videos is None else list(videos), rank, world)
-    engine = ClipInferencer(model, device, use_graphs=use_graphs)
+    engine = engine or ClipInferencer(model, device, use_graphs=use_graphs)
     cache = clip_io.VideoClipCache(clip_io.FramePreprocessor(device, size, max_size), workers=decode_workers)
-    stats = {"videos": 0, "expressions": 0, "frames": 0}
+    stats = {"videos": 0, "expressions": 0, "frames": 0, "seconds_input": 0.0, "seconds_model": 0.0}
     pending = []
     t0 = time.perf_counter()
     with ThreadPoolExecutor(max_workers=writer_workers) as writers:
-        for video in todo:
+        for vi, video in enumerate(todo):
             frames = data[video]["frames"]
             exps = data[video]["expressions"]
+            if vi + 1 < len(todo):      # decode the next video's first clip while this one is on the GPU
+                nxt = todo[vi + 1]
+                cache.prefetch(clip_io.frame_paths(img_folder, nxt, data[nxt]["frames"][:CLIP_LEN]))
             exp_ids = list(exps.keys())
             num_obj = len(exp_ids) // annotators
             for anno in range(annotators):
@@ -82,20 +86,26 @@ def run(model, tokenize: Tokenize, root: str, out_dir: str, rank: int = 0, world
                     ids = tokenize(" ".join(text.lower().split())).to(device)
                     chunks = []
                     for c0 in range(0, len(frames), CLIP_LEN):
+                        t1 = time.perf_counter()
                         clip, orig = cache.get(clip_io.frame_paths(img_folder, video, frames[c0:c0 + CLIP_LEN]))
+                        stats["seconds_input"] += time.perf_counter() - t1
                         chunks.append(engine(clip, ids)["mask_logits"].clone())   # [t,h,w]
                     per_obj.append(torch.cat(chunks, 0))
                     stats["expressions"] += 1
                     stats["frames"] += len(frames)
+                t2 = time.perf_counter()
                 labels = hot_ops.upsample_merge_labels(torch.stack(per_obj), orig).cpu().numpy()   # [T,H0,W0]
+                stats["seconds_model"] += time.perf_counter() - t2    # waits for this annotator's forwards
                 save_dir = os.path.join(out_dir, f"anno_{anno}", video)
                 os.makedirs(save_dir, exist_ok=True)
                 for f in range(labels.shape[0]):
                     pending.append(writers.submit(save_label_map, labels[f], os.path.join(save_dir, f"{f:05d}.png"),
                                                   palette))
             stats["videos"] += 1
+        t_tail = time.perf_counter()
         for f in pending:
             f.result()
+        stats["seconds_writer_tail"] = time.perf_counter() - t_tail
     torch.cuda.synchronize()
     stats.update(seconds=time.perf_counter() - t0, cache_hits=cache.hits, cache_misses=cache.misses)
     return stats

@@ -50,34 +50,68 @@ def load_meta(root: str, split: str = "valid"):
 @torch.no_grad()
 def run(model, tokenize: Tokenize, root: str, out_dir: str, rank: int = 0, world: int = 1, device="cuda",
         split: str = "valid", size: int = 360, max_size: Optional[int] = 640, use_graphs: bool = False,
-        decode_workers: int = 8, writer_workers: int = 4, videos: Optional[Sequence[str]] = None) -> Dict:
+        decode_workers: int = 8, writer_workers: int = 16, videos: Optional[Sequence[str]] = None,
+        engine: Optional[ClipInferencer] = None) -> Dict:
     """Process this rank's videos; returns counters + timings.  `tokenize(expression) -> int64 [1,L]`
     (RobertaTokenizerFast in production; no vocabulary files exist offline, so the caller supplies it)."""
     img_folder, data = load_meta(root, split)
     todo = split_videos(sorted(data.keys()) if videos is None else list(videos), rank, world)
-    engine = ClipInferencer(model, device, use_graphs=use_graphs)
+    engine = engine or ClipInferencer(model, device, use_graphs=use_graphs)
     cache = clip_io.VideoClipCache(clip_io.FramePreprocessor(device, size, max_size), workers=decode_workers)
-    stats = {"videos": 0, "expressions": 0, "frames": 0}
+    stats = {"videos": 0, "expressions": 0, "frames": 0, "seconds_input": 0.0, "seconds_model": 0.0}
     pending = []
     t0 = time.perf_counter()
+
+    def flush(job):
+        """clip i's masks -> PNG jobs; called after clip i+1 has been enqueued, so the D2H copy, the numpy
+        view and the job submission overlap the next forward instead of idling the GPU"""
+        host, done, save_dir, names = job
+        done.synchronize()
+        masks = host.numpy().copy()            # the pinned buffer is reused two clips later
+        for j, name in enumerate(names):
+            pending.append(writers.submit(save_binary_mask, masks[j], os.path.join(save_dir, name + ".png")))
+
+    pinned: Dict = {}                      # two host buffers per mask shape, reused (pinning is slow)
+
+    def host_buffer(shape, slot):
+        key = (tuple(shape), slot)
+        if key not in pinned:
+            pinned[key] = torch.empty(tuple(shape), dtype=torch.bool, pin_memory=True)
+        return pinned[key]
+
     with ThreadPoolExecutor(max_workers=writer_workers) as writers:
-        for video in todo:
+        prev = None
+        for vi, video in enumerate(todo):
             frames = data[video]["frames"]
             paths = clip_io.frame_paths(img_folder, video, frames)
+            if vi + 1 < len(todo):      # decode the next video's JPEGs while this one is on the GPU
+                cache.prefetch(clip_io.frame_paths(img_folder, todo[vi + 1], data[todo[vi + 1]]["frames"]))
             for exp_id, item in data[video]["expressions"].items():
+                t1 = time.perf_counter()
                 clip, orig = cache.get(paths)                                  # decoded / resized once per video
-                ids = tokenize(" ".join(item["exp"].lower().split())).to(device)
-                res = engine(clip, ids, orig)
-                masks = res["masks"].cpu().numpy()                             # [T,H0,W0] bool
+                ids = tokenize(" ".join(item["exp"].lower().split())).pin_memory().to(device, non_blocking=True)
+                t2 = time.perf_counter()
+                masks = engine(clip, ids, orig)["masks"]                       # [T,H0,W0] bool, still in flight
+                host = host_buffer(masks.shape, stats["expressions"] % 2)
+                host.copy_(masks, non_blocking=True)
+                done = torch.cuda.Event()
+                done.record()
                 save_dir = os.path.join(out_dir, video, exp_id)
                 os.makedirs(save_dir, exist_ok=True)
-                for j, name in enumerate(frames):
-                    pending.append(writers.submit(save_binary_mask, masks[j], os.path.join(save_dir, name + ".png")))
+                if prev is not None:
+                    flush(prev)
+                prev = (host, done, save_dir, frames)
+                stats["seconds_input"] += t2 - t1
+                stats["seconds_model"] += time.perf_counter() - t2
                 stats["expressions"] += 1
                 stats["frames"] += len(frames)
             stats["videos"] += 1
+        if prev is not None:
+            flush(prev)
+        t_tail = time.perf_counter()
         for f in pending:
             f.result()
+        stats["seconds_writer_tail"] = time.perf_counter() - t_tail
     torch.cuda.synchronize()
     stats.update(seconds=time.perf_counter() - t0, cache_hits=cache.hits, cache_misses=cache.misses)
     return stats

@@ -41,8 +41,9 @@ def _frame(rng, h, w, t):
 
 def make_dataset(root: str, videos: int = 2, frames: int = 8, height: int = 720, width: int = 1280,
                  expressions: int = 2, seed: int = 0, split: str = "valid", quality: int = 90,
-                 words: Sequence[str] = WORDS) -> str:
-    """Writes <root>/<split>/JPEGImages/<video>/<%05d>.jpg and <root>/meta_expressions/<split>/meta_expressions.json."""
+                 words: Sequence[str] = WORDS, n_words: int = 0) -> str:
+    """Writes <root>/<split>/JPEGImages/<video>/<%05d>.jpg and <root>/meta_expressions/<split>/meta_expressions.json.
+    n_words > 0 fixes the expression length (one token count -> one hipGraph geometry)."""
     from PIL import Image
     rng = np.random.default_rng(seed)
     meta = {"videos": {}}
@@ -57,7 +58,7 @@ def make_dataset(root: str, videos: int = 2, frames: int = 8, height: int = 720,
                 os.path.join(folder, n + ".jpg"), quality=quality)
         exps = {}
         for e in range(expressions):
-            k = int(vr.integers(3, 9))
+            k = n_words or int(vr.integers(3, 9))
             exps[str(e)] = {"exp": " ".join(words[int(i)] for i in rng.integers(0, len(words), k))}
         meta["videos"][name] = {"frames": names, "expressions": exps}
     mdir = os.path.join(root, "meta_expressions", split)

@@ -84,6 +84,11 @@ def test_load_frames_and_cache(tmp_path):
     a = cache.get(paths)
     b = cache.get(paths)
     assert a[0] is b[0] and len(calls) == 1 and (cache.hits, cache.misses) == (1, 1)
+    cache.prefetch(paths[:2])                                # background decode, consumed by the next get
+    cache.prefetch(paths[:2])
+    assert len(cache._inflight) == 1
+    c = cache.get(paths[:2])
+    assert calls[-1] == (2, 40, 56, 3) and not cache._inflight and c[1] == (40, 56)
 
 
 # ------------------------------------------------------------------ GPU
