@@ -12,7 +12,8 @@ t0, t1 = int(seg[0]["Start_Timestamp"]), int(seg[-1]["End_Timestamp"])
 
 
 def cat(n):
-    if any(k in n for k in ("win_attn", "msda", "xattn", "dyn_mask", "add_layernorm")):
+    if any(k in n for k in ("win_attn", "msda", "xattn", "dyn_mask", "add_layernorm", "linear_small", "box_refine",
+                            "upsample_", "resize_")):
         return "soc_hip kernels"
     if n.startswith("Cijk"):
         return "GEMM (hipBLASLt/rocBLAS)"
