@@ -56,6 +56,23 @@ int soc_msda_fwd_f64(const double* value, const int64_t* spatial_shapes,
                      int Lq, int P, void* stream);
 
 /*
+ * K2 backward -- gradients of the op above with respect to value, sampling_loc and attn_weight
+ * (training side of the reference's native module: MSDA.ms_deform_attn_backward,
+ * models/ops/src/vision.cpp:13-16, src/cuda/ms_deform_attn_cuda.cu:83-153, kernels
+ * src/cuda/ms_deform_im2col_cuda.cuh:301-921; called from functions/ms_deform_attn_func.py:31-38).
+ *   grad_out [N, Lq, M*D]  ->  grad_value [N, S, M, D] (zeroed, then accumulated with atomics),
+ *   grad_sampling_loc [N, Lq, M, L, P, 2], grad_attn_weight [N, Lq, M, L, P]; any D.
+ */
+int soc_msda_bwd_f32(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                     const float* sampling_loc, const float* attn_weight, const float* grad_out,
+                     float* grad_value, float* grad_sampling_loc, float* grad_attn_weight, int N, int S,
+                     int M, int D, int L, int Lq, int P, void* stream);
+int soc_msda_bwd_f64(const double* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                     const double* sampling_loc, const double* attn_weight, const double* grad_out,
+                     double* grad_value, double* grad_sampling_loc, double* grad_attn_weight, int N, int S,
+                     int M, int D, int L, int Lq, int P, void* stream);
+
+/*
  * K2 (fused form) -- the same sampling core with the arithmetic MSDeformAttn.forward wraps around
  * it folded in (models/ops/modules/ms_deform_attn.py:95-112): softmax over the L*P attention
  * logits, sampling locations from reference points + raw offsets, and the value padding mask.

@@ -14,7 +14,8 @@ EXPORTS = ("soc_hip_abi_version", "soc_hip_error_string", "soc_msda_fwd_f32", "s
            "soc_win_attn3d_f32", "soc_xattn_workspace_bytes", "soc_xattn_f32", "soc_dyn_mask_f32",
            "soc_add_layernorm_f32", "soc_msda_fused_fwd_f32", "soc_upsample_threshold_u8",
            "soc_linear_small_f32", "soc_linear_small_multi_f32", "soc_box_refine_f32",
-           "soc_upsample_merge_labels_u8", "soc_resize_workspace_bytes", "soc_resize_normalize_u8_f32")
+           "soc_upsample_merge_labels_u8", "soc_resize_workspace_bytes", "soc_resize_normalize_u8_f32",
+           "soc_msda_bwd_f32", "soc_msda_bwd_f64")
 ABI_VERSION = 2
 
 _lib = None
@@ -43,6 +44,9 @@ def load() -> C.CDLL:
     for fn in (lib.soc_msda_fwd_f32, lib.soc_msda_fwd_f64):
         fn.restype = i
         fn.argtypes = [p, p, p, p, p, p, i, i, i, i, i, i, i, p]
+    for fn in (lib.soc_msda_bwd_f32, lib.soc_msda_bwd_f64):
+        fn.restype = i
+        fn.argtypes = [p] * 9 + [i] * 7 + [p]
     lib.soc_win_attn3d_f32.restype = i
     lib.soc_win_attn3d_f32.argtypes = [p, p, p, p] + [i] * 15 + [p]
     lib.soc_xattn_workspace_bytes.restype = C.c_size_t

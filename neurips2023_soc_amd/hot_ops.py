@@ -109,6 +109,36 @@ def msda_forward(value: Tensor, spatial_shapes: Tensor, level_start_index: Tenso
     return out
 
 
+def msda_backward(value: Tensor, spatial_shapes: Tensor, level_start_index: Tensor, sampling_loc: Tensor,
+                  attn_weight: Tensor, grad_output: Tensor):
+    """K2 backward.  Same tensors as msda_forward plus grad_output [N,Lq,M*D] ->
+    (grad_value [N,S,M,D], grad_sampling_loc [N,Lq,M,L,P,2], grad_attn_weight [N,Lq,M,L,P])."""
+    _need_gpu(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output)
+    lib = _lib.load()
+    if value.dtype == torch.float32:
+        fn = lib.soc_msda_bwd_f32
+    elif value.dtype == torch.float64:
+        fn = lib.soc_msda_bwd_f64
+    else:
+        raise RuntimeError("ms_deform_attn_backward supports float32/float64 only")
+    if spatial_shapes.dtype != torch.int64 or level_start_index.dtype != torch.int64:
+        raise RuntimeError("spatial_shapes / level_start_index must be int64")
+    tensors = [value, sampling_loc, attn_weight, grad_output]
+    if any(x.dtype != value.dtype for x in tensors):
+        raise RuntimeError("value / sampling_loc / attn_weight / grad_output dtypes differ")
+    value, sampling_loc, attn_weight, grad_output = (x.contiguous() for x in tensors)
+    N, S, M, D = value.shape
+    _, Lq, _, L, P, _ = sampling_loc.shape
+    gv, gl, ga = torch.empty_like(value), torch.empty_like(sampling_loc), torch.empty_like(attn_weight)
+    with _timed("msda_bwd", (2 * value.numel() + 2 * sampling_loc.numel() + 2 * attn_weight.numel()
+                             + grad_output.numel()) * value.element_size()):
+        code = fn(value.data_ptr(), spatial_shapes.contiguous().data_ptr(), level_start_index.contiguous().data_ptr(),
+                  sampling_loc.data_ptr(), attn_weight.data_ptr(), grad_output.data_ptr(), gv.data_ptr(),
+                  gl.data_ptr(), ga.data_ptr(), N, S, M, D, L, Lq, P, _stream())
+    _lib.check(code, "soc_msda_bwd")
+    return gv, gl, ga
+
+
 def msda_fused_forward(value: Tensor, spatial_shapes: Tensor, level_start_index: Tensor,
                        reference_points: Tensor, offsets: Tensor, logits: Tensor,
                        pad_mask: Optional[Tensor] = None, any_pad: Optional[Tensor] = None) -> Tensor:

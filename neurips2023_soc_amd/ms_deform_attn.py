@@ -26,17 +26,36 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
     return hot_ops.msda_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight)
 
 
-def ms_deform_attn_backward(*args, **kwargs):
-    raise NotImplementedError("forward-only build: the MSDA backward kernels are training-only "
-                              "(SURVEY.md 8f rank 4)")
+def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output,
+                            im2col_step: int):
+    """(grad_value, grad_sampling_loc, grad_attn_weight): the other entry point of the reference
+    extension module (vision.cpp:13-16, ms_deform_attn_cuda.cu:83-153)."""
+    batch = value.shape[0]
+    step = min(batch, int(im2col_step))
+    if step <= 0 or batch % step != 0:
+        raise RuntimeError(f"batch({batch}) must divide im2col_step({step})")
+    return hot_ops.msda_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output)
 
 
-class MSDeformAttnFunction:
-    """Inference stand-in for the reference autograd Function (functions/ms_deform_attn_func.py:21-38)."""
+class MSDeformAttnFunction(torch.autograd.Function):
+    """The reference autograd Function (functions/ms_deform_attn_func.py:21-38) on K2 / K2 backward."""
 
     @staticmethod
-    def apply(value, shapes, lsi, loc, w, im2col_step):
-        return ms_deform_attn_forward(value, shapes, lsi, loc, w, im2col_step)
+    def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights,
+                im2col_step):
+        ctx.im2col_step = im2col_step
+        output = ms_deform_attn_forward(value, value_spatial_shapes, value_level_start_index, sampling_locations,
+                                        attention_weights, ctx.im2col_step)
+        ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index, sampling_locations,
+                              attention_weights)
+        return output
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_output):
+        value, shapes, lsi, loc, w = ctx.saved_tensors
+        gv, gl, ga = ms_deform_attn_backward(value, shapes, lsi, loc, w, grad_output.contiguous(), ctx.im2col_step)
+        return gv, None, None, gl, ga, None
 
 
 class MSDeformAttn(nn.Module):

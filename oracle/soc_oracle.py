@@ -525,6 +525,16 @@ def add_layernorm_core(x: Tensor, y: Optional[Tensor], weight: Tensor, bias: Ten
     return (s if (return_sum or y is None) else None), n
 
 
+def msda_backward_core(value: Tensor, shapes: Tensor, level_start: Tensor, loc: Tensor, w: Tensor,
+                       grad_out: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+    """(grad_value, grad_loc, grad_w) of msda_core by autograd -- the quantity the reference's native
+    backward (ms_deform_attn_cuda.cu:83-153) returns and its gradcheck (models/ops/test.py:62-80) verifies."""
+    with torch.enable_grad():
+        v, lo, ww = (t.detach().clone().requires_grad_(True) for t in (value, loc, w))
+        out = msda_core(v, shapes, level_start, lo, ww)
+        return torch.autograd.grad(out, (v, lo, ww), grad_out.reshape(out.shape))
+
+
 def linear_core(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, add: Optional[Tensor] = None,
                 relu: bool = False) -> Tensor:
     """Kernel-boundary form of K7: act((x + add) W^T + b), i.e. with_pos_embed + nn.Linear (+ ReLU) as

@@ -1,5 +1,5 @@
 """Generate the committed golden vectors by running the REFERENCE itself (CPU) in the build
-container.  Usage:  python tests/golden/make_goldens.py [--only tiny|kernels|msda|full|t10]
+container.  Usage:  python tests/golden/make_goldens.py [--only tiny|kernels|msda|msda_grad|full|t10]
 
 Inputs are regenerated from seeds (neurips2023_soc_amd.weights); only outputs / captured
 kernel I/O are stored.  The .npz files are data; no reference source is stored.
@@ -184,6 +184,40 @@ def gen_kernels(ref, model):
     print("kernel goldens:", {k: v.shape for k, v in d.items()})
 
 
+def gen_msda_grad(ref):
+    """Gradients of the reference's own ms_deform_attn_core_pytorch (autograd through grid_sample) -- what
+    its gradcheck (models/ops/test.py:62-80) compares the native backward against."""
+    core = ref._msda_core
+    d = {}
+    cases = {
+        # test.py recipe (value ~ 0.01, weights normalised), f64
+        "g4": (1, 2, 4, 2, [(6, 4), (3, 2)], 2, torch.float64, False),
+        "g30": (1, 2, 30, 2, [(6, 4), (3, 2)], 2, torch.float64, False),
+        # model-like heads with out-of-range sampling locations, f32
+        "gb": (2, 8, 32, 11, [(12, 20), (6, 10), (3, 5), (2, 3)], 4, torch.float32, True),
+    }
+    for tag, (N, M, D, Lq, shp, P, dt, wide) in cases.items():
+        shapes = torch.as_tensor(shp, dtype=torch.long)
+        lsi = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+        S, L = int(shapes.prod(1).sum()), len(shp)
+        g = torch.Generator().manual_seed(100 + D)
+        value = (torch.randn(N, S, M, D, generator=g) if wide else torch.rand(N, S, M, D, generator=g) * 0.01).to(dt)
+        loc = torch.rand(N, Lq, M, L, P, 2, generator=g).to(dt)
+        if wide:
+            loc = loc * 1.5 - 0.25
+        w = torch.rand(N, Lq, M, L, P, generator=g).to(dt) + 1e-5
+        w = w / w.sum(-1, keepdim=True).sum(-2, keepdim=True)
+        go = torch.randn(N, Lq, M * D, generator=g).to(dt)
+        value.requires_grad_(True), loc.requires_grad_(True), w.requires_grad_(True)
+        out = core(value, shapes, loc, w)
+        gv, gl, gw = torch.autograd.grad(out, (value, loc, w), go)
+        for k, v in (("value", value), ("loc", loc), ("w", w), ("go", go), ("out", out), ("gvalue", gv),
+                     ("gloc", gl), ("gw", gw), ("shapes", shapes), ("lsi", lsi)):
+            d[f"{tag}_{k}"] = v.detach().numpy()
+    np.savez_compressed(os.path.join(HERE, "msda_grad_cases.npz"), **d)
+    print("msda gradient goldens written")
+
+
 def gen_msda(ref):
     """Known-answer cases built with the reference's own checker recipe (models/ops/test.py:21-60)."""
     core = ref._msda_core
@@ -272,6 +306,8 @@ def main():
     want = lambda k: a.only in ("all", k)  # noqa: E731
     if want("msda"):
         gen_msda(ref)
+    if want("msda_grad"):
+        gen_msda_grad(ref)
     model = None
     if want("tiny") or want("kernels") or want("t10") or want("full"):
         model = build(ref)

@@ -387,3 +387,54 @@ def test_box_refine_vs_oracle(ops, rd, with_vr):
         assert maxdiff(ref_in, want_in) < 1e-6
     else:
         assert ref_in is None
+
+
+# ------------------------------------------------------------------ K2 backward
+@pytest.mark.parametrize("tag,tol", [("g4", 1e-12), ("g30", 1e-12), ("gb", 3e-5)])
+def test_msda_backward_golden(ops, golden, tag, tol):
+    g = golden("msda_grad_cases.npz")
+    a = {k: t(g[f"{tag}_{k}"]) for k in ("value", "shapes", "lsi", "loc", "w", "go", "gvalue", "gloc", "gw")}
+    gv, gl, gw = ops.msda_backward(dev(a["value"]), dev(a["shapes"]), dev(a["lsi"]), dev(a["loc"]), dev(a["w"]),
+                                   dev(a["go"]))
+    for got, want in ((gv, a["gvalue"]), (gl, a["gloc"]), (gw, a["gw"])):
+        assert got.shape == want.shape
+        assert maxdiff(got, want) <= tol * max(1.0, float(want.abs().max()))
+
+
+@pytest.mark.parametrize("N,Lq,M,D,dt", [(2, 50, 8, 32, torch.float32), (1, 7, 2, 71, torch.float64),
+                                          (1, 3, 1, 1025, torch.float64), (3, 9, 4, 64, torch.float32),
+                                          (2, 0, 2, 8, torch.float32)])
+def test_msda_backward_vs_oracle_autograd(ops, N, Lq, M, D, dt):
+    g = torch.Generator().manual_seed(N + Lq + D)
+    shapes = torch.tensor([[9, 7], [5, 4], [3, 2]])
+    lsi = torch.cat((shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]))
+    S, L, P = int(shapes.prod(1).sum()), 3, 4
+    value = torch.randn(N, S, M, D, generator=g).to(dt)
+    loc = (torch.rand(N, Lq, M, L, P, 2, generator=g) * 1.4 - 0.2).to(dt)
+    w = torch.rand(N, Lq, M, L, P, generator=g).to(dt)
+    go = torch.randn(N, Lq, M * D, generator=g).to(dt)
+    got = ops.msda_backward(dev(value), dev(shapes), dev(lsi), dev(loc), dev(w), dev(go))
+    if Lq == 0:
+        assert float(got[0].abs().max()) == 0.0 and got[1].numel() == 0
+        return
+    want = O.msda_backward_core(value.double(), shapes, lsi, loc.double(), w.double(), go.double())
+    tol = 1e-11 if dt == torch.float64 else 2e-5
+    for a, b in zip(got, want):
+        assert maxdiff(a, b) <= tol * max(1.0, float(b.abs().max()))
+
+
+@pytest.mark.parametrize("D", [4, 30])
+def test_msda_function_gradcheck(ops, D):
+    """The reference's own check (models/ops/test.py:62-80): gradcheck of the autograd Function in f64."""
+    from torch.autograd import gradcheck
+    from neurips2023_soc_amd.ms_deform_attn import MSDeformAttnFunction
+    torch.manual_seed(3)
+    N, M, Lq, L, P = 1, 2, 2, 2, 2
+    shapes = torch.as_tensor([(6, 4), (3, 2)], dtype=torch.long).cuda()
+    lsi = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+    S = int(shapes.prod(1).sum())
+    value = (torch.rand(N, S, M, D).cuda() * 0.01).double().requires_grad_(True)
+    loc = torch.rand(N, Lq, M, L, P, 2).cuda().double().requires_grad_(True)
+    w = torch.rand(N, Lq, M, L, P).cuda() + 1e-5
+    w = (w / w.sum(-1, keepdim=True).sum(-2, keepdim=True)).double().requires_grad_(True)
+    assert gradcheck(MSDeformAttnFunction.apply, (value, shapes, lsi, loc, w, 2))

@@ -156,3 +156,15 @@ def test_forward_full_config_matches_reference(golden, synthetic_sd):
     assert int(np.unpackbits(bits ^ g["pred_masks_signbits"]).sum()) == 0
     assert maxdiff(out["pred_cls"], g["pred_cls"]) < 1e-4
     assert maxdiff(out["pred_boxes"], g["pred_boxes"]) < 1e-5
+
+
+@pytest.mark.parametrize("tag,tol", [("g4", 1e-12), ("g30", 1e-12), ("gb", 2e-5)])
+def test_msda_backward_oracle_matches_reference_autograd(golden, tag, tol):
+    """Gradients of the reference's ms_deform_attn_core_pytorch (tests/golden/make_goldens.py --only msda_grad)."""
+    g = golden("msda_grad_cases.npz")
+    a = {k: t(g[f"{tag}_{k}"]) for k in ("value", "shapes", "lsi", "loc", "w", "go", "out", "gvalue", "gloc", "gw")}
+    assert float((O.msda_core(a["value"], a["shapes"], a["lsi"], a["loc"], a["w"]) - a["out"]).abs().max()) < tol
+    gv, gl, gw = O.msda_backward_core(a["value"], a["shapes"], a["lsi"], a["loc"], a["w"], a["go"])
+    for got, want in ((gv, a["gvalue"]), (gl, a["gloc"]), (gw, a["gw"])):
+        assert got.shape == want.shape
+        assert float((got - want).abs().max()) <= tol * max(1.0, float(want.abs().max()))
