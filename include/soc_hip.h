@@ -120,6 +120,9 @@ int soc_win_attn3d_f32(const float* qkv, const float* qkv_bias, const float* bia
  * 146-149) and the decoder self-attention (models/deformable_transformer.py:333).
  *   q [Lq, B, n_heads*head_dim], k / v [Lk, B, n_heads*head_dim]
  *   key_pad_mask [B, Lk] uint8, non-zero = ignore key (may be NULL)
+ *   attn_mask    [B * attn_mask_heads, Lq, Lk] float, ADDED to the scaled logits (torch's float attn_mask;
+ *                may be NULL); attn_mask_heads = 1 (one mask for all heads) or n_heads -- used by VOC's
+ *                shifted temporal windows (models/voc.py:367-377,401-414)
  *   out [Lq, B, n_heads*head_dim]
  * batch_first != 0: q / out are [B, Lq, E] and k / v [B, Lk, E] instead (the decoder's native layout,
  * which the reference transposes around nn.MultiheadAttention, deformable_transformer.py:333).
@@ -128,8 +131,9 @@ int soc_win_attn3d_f32(const float* qkv, const float* qkv_bias, const float* bia
  */
 size_t soc_xattn_workspace_bytes(int Lq, int Lk, int B, int n_heads, int head_dim);
 int soc_xattn_f32(const float* q, const float* k, const float* v, const uint8_t* key_pad_mask,
-                  float* out, int Lq, int Lk, int B, int n_heads, int head_dim, int batch_first,
-                  void* workspace, size_t workspace_bytes, void* stream);
+                  const float* attn_mask, int attn_mask_heads, float* out, int Lq, int Lk, int B,
+                  int n_heads, int head_dim, int batch_first, void* workspace, size_t workspace_bytes,
+                  void* stream);
 
 /*
  * K4 -- per-instance dynamic mask head (3 dynamic 1x1 conv layers over

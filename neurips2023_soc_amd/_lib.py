@@ -52,7 +52,7 @@ def load() -> C.CDLL:
     lib.soc_xattn_workspace_bytes.restype = C.c_size_t
     lib.soc_xattn_workspace_bytes.argtypes = [i] * 5
     lib.soc_xattn_f32.restype = i
-    lib.soc_xattn_f32.argtypes = [p, p, p, p, p, i, i, i, i, i, i, p, C.c_size_t, p]
+    lib.soc_xattn_f32.argtypes = [p, p, p, p, p, i, p, i, i, i, i, i, i, p, C.c_size_t, p]
     lib.soc_dyn_mask_f32.restype = i
     lib.soc_dyn_mask_f32.argtypes = [p, p, p, p, i, i, i, i, i, f, f, i, p]
     lib.soc_msda_fused_fwd_f32.restype = i

@@ -30,10 +30,12 @@ class HipMultiheadAttention(nn.Module):
 
     def forward(self, query: torch.Tensor, key: torch.Tensor, value: torch.Tensor,
                 key_padding_mask: Optional[torch.Tensor] = None, query_add: Optional[torch.Tensor] = None,
-                key_add: Optional[torch.Tensor] = None, batch_first: bool = False) -> torch.Tensor:
+                key_add: Optional[torch.Tensor] = None, batch_first: bool = False,
+                attn_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
         """attention(query + query_add, key + key_add, value): the *_add terms are the positional
         embeddings the reference adds before calling nn.MultiheadAttention (with_pos_embed).
-        batch_first: tensors are [B,L,E] instead of nn.MultiheadAttention's [L,B,E]."""
+        batch_first: tensors are [B,L,E] instead of nn.MultiheadAttention's [L,B,E].
+        attn_mask: additive float mask as in nn.MultiheadAttention ([Lq,Lk], [B,Lq,Lk] or [B*heads,Lq,Lk])."""
         if self.training:
             raise RuntimeError("HipMultiheadAttention is inference-only (no backward kernel)")
         E = self.embed_dim
@@ -58,5 +60,9 @@ class HipMultiheadAttention(nn.Module):
             else:
                 k = fused.linear(key, *wk, add=key_add)
                 v = fused.linear(value, *wv)
-        o = hot_ops.mha_core(q, k, v, self.num_heads, key_padding_mask, batch_first=batch_first)
+        if attn_mask is None:    # (keeps the call shape the CPU plumbing tests patch in)
+            o = hot_ops.mha_core(q, k, v, self.num_heads, key_padding_mask, batch_first=batch_first)
+        else:
+            o = hot_ops.mha_core(q, k, v, self.num_heads, key_padding_mask, batch_first=batch_first,
+                                 attn_mask=attn_mask)
         return fused.apply(self.out_proj, o)

@@ -25,8 +25,8 @@ constexpr long ROWS_BLOCK_PATH = 8192;
 // many queries: lane = query row, wave = 64 queries x one head, K/V wave-uniform (scalar cache)
 __global__ __launch_bounds__(256) void xattn_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
-    const uint8_t* __restrict__ kpm, float* __restrict__ out, int Lq, int Lk, int B, int H,
-    float scale, int batch_first) {
+    const uint8_t* __restrict__ kpm, const float* __restrict__ amask, int mask_heads,
+    float* __restrict__ out, int Lq, int Lk, int B, int H, float scale, int batch_first) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int h = blockIdx.y % H;
@@ -53,13 +53,15 @@ __global__ __launch_bounds__(256) void xattn_kernel(
     const float* kb = k + b * k_bs + h * HD;  // + j*kstride, wave-uniform
     const float* vb = v + b * k_bs + h * HD;
     const uint8_t* mp = kpm ? kpm + (long)b * Lk : nullptr;
+    // additive float mask row of this query: [B or B*H, Lq, Lk] (torch attn_mask semantics)
+    const float* am = amask ? amask + (((long)b * mask_heads + (mask_heads > 1 ? h : 0)) * Lq + qc) * Lk : nullptr;
 
     // pass 1: row maximum over this block's keys
     float mx = -INFINITY;
     for (int j = k0; j < k1; ++j) {
         if (mp && mp[j]) continue;  // wave-uniform
         const float* kr = kb + j * kstride;
-        float s = 0.f;
+        float s = am ? am[j] : 0.f;
 #pragma unroll
         for (int d = 0; d < HD; ++d) s += qr[d] * kr[d];
         mx = fmaxf(mx, s);
@@ -73,7 +75,7 @@ __global__ __launch_bounds__(256) void xattn_kernel(
         if (mp && mp[j]) continue;
         const float* kr = kb + j * kstride;
         const float* vr = vb + j * kstride;
-        float s = 0.f;
+        float s = am ? am[j] : 0.f;
 #pragma unroll
         for (int d = 0; d < HD; ++d) s += qr[d] * kr[d];
         const float p = __expf(s - mx);
@@ -96,8 +98,8 @@ __global__ __launch_bounds__(256) void xattn_kernel(
 //   phase C  32 key slots x 8 lanes(float4 of V): acc4 += p[j] * V[j]; slots reduced through LDS
 __global__ __launch_bounds__(256) void xattn_row_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
-    const uint8_t* __restrict__ kpm, float* __restrict__ out, int Lq, int Lk, int B, int H,
-    float scale, int batch_first) {
+    const uint8_t* __restrict__ kpm, const float* __restrict__ amask, int mask_heads,
+    float* __restrict__ out, int Lq, int Lk, int B, int H, float scale, int batch_first) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* sc = lds;                       // [Lk] scores -> probabilities
     float* red = lds + ((Lk + 3) & ~3);    // [32 slots][32 dims] partial outputs / 8 reduce words
@@ -112,6 +114,7 @@ __global__ __launch_bounds__(256) void xattn_row_kernel(
     const float* kb = k + b * k_bs + h * HD;
     const float* vb = v + b * k_bs + h * HD;
     const uint8_t* mp = kpm ? kpm + (long)b * Lk : nullptr;
+    const float* am = amask ? amask + (((long)b * mask_heads + (mask_heads > 1 ? h : 0)) * Lq + qi) * Lk : nullptr;
 
     float qr[HD];
     {
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(256) void xattn_row_kernel(
         float s = -INFINITY;
         if (!(mp && mp[j])) {
             const float4* kr = reinterpret_cast<const float4*>(kb + j * kstride);
-            s = 0.f;
+            s = am ? am[j] : 0.f;
 #pragma unroll
             for (int i = 0; i < HD / 4; ++i) {
                 const float4 t = kr[i];
@@ -182,12 +185,13 @@ extern "C" size_t soc_xattn_workspace_bytes(int Lq, int Lk, int B, int n_heads, 
 }
 
 extern "C" int soc_xattn_f32(const float* q, const float* k, const float* v,
-                             const uint8_t* key_pad_mask, float* out, int Lq, int Lk, int B,
-                             int n_heads, int head_dim, int batch_first, void* workspace,
-                             size_t workspace_bytes, void* stream) {
+                             const uint8_t* key_pad_mask, const float* attn_mask, int attn_mask_heads,
+                             float* out, int Lq, int Lk, int B, int n_heads, int head_dim,
+                             int batch_first, void* workspace, size_t workspace_bytes, void* stream) {
     (void)workspace; (void)workspace_bytes;
     if (!q || !k || !v || !out || Lq < 0 || Lk <= 0 || B <= 0 || n_heads <= 0) return SOC_EINVAL;
     if (head_dim != HD) return SOC_EUNSUPPORTED;
+    if (attn_mask && attn_mask_heads != 1 && attn_mask_heads != n_heads) return SOC_EINVAL;
     if (Lq == 0) return SOC_OK;
     hipStream_t st = (hipStream_t)stream;
     const float scale = (float)sqrt(1.0 / (double)head_dim);
@@ -195,11 +199,11 @@ extern "C" int soc_xattn_f32(const float* q, const float* k, const float* v,
     const size_t row_lds = (size_t)(((Lk + 3) & ~3) + 32 * HD) * sizeof(float);
     if (rows <= ROWS_BLOCK_PATH && row_lds <= 64 * 1024) {
         hipLaunchKernelGGL(xattn_row_kernel, dim3((unsigned)rows), dim3(256), row_lds, st, q, k, v,
-                           key_pad_mask, out, Lq, Lk, B, n_heads, scale, batch_first);
+                           key_pad_mask, attn_mask, attn_mask_heads, out, Lq, Lk, B, n_heads, scale, batch_first);
         return soc_check_launch();
     }
     dim3 grid(soc_ceil_div(Lq, 256), B * n_heads);
-    hipLaunchKernelGGL(xattn_kernel, grid, dim3(256), 0, st, q, k, v, key_pad_mask, out, Lq, Lk, B,
-                       n_heads, scale, batch_first);
+    hipLaunchKernelGGL(xattn_kernel, grid, dim3(256), 0, st, q, k, v, key_pad_mask, attn_mask, attn_mask_heads,
+                       out, Lq, Lk, B, n_heads, scale, batch_first);
     return soc_check_launch();
 }

@@ -202,10 +202,12 @@ _ws_cache = {}
 
 
 def mha_core(q: Tensor, k: Tensor, v: Tensor, n_heads: int,
-             key_padding_mask: Optional[Tensor] = None, batch_first: bool = False) -> Tensor:
+             key_padding_mask: Optional[Tensor] = None, batch_first: bool = False,
+             attn_mask: Optional[Tensor] = None) -> Tensor:
     """K3.  q [Lq,B,E], k/v [Lk,B,E] projected, key_padding_mask [B,Lk] bool -> [Lq,B,E]
-    (batch_first: q [B,Lq,E], k/v [B,Lk,E] -> [B,Lq,E])."""
-    _need_gpu(q, k, v, key_padding_mask)
+    (batch_first: q [B,Lq,E], k/v [B,Lk,E] -> [B,Lq,E]).  attn_mask: float, added to the scaled logits,
+    [Lq,Lk], [B,Lq,Lk] or torch's [B*n_heads,Lq,Lk]."""
+    _need_gpu(q, k, v, key_padding_mask, attn_mask)
     lib = _lib.load()
     q, k, v = _f32c(q), _f32c(k), _f32c(v)
     if batch_first:
@@ -220,6 +222,15 @@ def mha_core(q: Tensor, k: Tensor, v: Tensor, n_heads: int,
     if key_padding_mask is not None:
         kpm = _as_u8(key_padding_mask)
         kpm_ptr = kpm.data_ptr()
+    am_ptr, am_heads = None, 1
+    if attn_mask is not None:
+        if attn_mask.dtype == torch.bool:
+            raise _lib.SocHipError("mha_core: boolean attn_mask is not supported; pass an additive float mask")
+        am = _f32c(attn_mask if attn_mask.dim() == 3 else attn_mask[None].expand(B, -1, -1))
+        if am.shape[-2:] != (Lq, Lk) or am.shape[0] not in (B, B * n_heads):
+            raise _lib.SocHipError(f"mha_core: attn_mask shape {tuple(attn_mask.shape)} does not fit "
+                                   f"[{B} or {B * n_heads}, {Lq}, {Lk}]")
+        am_ptr, am_heads = am.data_ptr(), (n_heads if am.shape[0] == B * n_heads and n_heads > 1 else 1)
     need = lib.soc_xattn_workspace_bytes(Lq, Lk, B, n_heads, hd)
     ws_ptr = None
     if need:
@@ -230,7 +241,7 @@ def mha_core(q: Tensor, k: Tensor, v: Tensor, n_heads: int,
             _ws_cache[key] = ws
         ws_ptr = ws.data_ptr()
     with _timed("xattn", (2 * q.numel() + k.numel() + v.numel()) * 4):
-        code = lib.soc_xattn_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), kpm_ptr, out.data_ptr(),
+        code = lib.soc_xattn_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), kpm_ptr, am_ptr, am_heads, out.data_ptr(),
                                  Lq, Lk, B, n_heads, hd, int(bool(batch_first)), ws_ptr, need, _stream())
     _lib.check(code, "soc_xattn_f32")
     return out

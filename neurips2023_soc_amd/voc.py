@@ -1,12 +1,17 @@
-"""Video object cluster module (reference models/voc.py:181-335), inference form.
+"""Video object cluster module (reference models/voc.py:181-414), inference form.
 
-Encoder: self-attention + FFN over all T*Q frame queries (window_size 0 = full attention);
-decoder: cross -> self -> FFN with queries initialised from the sentence feature.  Every
-attention core is the HIP kernel K3; post-norm throughout (pre_norm=False in every config).
+Encoder: self-attention + FFN over all T*Q frame queries (window_size 0 = full attention, every
+shipped config) or over temporal windows of `window_size` frames (plain windows on even layers,
+windows shifted by ceil(W/2) frames on odd ones, :336-414); decoder: cross -> self -> FFN with queries
+initialised from the sentence feature.  Every attention core is the HIP kernel K3; post-norm
+throughout (pre_norm=False in every config).
 """
 from __future__ import annotations
 
+import math
+
 import torch
+import torch.nn.functional as F
 from torch import nn
 
 from . import hot_ops
@@ -36,9 +41,9 @@ class SelfAttentionLayer(nn.Module):
         self.self_attn = HipMultiheadAttention(d_model, nhead)
         self.norm = nn.LayerNorm(d_model)
 
-    def forward(self, tgt, tgt_key_padding_mask=None, query_pos=None):
+    def forward(self, tgt, tgt_key_padding_mask=None, query_pos=None, tgt_mask=None):
         return _add_norm(tgt, self.self_attn(tgt, tgt, tgt, tgt_key_padding_mask, query_add=query_pos,
-                                             key_add=query_pos), self.norm)
+                                             key_add=query_pos, attn_mask=tgt_mask), self.norm)
 
 
 class CrossAttentionLayer(nn.Module):
@@ -57,9 +62,8 @@ class VOC(nn.Module):
         super().__init__()
         if pre_norm:
             raise NotImplementedError("SOC always builds VOC with post-norm")
-        if config["window_size"] != 0:
-            raise NotImplementedError("temporal-window VOC (reference voc.py:356-414) is unused by every "
-                                      "shipped config; SURVEY.md 8f rank 4")
+        if config["window_size"] < 0:
+            raise ValueError("window_size must be >= 0")
         d = config["input_dim"]
         self.window_size = config["window_size"]
         self.num_frame_queries, self.num_queries = config["num_frame_queries"], config["num_queries"]
@@ -88,9 +92,14 @@ class VOC(nn.Module):
             raise RuntimeError("inference-only module")
         fq = frame_query[-1]                      # [T,B,Q,C]
         T, B, Q, C = fq.shape
-        x = fq.permute(0, 2, 1, 3).reshape(T * Q, B, C)  # (t q) b c
-        for attn, ffn in zip(self.enc_self_attn, self.enc_ffn):
-            x = ffn(attn(x))
+        if self.enc_layers == 0:
+            x = fq.permute(0, 2, 1, 3).reshape(T * Q, B, C)
+        elif self.window_size == 0:
+            x = fq.permute(0, 2, 1, 3).reshape(T * Q, B, C)  # (t q) b c
+            for attn, ffn in zip(self.enc_self_attn, self.enc_ffn):
+                x = ffn(attn(x))
+        else:
+            x = self._encode_windows(fq.permute(0, 2, 1, 3))
         dec_pos = self.fq_pos.weight[None, :, None, :].expand(T, -1, B, -1).reshape(T * Q, B, C)
         qe = self.query_embed.weight[:, None, :].expand(-1, B, -1)
         out = language_query[None].expand(self.num_queries, -1, -1)
@@ -100,3 +109,45 @@ class VOC(nn.Module):
             out = self_attn(out, query_pos=qe)
             out = ffn(out)
         return self.decoder_norm(out).transpose(0, 1)[None]
+
+    # ------------------------------------------------------------------ temporal windows (:336-414)
+    @staticmethod
+    def window_masks(pad: torch.Tensor, W: int, Q: int):
+        """pad [B,T_] bool (True = frame added to fill the last window) -> (key padding mask of the plain
+        windows [B*Nw, W*Q], additive mask of the shifted windows [B*Nw, W*Q, W*Q]: -1000 between frames that
+        only became neighbours through the cyclic shift, or that are padding)."""
+        B, T_ = pad.shape
+        Nw, half = T_ // W, math.ceil(W / 2)
+        plain = pad.view(B * Nw, W, 1).expand(-1, -1, Q).reshape(B * Nw, W * Q)
+        by_query = torch.roll(pad, half, 1).view(B, Nw, W, 1).expand(-1, -1, -1, W)      # blocked rows
+        blocked = by_query.clone()
+        for n in (0, Nw - 1):                                   # first / last window: rows and columns
+            blocked[:, n] = blocked[:, n] | blocked[:, n].transpose(-2, -1)
+        blocked[:, 0, :half, half:] = True                       # window 0 mixes the clip's end with its start
+        blocked[:, 0, half:, :half] = True
+        frames = blocked.view(B * Nw, W, 1, W, 1).expand(-1, -1, Q, -1, Q).reshape(B * Nw, W * Q, W * Q)
+        return plain, frames.to(torch.float32) * -1000.0
+
+    def _encode_windows(self, x: torch.Tensor) -> torch.Tensor:
+        """x [T,Q,B,C] -> (t q) b c after the windowed encoder (eval: even layers plain, odd layers shifted)."""
+        T, Q, B, C = x.shape
+        W = self.window_size
+        T_ = math.ceil(T / W) * W
+        Nw, half = T_ // W, math.ceil(W / 2)
+        x = F.pad(x, (0, 0, 0, 0, 0, 0, 0, T_ - T))
+        pad = torch.ones(B, T_, dtype=torch.bool, device=x.device)
+        pad[:, :T] = False
+        plain, shifted = self.window_masks(pad, W, Q)
+
+        def split(t):     # [T_,Q,B,C] -> [(W Q), (B Nw), C]: every window is a batch element
+            return t.view(Nw, W, Q, B, C).permute(1, 2, 3, 0, 4).reshape(W * Q, B * Nw, C)
+
+        def merge(t):
+            return t.reshape(W, Q, B, Nw, C).permute(3, 0, 1, 2, 4).reshape(T_, Q, B, C)
+
+        for i, (attn, ffn) in enumerate(zip(self.enc_self_attn, self.enc_ffn)):
+            if i % 2 == 0:
+                x = merge(ffn(attn(split(x), tgt_key_padding_mask=plain)))
+            else:
+                x = torch.roll(merge(ffn(attn(split(torch.roll(x, half, 0)), tgt_mask=shifted))), -half, 0)
+        return x[:T].reshape(T * Q, B, C)

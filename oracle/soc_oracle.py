@@ -99,7 +99,8 @@ def sine_pos_1d(mask: Tensor, num_pos_feats: int = 256, temperature: float = 100
 
 # ----------------------------------------------------------------------------- hot op 3: MHA core
 def mha_core(q: Tensor, k: Tensor, v: Tensor, n_heads: int,
-             key_padding_mask: Optional[Tensor] = None, batch_first: bool = False) -> Tensor:
+             key_padding_mask: Optional[Tensor] = None, batch_first: bool = False,
+             attn_mask: Optional[Tensor] = None) -> Tensor:
     """softmax(q k^T / sqrt(d)) v per head, seq-first layout ([B,L,E] tensors when batch_first).
 
     q [Lq,B,E], k/v [Lk,B,E] are the *projected* tensors; key_padding_mask [B,Lk] bool, True =
@@ -109,7 +110,7 @@ def mha_core(q: Tensor, k: Tensor, v: Tensor, n_heads: int,
     """
     if batch_first:
         return mha_core(q.transpose(0, 1), k.transpose(0, 1), v.transpose(0, 1), n_heads,
-                        key_padding_mask).transpose(0, 1)
+                        key_padding_mask, attn_mask=attn_mask).transpose(0, 1)
     Lq, B, E = q.shape
     Lk = k.shape[0]
     hd = E // n_heads
@@ -117,6 +118,11 @@ def mha_core(q: Tensor, k: Tensor, v: Tensor, n_heads: int,
     kh = k.reshape(Lk, B * n_heads, hd).transpose(0, 1)
     vh = v.reshape(Lk, B * n_heads, hd).transpose(0, 1)
     s = torch.bmm(qh, kh.transpose(1, 2))
+    if attn_mask is not None:  # additive float mask [Lq,Lk] / [B,Lq,Lk] / [B*nH,Lq,Lk] (F.multi_head_attention_forward)
+        am = attn_mask if attn_mask.dim() == 3 else attn_mask[None].expand(B, -1, -1)
+        if am.shape[0] == B and n_heads > 1:
+            am = am[:, None].expand(B, n_heads, Lq, Lk).reshape(B * n_heads, Lq, Lk)
+        s = s + am
     if key_padding_mask is not None:
         m = key_padding_mask.view(B, 1, 1, Lk).expand(B, n_heads, 1, Lk).reshape(B * n_heads, 1, Lk)
         s = s.masked_fill(m, float("-inf"))
@@ -126,14 +132,14 @@ def mha_core(q: Tensor, k: Tensor, v: Tensor, n_heads: int,
 
 
 def mha(sd: SD, p: str, query: Tensor, key: Tensor, value: Tensor, n_heads: int = 8,
-        key_padding_mask: Optional[Tensor] = None) -> Tensor:
+        key_padding_mask: Optional[Tensor] = None, attn_mask: Optional[Tensor] = None) -> Tensor:
     """nn.MultiheadAttention (in_proj -> core -> out_proj), parameters under prefix ``p``."""
     E = query.shape[-1]
     w, b = sd[p + ".in_proj_weight"], sd[p + ".in_proj_bias"]
     q = F.linear(query, w[:E], b[:E])
     k = F.linear(key, w[E:2 * E], b[E:2 * E])
     v = F.linear(value, w[2 * E:], b[2 * E:])
-    o = mha_core(q, k, v, n_heads, key_padding_mask)
+    o = mha_core(q, k, v, n_heads, key_padding_mask, attn_mask=attn_mask)
     return F.linear(o, sd[p + ".out_proj.weight"], sd[p + ".out_proj.bias"])
 
 
@@ -443,18 +449,67 @@ def deformable_transformer(sd: SD, srcs: List[Tensor], masks: List[Tensor], pose
 
 
 # ----------------------------------------------------------------------------- VOC
-def voc(sd: SD, hs_last: Tensor, sentence: Tensor, p: str = "voc", n_enc: int = 3, n_dec: int = 3) -> Tensor:
-    """reference VOC.forward models/voc.py:268-335 in eval with window_size=0.
+def _voc_enc_layer(sd: SD, p: str, i: int, x: Tensor, key_padding_mask=None, attn_mask=None) -> Tensor:
+    """SelfAttentionLayer.forward_post (:84-94) + FFNLayer.forward_post (:44-48) of encoder layer i"""
+    a = f"{p}.enc_self_attn.{i}"
+    x = layer_norm(sd, a + ".norm", x + mha(sd, a + ".self_attn", x, x, x, 8, key_padding_mask, attn_mask))
+    f = f"{p}.enc_ffn.{i}"
+    return layer_norm(sd, f + ".norm", x + linear(sd, f + ".linear2", F.relu(linear(sd, f + ".linear1", x))))
+
+
+def voc_window_masks(pad: Tensor, W: int, fQ: int) -> Tuple[Tensor, Tensor]:
+    """Masks of the temporal-window encoder (reference models/voc.py:361-377).
+
+    pad [LB, T_] bool (True = padded frame).  Returns (key padding mask of the plain windows
+    [LB*Nw, W*fQ] bool, additive mask of the shifted windows [LB*Nw, W*fQ, W*fQ] float: -1000 where a
+    query frame may not see a key frame)."""
+    LB, T_ = pad.shape
+    Nw, half = T_ // W, int(math.ceil(W / 2))
+    win = pad.view(LB * Nw, W)[..., None].repeat(1, 1, fQ).flatten(1)
+    r = torch.roll(pad, half, 1).view(LB, Nw, W)[..., None].repeat(1, 1, 1, W)      # [LB,Nw,Wq,Wk], by QUERY frame
+    r[:, 0] = r[:, 0] | r[:, 0].transpose(-2, -1)
+    r[:, -1] = r[:, -1] | r[:, -1].transpose(-2, -1)
+    r[:, 0, :half, half:] = True          # frames rolled in from the end of the clip ...
+    r[:, 0, half:, :half] = True          # ... and the first real frames do not see each other
+    tok = r.view(LB * Nw, W, 1, W, 1).repeat(1, 1, fQ, 1, fQ).view(LB * Nw, W * fQ, W * fQ)
+    return win, tok.float() * -1000
+
+
+def voc(sd: SD, hs_last: Tensor, sentence: Tensor, p: str = "voc", n_enc: int = 3, n_dec: int = 3,
+        window_size: int = 0) -> Tensor:
+    """reference VOC.forward models/voc.py:268-335 in eval (window_size = 0: full attention over all
+    T*Q frame queries; > 0: temporal windows, plain on even encoder layers, shifted by ceil(W/2) frames on
+    odd ones, :336-414).
 
     hs_last [T,B,Q,C] (= hs[-1]), sentence [B,C] -> [B,Q,C]
     """
     T, B, Q, C = hs_last.shape
-    fq = hs_last.permute(0, 2, 1, 3).reshape(T * Q, B, C)  # (t q) b c
-    for i in range(n_enc):  # :349-351, SelfAttentionLayer.forward_post :84-94, FFNLayer :44-48
-        a = f"{p}.enc_self_attn.{i}"
-        fq = layer_norm(sd, a + ".norm", fq + mha(sd, a + ".self_attn", fq, fq, fq, 8))
-        f = f"{p}.enc_ffn.{i}"
-        fq = layer_norm(sd, f + ".norm", fq + linear(sd, f + ".linear2", F.relu(linear(sd, f + ".linear1", fq))))
+    if window_size == 0:
+        fq = hs_last.permute(0, 2, 1, 3).reshape(T * Q, B, C)  # (t q) b c
+        for i in range(n_enc):  # :349-351
+            fq = _voc_enc_layer(sd, p, i, fq)
+    else:
+        W = window_size
+        T_ = int(math.ceil(T / W)) * W
+        x = F.pad(hs_last.permute(0, 2, 1, 3), (0, 0, 0, 0, 0, 0, 0, T_ - T))          # [T_,Q,B,C]
+        pad = torch.ones(B, T_, dtype=torch.bool)
+        pad[:, :T] = False
+        win_mask, shift_mask = voc_window_masks(pad, W, Q)
+        Nw, half = T_ // W, int(math.ceil(W / 2))
+
+        def to_windows(t):   # [T_,Q,B,C] -> [(W Q), (B Nw), C]
+            return t.view(Nw, W, Q, B, C).permute(1, 2, 3, 0, 4).reshape(W * Q, B * Nw, C)
+
+        def from_windows(t):
+            return t.reshape(W, Q, B, Nw, C).permute(3, 0, 1, 2, 4).reshape(T_, Q, B, C)
+
+        for i in range(n_enc):
+            if i % 2 == 0:
+                x = from_windows(_voc_enc_layer(sd, p, i, to_windows(x), key_padding_mask=win_mask))
+            else:
+                y = _voc_enc_layer(sd, p, i, to_windows(torch.roll(x, half, 0)), attn_mask=shift_mask)
+                x = torch.roll(from_windows(y), -half, 0)
+        fq = x[:T].flatten(0, 1)
     dec_pos = sd[p + ".fq_pos.weight"][None, :, None, :].repeat(T, 1, B, 1).flatten(0, 1)
     qe = sd[p + ".query_embed.weight"][:, None, :].repeat(1, B, 1)
     nq = qe.shape[0]

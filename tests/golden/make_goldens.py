@@ -1,5 +1,5 @@
 """Generate the committed golden vectors by running the REFERENCE itself (CPU) in the build
-container.  Usage:  python tests/golden/make_goldens.py [--only tiny|kernels|msda|msda_grad|full|t10]
+container.  Usage:  python tests/golden/make_goldens.py [--only tiny|kernels|msda|msda_grad|voc_window|full|t10]
 
 Inputs are regenerated from seeds (neurips2023_soc_amd.weights); only outputs / captured
 kernel I/O are stored.  The .npz files are data; no reference source is stored.
@@ -184,6 +184,30 @@ def gen_kernels(ref, model):
     print("kernel goldens:", {k: v.shape for k, v in d.items()})
 
 
+def gen_voc_window(ref):
+    """The reference VOC module with temporal windows (models/voc.py:336-414; window_size > 0 is in no
+    shipped config, so it gets its own known-answer cases): T = 6 (padded to 8) and T = 8, W = 4."""
+    import importlib
+    ref_voc = importlib.import_module("models.voc")
+    from neurips2023_soc_amd import weights as W_
+    cfg = dict(input_dim=256, window_size=4, num_frame_queries=20, num_frames=8, num_queries=20, nheads=8,
+               dim_feedforward=2048, enc_layers=3, dec_layers=3)
+    mod = ref_voc.VOC(cfg).eval()
+    shapes = {"voc." + k: tuple(v.shape) for k, v in mod.state_dict().items() if v.is_floating_point()}
+    sd = W_.synthetic_state_dict(shapes, 2023)
+    mod.load_state_dict({k[4:]: v for k, v in sd.items()})
+    d = {}
+    for tag, T in (("t6", 6), ("t8", 8)):
+        g = torch.Generator().manual_seed(40 + T)
+        fq = torch.randn(1, T, 1, 20, 256, generator=g)        # [L, T, B, Q, C]
+        lang = torch.randn(1, 256, generator=g)
+        with torch.no_grad():
+            out = mod(fq, lang)                                 # [L, B, Q, C]
+        d[f"{tag}_fq"], d[f"{tag}_lang"], d[f"{tag}_out"] = fq.numpy(), lang.numpy(), out.numpy()
+    np.savez_compressed(os.path.join(HERE, "voc_window.npz"), **d)
+    print("windowed-VOC goldens written")
+
+
 def gen_msda_grad(ref):
     """Gradients of the reference's own ms_deform_attn_core_pytorch (autograd through grid_sample) -- what
     its gradcheck (models/ops/test.py:62-80) compares the native backward against."""
@@ -308,6 +332,8 @@ def main():
         gen_msda(ref)
     if want("msda_grad"):
         gen_msda_grad(ref)
+    if want("voc_window"):
+        gen_voc_window(ref)
     model = None
     if want("tiny") or want("kernels") or want("t10") or want("full"):
         model = build(ref)

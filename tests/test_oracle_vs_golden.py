@@ -168,3 +168,14 @@ def test_msda_backward_oracle_matches_reference_autograd(golden, tag, tol):
     for got, want in ((gv, a["gvalue"]), (gl, a["gloc"]), (gw, a["gw"])):
         assert got.shape == want.shape
         assert float((got - want).abs().max()) <= tol * max(1.0, float(want.abs().max()))
+
+
+@pytest.mark.parametrize("tag", ["t6", "t8"])
+def test_windowed_voc_oracle_matches_reference(golden, ref_shapes, tag):
+    """Temporal-window VOC (reference models/voc.py:336-414), T = 6 (padded to 8) and T = 8, W = 4."""
+    from neurips2023_soc_amd import weights as W
+    g = golden("voc_window.npz")
+    shapes = {k: tuple(v[0]) for k, v in ref_shapes("t").items() if k.startswith("voc.") and v[1].startswith("float")}
+    sd = W.synthetic_state_dict(shapes, 2023)
+    out = O.voc(sd, t(g[tag + "_fq"])[-1], t(g[tag + "_lang"]), window_size=4)
+    assert float((out - t(g[tag + "_out"])[0]).abs().max()) < 2e-5
