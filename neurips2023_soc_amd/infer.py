@@ -38,6 +38,7 @@ class ClipInferencer:
         key = (T, H, W, L)
         if key not in self._graphs:
             while len(self._graphs) >= self.max_graphs:      # a graph pins its activation pool: keep few
+                torch.cuda.synchronize(self.device)          # never drop a graph that may still be replaying
                 self._graphs.pop(next(iter(self._graphs)))
             self._graphs[key] = ClipGraph(self.model, T, H, W, L, self.device)
         return self._graphs[key]
