@@ -206,6 +206,20 @@ int soc_resize_normalize_u8_f32(const uint8_t* frames, float* out, uint8_t* out_
                                 const float* std, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * K10 -- GroupNorm over token-major activations (the layout copies around the
+ * library GEMMs).  Replaces nn.GroupNorm(32, d_model) of input_proj (models/soc.py:107-125, applied at
+ * :226-230) together with the NCHW <-> token-major copies on either side of it; the 1x1 Conv2d in
+ * front becomes a GEMM over tokens.
+ *   x, out [N, S, C]  (N = frames, S = h*w);  gamma, beta [C];  G groups of C/G consecutive channels;
+ *   statistics per (frame, group) over S * C/G elements, biased variance, as torch.nn.GroupNorm.
+ * C <= 256, C % 4 == 0, (C/G) a multiple of 4 with (C/G)/4 a power of two, G <= 64.
+ * workspace: soc_groupnorm_tokens_workspace_bytes() bytes of device memory (per-chunk partial sums).
+ */
+size_t soc_groupnorm_tokens_workspace_bytes(int N, int S, int C, int G);
+int soc_groupnorm_tokens_f32(const float* x, const float* gamma, const float* beta, float* out, int N, int S,
+                             int C, int G, float eps, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
  * K7 -- small-M linear layer out = act((x [+ x_add]) W^T + bias)  ("next": the
  * library-GEMM share; here the latency-bound query-side layers).  Replaces nn.Linear / F.linear on
  * the frame-query / video-query / word tensors: DeformableTransformerDecoderLayer

@@ -15,7 +15,8 @@ EXPORTS = ("soc_hip_abi_version", "soc_hip_error_string", "soc_msda_fwd_f32", "s
            "soc_add_layernorm_f32", "soc_msda_fused_fwd_f32", "soc_upsample_threshold_u8",
            "soc_linear_small_f32", "soc_linear_small_multi_f32", "soc_box_refine_f32",
            "soc_upsample_merge_labels_u8", "soc_resize_workspace_bytes", "soc_resize_normalize_u8_f32",
-           "soc_msda_bwd_f32", "soc_msda_bwd_f64")
+           "soc_msda_bwd_f32", "soc_msda_bwd_f64", "soc_groupnorm_tokens_workspace_bytes",
+           "soc_groupnorm_tokens_f32")
 ABI_VERSION = 2
 
 _lib = None
@@ -73,6 +74,10 @@ def load() -> C.CDLL:
     lib.soc_resize_workspace_bytes.argtypes = [i] * 5
     lib.soc_resize_normalize_u8_f32.restype = i
     lib.soc_resize_normalize_u8_f32.argtypes = [p, p, p, i, i, i, i, i, p, p, i, p, p, i, p, p, p, C.c_size_t, p]
+    lib.soc_groupnorm_tokens_workspace_bytes.restype = C.c_size_t
+    lib.soc_groupnorm_tokens_workspace_bytes.argtypes = [i] * 4
+    lib.soc_groupnorm_tokens_f32.restype = i
+    lib.soc_groupnorm_tokens_f32.argtypes = [p, p, p, p, i, i, i, i, f, p, C.c_size_t, p]
     if lib.soc_hip_abi_version() != ABI_VERSION:
         raise SocHipError("libsoc_hip.so ABI version mismatch; rebuild it")
     _lib = lib

@@ -451,3 +451,21 @@ def resize_normalize(frames: Tensor, size: Sequence[int], tables_x, tables_y, me
                                                ky.data_ptr(), ky.shape[1], m, s, ws.data_ptr(), need, _stream())
     _lib.check(code, "soc_resize_normalize_u8_f32")
     return (out, out_u8) if return_u8 else out
+
+
+def groupnorm_tokens(x: Tensor, weight: Tensor, bias: Tensor, groups: int, eps: float = 1e-5) -> Tensor:
+    """K10.  GroupNorm of token-major activations: x [N,S,C] -> [N,S,C], statistics per (n, group) over
+    S * C/groups elements (what nn.GroupNorm computes on the '(n) c h w' view of the same data)."""
+    _need_gpu(x, weight, bias)
+    lib = _lib.load()
+    x = _f32c(x)
+    N, S, C_ = x.shape
+    out = torch.empty_like(x)
+    need = lib.soc_groupnorm_tokens_workspace_bytes(N, S, C_, groups)
+    ws = torch.empty(max(need, 1), dtype=torch.uint8, device=x.device)
+    with _timed("groupnorm_tokens", 3 * x.numel() * 4):
+        code = lib.soc_groupnorm_tokens_f32(x.data_ptr(), _f32c(weight).data_ptr(), _f32c(bias).data_ptr(),
+                                            out.data_ptr(), N, S, C_, int(groups), float(eps), ws.data_ptr(), need,
+                                            _stream())
+    _lib.check(code, "soc_groupnorm_tokens_f32")
+    return out

@@ -175,6 +175,21 @@ class SOC(nn.Module):
         return NestedTensor(words, attn.ne(1)), sentence
 
     # ------------------------------------------------------------------ forward
+    def _project_level(self, l: int, src, B: int, T: int):
+        """input_proj[l] = Conv2d(1x1) + GroupNorm(32) of a backbone level, returned as the '(t h w) b c'
+        sequence the fusion consumes (reference models/soc.py:226-230).  The backbone's maps are
+        channels-last in memory, so on the GPU the 1x1 convolution is a GEMM over tokens and the
+        GroupNorm runs on the token-major result (K10): no layout copy before or after."""
+        conv, gn = self.input_proj[l][0], self.input_proj[l][1]
+        n, cin, h, w = src.shape
+        tok = src.permute(0, 2, 3, 1)                              # a view of the backbone's native layout
+        if not (src.is_cuda and tok.is_contiguous() and conv.kernel_size == (1, 1)):
+            return self._seq(self.input_proj[l](src), B, T)
+        y = F.linear(tok.reshape(n, h * w, cin), conv.weight.view(conv.out_channels, cin), conv.bias)
+        y = hot_ops.groupnorm_tokens(y, gn.weight, gn.bias, gn.num_groups, gn.eps)    # '(b t) (h w) c'
+        c = y.shape[-1]
+        return y.view(B, T, h * w, c).permute(1, 2, 0, 3).reshape(T * h * w, B, c)  # a view for B = 1
+
     @staticmethod
     def _seq(x, B, T):
         """'(b t) c h w -> (t h w) b c'"""
@@ -222,9 +237,8 @@ class SOC(nn.Module):
         levels = list(zip(backbone_out[-3:], pos[-3:]))
         for l, (feat, pos_l) in enumerate(levels):
             src, mask = feat.decompose()
-            proj = self.input_proj[l](src)
-            h, w = proj.shape[-2:]
-            seq = self._seq(proj, B, T)
+            h, w = src.shape[-2:]
+            seq = self._project_level(l, src, B, T)
             fused = self.vlf(tgt=seq, memory=words, memory_key_padding_mask=word_pad, pos=text_pos)
             if l == len(levels) - 1:  # only langs[-1] is read downstream
                 lang_last = self.lvf(tgt=words, memory=seq,

@@ -590,6 +590,12 @@ def msda_backward_core(value: Tensor, shapes: Tensor, level_start: Tensor, loc: 
         return torch.autograd.grad(out, (v, lo, ww), grad_out.reshape(out.shape))
 
 
+def groupnorm_tokens_core(x: Tensor, weight: Tensor, bias: Tensor, groups: int, eps: float = 1e-5) -> Tensor:
+    """Kernel-boundary form of K10: nn.GroupNorm (reference models/soc.py:107-125) applied to token-major
+    x [N,S,C], i.e. to its '(n) c s' view."""
+    return F.group_norm(x.transpose(1, 2), groups, weight, bias, eps).transpose(1, 2).contiguous()
+
+
 def linear_core(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, add: Optional[Tensor] = None,
                 relu: bool = False) -> Tensor:
     """Kernel-boundary form of K7: act((x + add) W^T + b), i.e. with_pos_embed + nn.Linear (+ ReLU) as

@@ -469,3 +469,23 @@ def test_windowed_voc_module_matches_reference(ops, golden, ref_shapes, tag):
     out = mod.cuda()(dev(t(g[tag + "_fq"])), dev(t(g[tag + "_lang"])))
     assert out.shape == g[tag + "_out"].shape
     assert maxdiff(out, g[tag + "_out"]) < 5e-5
+
+
+# ------------------------------------------------------------------ K10 GroupNorm over tokens
+@pytest.mark.parametrize("N,S,C,G,shift", [(8, 3600, 256, 32, 0.0), (8, 920, 256, 32, 50.0), (3, 77, 256, 32, 0.0),
+                                           (1, 1, 256, 32, 0.0), (2, 130, 128, 8, -7.0), (0, 5, 256, 32, 0.0)])
+def test_groupnorm_tokens_vs_torch(ops, N, S, C, G, shift):
+    g = torch.Generator().manual_seed(S + C)
+    x = torch.randn(N, S, C, generator=g) * 2 + shift          # shift: |mean| >> std must not lose the variance
+    w, b = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    got = ops.groupnorm_tokens(dev(x), dev(w), dev(b), G, 1e-5)
+    assert got.shape == x.shape
+    if N:
+        want = O.groupnorm_tokens_core(x.double(), w.double(), b.double(), G, 1e-5).float()
+        assert maxdiff(got, want) < 3e-5 * max(1.0, float(want.abs().max()))
+        assert torch.equal(got, ops.groupnorm_tokens(dev(x), dev(w), dev(b), G, 1e-5))   # no atomics: repeatable
+
+
+def test_groupnorm_tokens_rejects_unsupported(ops):
+    with pytest.raises(RuntimeError):       # 6 channels per group: a lane's float4 would straddle groups
+        ops.groupnorm_tokens(torch.zeros(1, 4, 96).cuda(), torch.ones(96).cuda(), torch.zeros(96).cuda(), 16)
