@@ -143,9 +143,17 @@ class PatchEmbed3D(nn.Module):
             x = F.pad(x, (0, 4 - W % 4))
         if H % 4:
             x = F.pad(x, (0, 0, 0, 4 - H % 4))
-        f = x.transpose(1, 2).reshape(B * T, 3, x.shape[-2], x.shape[-1])
-        f = F.conv2d(f, self.proj.weight[:, :, 0], self.proj.bias, stride=4)
-        f = f.permute(0, 2, 3, 1).reshape(B, T, f.shape[-2], f.shape[-1], -1)
+        Hp, Wp = x.shape[-2] // 4, x.shape[-1] // 4
+        if x.is_cuda:
+            # non-overlapping 4x4 patches: the convolution is a GEMM over (c, kh, kw) = 48 inputs per token,
+            # whose output is already token-major (no NCHW -> NHWC copy of the 44 MB map)
+            cols = x.transpose(1, 2).reshape(B * T, 3, Hp, 4, Wp, 4).permute(0, 2, 4, 1, 3, 5)
+            f = F.linear(cols.reshape(B * T * Hp * Wp, 48), self.proj.weight.view(-1, 48), self.proj.bias)
+            f = f.view(B, T, Hp, Wp, -1)
+        else:
+            f = x.transpose(1, 2).reshape(B * T, 3, x.shape[-2], x.shape[-1])
+            f = F.conv2d(f, self.proj.weight[:, :, 0], self.proj.bias, stride=4)
+            f = f.permute(0, 2, 3, 1).reshape(B, T, Hp, Wp, -1)
         return hot_ops.add_layernorm(f, None, self.norm.weight, self.norm.bias, self.norm.eps)[1]
 
 
