@@ -220,6 +220,17 @@ int soc_groupnorm_tokens_f32(const float* x, const float* gamma, const float* be
                              int C, int G, float eps, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * K11 -- Video-Swin patch merging: 2x2 spatial gather + LayerNorm(4C) in one pass.  Replaces
+ * PatchMerging.forward up to its `reduction` Linear (models/video_swin_transformer.py:279-313: F.pad for odd
+ * sizes, the four strided slices x0..x3, torch.cat, self.norm).
+ *   x [BD, H, W, C] token-major (BD = batch * frames)  ->  out [BD, ceil(H/2), ceil(W/2), 4C];
+ *   channel order of the reference: (h even, w even), (h odd, w even), (h even, w odd), (h odd, w odd).
+ * C % 4 == 0, C <= 512.
+ */
+int soc_patch_merge_layernorm_f32(const float* x, const float* gamma, const float* beta, float* out, int BD,
+                                  int H, int W, int C, float eps, void* stream);
+
+/*
  * K7 -- small-M linear layer out = act((x [+ x_add]) W^T + bias)  ("next": the
  * library-GEMM share; here the latency-bound query-side layers).  Replaces nn.Linear / F.linear on
  * the frame-query / video-query / word tensors: DeformableTransformerDecoderLayer

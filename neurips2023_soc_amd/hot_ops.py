@@ -469,3 +469,17 @@ def groupnorm_tokens(x: Tensor, weight: Tensor, bias: Tensor, groups: int, eps: 
                                             _stream())
     _lib.check(code, "soc_groupnorm_tokens_f32")
     return out
+
+
+def patch_merge_layernorm(x: Tensor, weight: Tensor, bias: Tensor, eps: float = 1e-5) -> Tensor:
+    """K11.  x [B,D,H,W,C] -> LayerNorm(concat of the 2x2 spatial neighbours) [B,D,ceil(H/2),ceil(W/2),4C]."""
+    _need_gpu(x, weight, bias)
+    lib = _lib.load()
+    x = _f32c(x)
+    B, D, H, W, C_ = x.shape
+    out = torch.empty((B, D, (H + 1) // 2, (W + 1) // 2, 4 * C_), dtype=torch.float32, device=x.device)
+    with _timed("patch_merge_layernorm", x.numel() * 4 + out.numel() * 4):
+        code = lib.soc_patch_merge_layernorm_f32(x.data_ptr(), _f32c(weight).data_ptr(), _f32c(bias).data_ptr(),
+                                                 out.data_ptr(), B * D, H, W, C_, float(eps), _stream())
+    _lib.check(code, "soc_patch_merge_layernorm_f32")
+    return out

@@ -122,6 +122,10 @@ class PatchMerging(nn.Module):
         self.norm = nn.LayerNorm(4 * dim)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self.reduction(hot_ops.patch_merge_layernorm(x, self.norm.weight, self.norm.bias, self.norm.eps))
+
+    def forward_unfused(self, x: torch.Tensor) -> torch.Tensor:
+        """The reference's sequence of ops (pad, four strided slices, cat, norm, reduction)."""
         H, W = x.shape[2], x.shape[3]
         if H % 2 or W % 2:
             x = F.pad(x, (0, 0, 0, W % 2, 0, H % 2))

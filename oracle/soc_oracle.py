@@ -596,6 +596,16 @@ def groupnorm_tokens_core(x: Tensor, weight: Tensor, bias: Tensor, groups: int, 
     return F.group_norm(x.transpose(1, 2), groups, weight, bias, eps).transpose(1, 2).contiguous()
 
 
+def patch_merge_layernorm_core(x: Tensor, weight: Tensor, bias: Tensor, eps: float = 1e-5) -> Tensor:
+    """Kernel-boundary form of K11: PatchMerging.forward without the reduction Linear
+    (reference models/video_swin_transformer.py:296-311)."""
+    H, W = x.shape[2], x.shape[3]
+    if H % 2 or W % 2:
+        x = F.pad(x, (0, 0, 0, W % 2, 0, H % 2))
+    x = torch.cat([x[:, :, 0::2, 0::2], x[:, :, 1::2, 0::2], x[:, :, 0::2, 1::2], x[:, :, 1::2, 1::2]], -1)
+    return F.layer_norm(x, (x.shape[-1],), weight, bias, eps)
+
+
 def linear_core(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, add: Optional[Tensor] = None,
                 relu: bool = False) -> Tensor:
     """Kernel-boundary form of K7: act((x + add) W^T + b), i.e. with_pos_embed + nn.Linear (+ ReLU) as

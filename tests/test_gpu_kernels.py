@@ -489,3 +489,17 @@ def test_groupnorm_tokens_vs_torch(ops, N, S, C, G, shift):
 def test_groupnorm_tokens_rejects_unsupported(ops):
     with pytest.raises(RuntimeError):       # 6 channels per group: a lane's float4 would straddle groups
         ops.groupnorm_tokens(torch.zeros(1, 4, 96).cuda(), torch.ones(96).cuda(), torch.zeros(96).cuda(), 16)
+
+
+# ------------------------------------------------------------------ K11 patch merging + LayerNorm
+@pytest.mark.parametrize("B,D,H,W,C", [(1, 8, 90, 160, 96), (1, 8, 45, 80, 192), (1, 8, 23, 40, 384), (2, 3, 7, 5, 128),
+                                       (1, 2, 1, 1, 512), (1, 0, 4, 4, 96)])
+def test_patch_merge_layernorm_vs_oracle(ops, B, D, H, W, C):
+    g = torch.Generator().manual_seed(H * W + C)
+    x = torch.randn(B, D, H, W, C, generator=g) * 2 + 0.5
+    w, b = torch.randn(4 * C, generator=g), torch.randn(4 * C, generator=g)
+    got = ops.patch_merge_layernorm(dev(x), dev(w), dev(b), 1e-5)
+    want = O.patch_merge_layernorm_core(x, w, b, 1e-5)
+    assert got.shape == want.shape
+    if got.numel():
+        assert maxdiff(got, want) < 3e-5

@@ -78,6 +78,7 @@ def oracle_kernels(monkeypatch):
     monkeypatch.setattr(hot_ops, "dynamic_mask", O.dynamic_mask_core)
     monkeypatch.setattr(hot_ops, "add_layernorm", O.add_layernorm_core)
     monkeypatch.setattr(hot_ops, "box_refine", O.box_refine_core)
+    monkeypatch.setattr(hot_ops, "patch_merge_layernorm", O.patch_merge_layernorm_core)
 
 
 def run_cfg(model, g):
