@@ -231,6 +231,16 @@ int soc_patch_merge_layernorm_f32(const float* x, const float* gamma, const floa
                                   int H, int W, int C, float eps, void* stream);
 
 /*
+ * K12 -- tiled fp32 MFMA GEMM with a fused activation: out = act(x W^T + bias), act 0 = none, 1 = ReLU,
+ * 2 = exact (erf) GELU.  Replaces fc1 + nn.GELU of the Video-Swin MLP (models/video_swin_transformer.py:24-37)
+ * where the fused form beats the library GEMM + a separate GELU pass.
+ *   x [M, K], w [N, K] (nn.Linear.weight layout), bias [N] or NULL, out [M, N]; K % 16 == 0, N % 4 == 0,
+ *   16-byte aligned pointers.
+ */
+int soc_linear_act_f32(const float* x, const float* w, const float* bias, float* out, int M, int N, int K, int act,
+                       void* stream);
+
+/*
  * K7 -- small-M linear layer out = act((x [+ x_add]) W^T + bias)  ("next": the
  * library-GEMM share; here the latency-bound query-side layers).  Replaces nn.Linear / F.linear on
  * the frame-query / video-query / word tensors: DeformableTransformerDecoderLayer

@@ -57,6 +57,18 @@ def linear_relu(x: torch.Tensor, lin: nn.Linear) -> torch.Tensor:
     return linear(x, lin.weight, lin.bias, relu=True)
 
 
+def linear_gelu(x: torch.Tensor, lin: nn.Linear) -> torch.Tensor:
+    """gelu(lin(x)), exact (erf) GELU.  Tall inputs with a short reduction (Video-Swin stages 0-1: >= 16384
+    tokens, K <= 256) run as K12 with the GELU applied to the accumulators; elsewhere the library GEMM is
+    faster than K12 by more than the separate GELU pass costs (tools/gemm_probe.py) and is kept."""
+    K = x.shape[-1]
+    rows = x.numel() // K
+    if (x.is_cuda and x.dtype == torch.float32 and rows >= 16384 and K <= 256 and K % 16 == 0
+            and lin.out_features % 4 == 0):
+        return hot_ops.linear_act(x, lin.weight, lin.bias, "gelu")
+    return F.gelu(lin(x))
+
+
 def apply(lin: nn.Linear, x: torch.Tensor, add: Optional[torch.Tensor] = None) -> torch.Tensor:
     """lin(x [+ add]) through `linear`."""
     return linear(x, lin.weight, lin.bias, add=add)

@@ -483,3 +483,19 @@ def patch_merge_layernorm(x: Tensor, weight: Tensor, bias: Tensor, eps: float = 
                                                  out.data_ptr(), B * D, H, W, C_, float(eps), _stream())
     _lib.check(code, "soc_patch_merge_layernorm_f32")
     return out
+
+
+def linear_act(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, act: str = "none") -> Tensor:
+    """K12.  act(x @ weight.T + bias) with act in {"none", "relu", "gelu"} (gelu = exact erf form) in one tiled
+    MFMA GEMM; x [..., K] with K % 16 == 0, weight [N, K] with N % 4 == 0."""
+    _need_gpu(x, weight, bias)
+    lib = _lib.load()
+    x, w = _f32c(x), _f32c(weight)
+    K = x.shape[-1]
+    M, N = x.numel() // K, w.shape[0]
+    out = torch.empty(*x.shape[:-1], N, dtype=torch.float32, device=x.device)
+    with _timed("linear_act", (M * K + N * K + M * N) * 4):
+        code = lib.soc_linear_act_f32(x.data_ptr(), w.data_ptr(), None if bias is None else _f32c(bias).data_ptr(),
+                                      out.data_ptr(), M, N, K, {"none": 0, "relu": 1, "gelu": 2}[act], _stream())
+    _lib.check(code, "soc_linear_act_f32")
+    return out

@@ -16,7 +16,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from . import hot_ops
+from . import fused, hot_ops
 from .nested_tensor import NestedTensor
 from .position_encoding import PositionEmbeddingSine2D
 
@@ -69,7 +69,7 @@ class Mlp(nn.Module):
         self.fc2 = nn.Linear(hidden, dim)
 
     def forward(self, x):
-        return self.fc2(F.gelu(self.fc1(x)))
+        return self.fc2(fused.linear_gelu(x, self.fc1))
 
 
 class SwinTransformerBlock3D(nn.Module):

@@ -614,6 +614,13 @@ def linear_core(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, add: O
     return F.relu(y) if relu else y
 
 
+def linear_act_core(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, act: str = "none") -> Tensor:
+    """Kernel-boundary form of K12: nn.Linear followed by nothing / ReLU / nn.GELU() (exact erf form), as in
+    Mlp.forward of reference models/video_swin_transformer.py:24-37."""
+    y = F.linear(x, weight, bias)
+    return {"none": lambda t: t, "relu": F.relu, "gelu": F.gelu}[act](y)
+
+
 def box_refine_core(delta: Tensor, ref: Tensor, valid_ratios: Optional[Tensor] = None):
     """Kernel-boundary form of K8: the iterative box refinement of reference
     models/deformable_transformer.py:369-381 plus the next layer's reference_points_input (:358-364)."""

@@ -503,3 +503,26 @@ def test_patch_merge_layernorm_vs_oracle(ops, B, D, H, W, C):
     assert got.shape == want.shape
     if got.numel():
         assert maxdiff(got, want) < 3e-5
+
+
+# ------------------------------------------------------------------ K12 tiled GEMM + activation
+@pytest.mark.parametrize("M,K,N,act,bias", [(115200, 96, 384, "gelu", True), (28800, 192, 768, "gelu", True),
+                                            (1000, 64, 132, "relu", True), (130, 16, 4, "none", False),
+                                            (257, 256, 260, "gelu", True), (0, 32, 8, "none", True)])
+def test_linear_act_vs_oracle(ops, M, K, N, act, bias):
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g) if bias else None
+    got = ops.linear_act(dev(x), dev(w), None if b is None else dev(b), act)
+    assert got.shape == (M, N)
+    if M:
+        want = O.linear_act_core(x.double(), w.double(), None if b is None else b.double(), act).float()
+        assert maxdiff(got, want) < 2e-5 * max(1.0, float(want.abs().max()))
+
+
+def test_linear_act_rejects_unsupported(ops):
+    with pytest.raises(RuntimeError):
+        ops.linear_act(torch.zeros(8, 24).cuda(), torch.zeros(8, 24).cuda())       # K % 16
+    with pytest.raises(RuntimeError):
+        ops.linear_act(torch.zeros(8, 32).cuda(), torch.zeros(6, 32).cuda())       # N % 4
