@@ -92,6 +92,10 @@ class VOC(nn.Module):
             raise RuntimeError("inference-only module")
         fq = frame_query[-1]                      # [T,B,Q,C]
         T, B, Q, C = fq.shape
+        # The reference RESHAPES [L,T,B,Q,C] to [L*B,T,Q,C] (:279) instead of permuting: for B > 1 the (t, b)
+        # pairs are re-read as (b, t) in memory order, i.e. frames are redistributed over the batch.
+        # Identity for B = 1 (every inference driver); kept so that a padded batch matches the reference too.
+        fq = fq.reshape(B, T, Q, C).transpose(0, 1)
         if self.enc_layers == 0:
             x = fq.permute(0, 2, 1, 3).reshape(T * Q, B, C)
         elif self.window_size == 0:

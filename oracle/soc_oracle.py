@@ -484,6 +484,7 @@ def voc(sd: SD, hs_last: Tensor, sentence: Tensor, p: str = "voc", n_enc: int = 
     hs_last [T,B,Q,C] (= hs[-1]), sentence [B,C] -> [B,Q,C]
     """
     T, B, Q, C = hs_last.shape
+    hs_last = hs_last.reshape(B, T, Q, C).transpose(0, 1)   # the reference reshapes [L,T,B,..] to [L*B,T,..] (:279); identity for B = 1
     if window_size == 0:
         fq = hs_last.permute(0, 2, 1, 3).reshape(T * Q, B, C)  # (t q) b c
         for i in range(n_enc):  # :349-351

@@ -36,11 +36,13 @@ class FixedTokenizer:
 
     def __init__(self):
         self.ids = None
+        self.attn = None        # optional attention mask (padded expressions in a batch)
 
     def batch_encode_plus(self, texts, padding="longest", return_tensors="pt"):
         from transformers import BatchEncoding
         ids = self.ids.clone()
-        return BatchEncoding({"input_ids": ids, "attention_mask": torch.ones_like(ids)})
+        attn = torch.ones_like(ids) if self.attn is None else self.attn.clone()
+        return BatchEncoding({"input_ids": ids, "attention_mask": attn})
 
 
 def _install_stubs():

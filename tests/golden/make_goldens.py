@@ -1,5 +1,5 @@
 """Generate the committed golden vectors by running the REFERENCE itself (CPU) in the build
-container.  Usage:  python tests/golden/make_goldens.py [--only tiny|kernels|msda|msda_grad|voc_window|full|t10]
+container.  Usage:  python tests/golden/make_goldens.py [--only tiny|kernels|msda|msda_grad|voc_window|padded_b2|full|t10]
 
 Inputs are regenerated from seeds (neurips2023_soc_amd.weights); only outputs / captured
 kernel I/O are stored.  The .npz files are data; no reference source is stored.
@@ -184,6 +184,32 @@ def gen_kernels(ref, model):
     print("kernel goldens:", {k: v.shape for k, v in d.items()})
 
 
+def gen_padded_b2(ref):
+    """A padded batch of two clips of different size with two expressions of different length: the
+    general form of misc.nested_tensor_from_videos_list + tokenizer padding (B = 1 never pads)."""
+    import misc
+    model = build(ref)
+    T, L = 2, 7
+    sizes = [(64, 96), (48, 80)]
+    clips = [W.synthetic_clip(21 + b, T, h, w) for b, (h, w) in enumerate(sizes)]
+    ids = torch.cat([W.synthetic_token_ids(21, L), W.synthetic_token_ids(22, L)], 0)
+    attn = torch.ones_like(ids)
+    ids[1, 5:] = 1            # <pad>
+    ids[1, 4] = 2             # </s> of the shorter expression
+    attn[1, 5:] = 0
+    model.tokenizer.ids, model.tokenizer.attn = ids, attn
+    samples = misc.nested_tensor_from_videos_list(clips)
+    targets = [[{"size": torch.tensor(list(s))} for s in sizes] for _ in range(T)]
+    with torch.no_grad():
+        out = model(samples, None, ["a", "b"], targets)
+    model.tokenizer.attn = None
+    d = out_dict(out)
+    d["ids"], d["attn"] = ids.numpy(), attn.numpy()
+    d["sizes"], d["seeds"], d["T"] = np.array(sizes), np.array([21, 22]), np.array(T)
+    np.savez_compressed(os.path.join(HERE, "padded_b2_forward.npz"), **d)
+    print("padded B=2 forward written; max|logit| =", float(np.abs(d["pred_masks"]).max()), d["pred_masks"].shape)
+
+
 def gen_voc_window(ref):
     """The reference VOC module with temporal windows (models/voc.py:336-414; window_size > 0 is in no
     shipped config, so it gets its own known-answer cases): T = 6 (padded to 8) and T = 8, W = 4."""
@@ -334,6 +360,8 @@ def main():
         gen_msda_grad(ref)
     if want("voc_window"):
         gen_voc_window(ref)
+    if want("padded_b2"):
+        gen_padded_b2(ref)
     model = None
     if want("tiny") or want("kernels") or want("t10") or want("full"):
         model = build(ref)

@@ -165,3 +165,10 @@ def test_clip_inferencer_end_to_end(gpu_model, golden):
     diff = res["masks"].cpu() != (want > 0)
     assert res["masks"].shape == (T, 720, 1280)
     assert int(diff.sum()) <= 40 and (not diff.any() or float(want[diff].abs().max()) < 1e-3)
+
+
+def test_padded_batch_of_two_matches_reference(gpu_model, golden):
+    """B = 2 with frame and word padding on the GPU (fused K2 with the pad mask, K3 key padding masks)."""
+    from tests.test_host_plumbing import check_padded_b2, run_padded_b2
+    g = golden("padded_b2_forward.npz")
+    check_padded_b2(run_padded_b2(gpu_model, g, "cuda"), g)

@@ -19,7 +19,7 @@ from tests.golden_utils import t
 
 
 def maxdiff(a, b):
-    return float((torch.as_tensor(a).double() - torch.as_tensor(b).double()).abs().max())
+    return float((torch.as_tensor(a).detach().cpu().double() - torch.as_tensor(b).double()).abs().max())
 
 
 @pytest.fixture(scope="module")
@@ -102,6 +102,35 @@ def test_plumbing_reproduces_reference_tiny(cpu_model, oracle_kernels, golden):
     assert maxdiff(out["pred_boxes"], g["pred_boxes"]) < 1e-5
     assert maxdiff(out["pred_logit"], g["pred_logit"]) < 1e-4
     assert maxdiff(out["text_sentence_feature"], g["text_sentence_feature"]) < 1e-4
+
+
+def run_padded_b2(model, g, device="cpu"):
+    T = int(g["T"])
+    clips = [W.synthetic_clip(int(seed), T, int(h), int(w)) for seed, (h, w) in zip(g["seeds"], g["sizes"])]
+    samples = S.nested_tensor_from_videos_list(clips).to(device)
+    assert not samples.unpadded and bool(samples.mask.any())
+    ids, attn = torch.from_numpy(g["ids"]).to(device), torch.from_numpy(g["attn"]).to(device)
+    targets = [[{"size": torch.tensor([int(h), int(w)])} for h, w in g["sizes"]] for _ in range(T)]
+    return model(samples, None, {"input_ids": ids, "attention_mask": attn}, targets)
+
+
+def check_padded_b2(out, g):
+    for k in ("pred_masks", "pred_cls", "pred_boxes", "pred_logit", "text_sentence_feature"):
+        assert tuple(out[k].shape) == g[k].shape, k
+    assert maxdiff(out["pred_masks"], g["pred_masks"]) < 1e-3
+    flips = (out["pred_masks"].cpu().numpy() > 0) != (g["pred_masks"] > 0)
+    assert flips.sum() <= 2 and (not flips.any() or np.abs(g["pred_masks"][flips]).max() < 2.5e-4)
+    assert maxdiff(out["pred_cls"], g["pred_cls"]) < 1e-4
+    assert maxdiff(out["pred_boxes"], g["pred_boxes"]) < 1e-5
+    assert maxdiff(out["pred_logit"], g["pred_logit"]) < 1e-4
+    assert maxdiff(out["text_sentence_feature"], g["text_sentence_feature"]) < 1e-4
+
+
+def test_plumbing_padded_batch_of_two(cpu_model, oracle_kernels, golden):
+    """B = 2, clips of different size (frame padding, valid ratios < 1, K2 pad mask) and expressions of
+    different length (word padding mask in vlf / lvf / the sentence feature)."""
+    g = golden("padded_b2_forward.npz")
+    check_padded_b2(run_padded_b2(cpu_model, g), g)
 
 
 def test_plumbing_t10_temporal_shift(cpu_model, oracle_kernels, golden):
