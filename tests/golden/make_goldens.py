@@ -1,5 +1,5 @@
 """Generate the committed golden vectors by running the REFERENCE itself (CPU) in the build
-container.  Usage:  python tests/golden/make_goldens.py [--only tiny|kernels|msda|msda_grad|voc_window|padded_b2|full|t10]
+container.  Usage:  python tests/golden/make_goldens.py [--only tiny|kernels|msda|msda_grad|voc_window|padded_b2|odd|full|t10]
 
 Inputs are regenerated from seeds (neurips2023_soc_amd.weights); only outputs / captured
 kernel I/O are stored.  The .npz files are data; no reference source is stored.
@@ -184,6 +184,21 @@ def gen_kernels(ref, model):
     print("kernel goldens:", {k: v.shape for k, v in d.items()})
 
 
+ODD = [(1, 96, 128, 4), (5, 70, 90, 9), (9, 64, 64, 3), (2, 33, 47, 12)]
+
+
+def gen_odd(ref):
+    """Clip shapes outside the headline configs: one frame, odd frame counts, sizes that pad at every stage."""
+    model = build(ref)
+    d = {"cfgs": np.array(ODD)}
+    for i, (T, H_, W_, L) in enumerate(ODD):
+        out, _, _ = run(ref, model, dict(seed=100 + T, T=T, H=H_, W=W_, L=L))
+        for k in ("pred_masks", "pred_cls", "pred_boxes", "pred_logit"):
+            d[f"c{i}_{k}"] = out[k].numpy()
+    np.savez_compressed(os.path.join(HERE, "odd_geometries.npz"), **d)
+    print("odd-geometry goldens written")
+
+
 def gen_padded_b2(ref):
     """A padded batch of two clips of different size with two expressions of different length: the
     general form of misc.nested_tensor_from_videos_list + tokenizer padding (B = 1 never pads)."""
@@ -362,6 +377,8 @@ def main():
         gen_voc_window(ref)
     if want("padded_b2"):
         gen_padded_b2(ref)
+    if want("odd"):
+        gen_odd(ref)
     model = None
     if want("tiny") or want("kernels") or want("t10") or want("full"):
         model = build(ref)

@@ -179,3 +179,16 @@ def test_windowed_voc_oracle_matches_reference(golden, ref_shapes, tag):
     sd = W.synthetic_state_dict(shapes, 2023)
     out = O.voc(sd, t(g[tag + "_fq"])[-1], t(g[tag + "_lang"]), window_size=4)
     assert float((out - t(g[tag + "_out"])[0]).abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize("case", [0, 1, 2, 3])
+def test_oracle_odd_geometries(golden, synthetic_sd, case):
+    """T = 1 / 5 / 9 / 2 at sizes that pad at every stage (tests/golden/make_goldens.py --only odd)."""
+    from neurips2023_soc_amd import weights as W
+    g = golden("odd_geometries.npz")
+    T, H, Wd, L = (int(v) for v in g["cfgs"][case])
+    ids = W.synthetic_token_ids(100 + T, L)
+    out = O.soc_forward(synthetic_sd, W.synthetic_clip(100 + T, T, H, Wd), ids, torch.ones_like(ids), (H, Wd))
+    assert float((out["pred_masks"] - t(g[f"c{case}_pred_masks"])).abs().max()) < 2e-4
+    assert float((out["pred_cls"] - t(g[f"c{case}_pred_cls"])).abs().max()) < 1e-5
+    assert float((out["pred_boxes"] - t(g[f"c{case}_pred_boxes"])).abs().max()) < 1e-5
