@@ -408,7 +408,7 @@ def main():
 def gen_shapes(ref):
     """key -> [shape, dtype] of the reference state_dict (checkpoint-compat contract)."""
     import json
-    for bb in ("video-swin-t", "video-swin-b"):
+    for bb in ("video-swin-t", "video-swin-s", "video-swin-b"):
         torch.manual_seed(0)
         model, _, _ = ref.build_model(H.reference_args(bb))
         table = {k: [list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in model.state_dict().items()}

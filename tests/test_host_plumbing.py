@@ -32,7 +32,7 @@ def cpu_model(synthetic_sd):
     return model.eval()
 
 
-@pytest.mark.parametrize("tag,backbone", [("t", "video-swin-t"), ("b", "video-swin-b")])
+@pytest.mark.parametrize("tag,backbone", [("t", "video-swin-t"), ("s", "video-swin-s"), ("b", "video-swin-b")])
 def test_state_dict_matches_reference_checkpoint_layout(ref_shapes, tag, backbone):
     """Every key / shape / dtype of the reference state_dict exists here (SURVEY 8b checkpoint API)."""
     model, _, _ = S.build_model(S.default_args(backbone, text_encoder_random_init=True))
