@@ -173,7 +173,7 @@ def main():
                                 "avg_launch_us": 1e3 * k1["ms"] / k1["launches"],
                                 "ms_per_clip": k1["ms"] / a.steps}
         other = {}
-        for name in ("msda_fwd", "xattn", "dyn_mask", "add_layernorm"):
+        for name in ("msda_fwd", "xattn", "dyn_mask", "add_layernorm", "groupnorm_tokens", "patch_merge_layernorm"):
             if name in prof:
                 r = prof[name]
                 gbs = r["work"] / (r["ms"] * 1e-3) / 1e9
@@ -183,6 +183,9 @@ def main():
                                "algorithmic_bytes_per_clip": r["work"] / a.steps,
                                "traffic": traffic.get(name) if default_cfg else None}
         line["roofline_other"] = other
+        # every hand-written kernel of the forward (HIP-event time of the instrumented eager pass)
+        line["kernel_ms_per_clip"] = {name: {"launches_per_clip": r["launches"] / a.steps, "ms": r["ms"] / a.steps}
+                                      for name, r in sorted(prof.items())}
 
         if world == 1 and not a.no_cpu_baseline:
             from oracle import soc_oracle as O
