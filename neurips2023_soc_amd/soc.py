@@ -151,8 +151,10 @@ class SOC(nn.Module):
         self.vl_loss, self.aux_loss = config.vl_loss, config.aux_loss
 
     def _side_stream(self, device):
+        """One side stream per (device, calling stream): forwards issued on different streams (several
+        clips in flight) fork onto different side streams and stay independent."""
         streams = self.__dict__.setdefault("_streams", {})
-        key = str(device)
+        key = (str(device), torch.cuda.current_stream(device).cuda_stream)
         if key not in streams:
             streams[key] = torch.cuda.Stream(device=device)
         return streams[key]
