@@ -181,6 +181,11 @@ class VideoClipCache:
         self._inflight: Dict[Tuple[str, ...], "object"] = {}
         self._pool = PinnedPool()
 
+    def close(self) -> None:
+        """Stop the background decoder thread (pending prefetches are dropped)."""
+        self._loader.shutdown(wait=False, cancel_futures=True)
+        self._inflight.clear()
+
     def prefetch(self, paths: Sequence[str]) -> None:
         """Start decoding `paths` on the host in the background (no GPU work, no effect on results)."""
         key = tuple(paths)

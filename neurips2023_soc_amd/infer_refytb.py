@@ -113,5 +113,6 @@ def run(model, tokenize: Tokenize, root: str, out_dir: str, rank: int = 0, world
             f.result()
         stats["seconds_writer_tail"] = time.perf_counter() - t_tail
     torch.cuda.synchronize()
+    cache.close()
     stats.update(seconds=time.perf_counter() - t0, cache_hits=cache.hits, cache_misses=cache.misses)
     return stats

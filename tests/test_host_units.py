@@ -71,3 +71,48 @@ def test_product_package_never_imports_the_oracle():
                 assert not pat.search(src), f"{f} references the oracle"
     bench = open(os.path.join(ROOT, "bench.py")).read()
     assert bench.count("from oracle import") == 1   # the cpu_baseline leg only
+
+
+def test_broadcast_rows_forms():
+    """hot_ops._broadcast_rows: how a positional term broadcasts over the flattened rows of x (K7's x_add)."""
+    from neurips2023_soc_amd.hot_ops import _broadcast_rows
+    K = 16
+    pos = torch.randn(5, K)
+    x_lead = (3, 5)
+    # batch-first: the same [Q,K] table for every frame -> row m uses pos[m % 5]
+    base, div, mod = _broadcast_rows(pos[None].expand(3, 5, K), x_lead, K)
+    assert (div, mod) == (1, 5) and base.data_ptr() == pos.data_ptr()
+    # sequence-first: [Q,1,K] expanded over the frame dim -> row m uses pos[m // 3]
+    base, div, mod = _broadcast_rows(pos[:, None].expand(5, 3, K), (5, 3), K)
+    assert (div, mod) == (3, 5) and base.data_ptr() == pos.data_ptr()
+    # plain contiguous tensor of x's shape
+    full = torch.randn(3, 5, K)
+    base, div, mod = _broadcast_rows(full, x_lead, K)
+    assert (div, mod) == (1, 15) and base.shape == (15, K)
+    # a single row broadcast everywhere
+    base, div, mod = _broadcast_rows(pos[:1][None].expand(3, 5, K), x_lead, K)
+    assert (div, mod) == (1, 1)
+    # every row checked against x + add
+    x = torch.randn(3, 5, K)
+    for add in (pos[None].expand(3, 5, K), full, pos[:1][None].expand(3, 5, K)):
+        base, div, mod = _broadcast_rows(add, x_lead, K)
+        rows = torch.arange(15)
+        assert torch.equal(x.reshape(15, K) + base[(rows // div) % mod], (x + add).reshape(15, K))
+    # not of that form: non-contiguous last dim / wrong shape / transposed inner dims
+    assert _broadcast_rows(torch.randn(3, 5, 2 * K)[..., ::2], x_lead, K) is None
+    assert _broadcast_rows(torch.randn(5, K), x_lead, K) is None
+    assert _broadcast_rows(torch.randn(5, 3, K).transpose(0, 1), x_lead, K) is None
+
+
+def test_fused_linear_uses_library_on_cpu():
+    """fused.linear / linear_multi / linear_gelu on CPU tensors: the library path, same numbers as torch."""
+    import torch.nn.functional as F
+    from neurips2023_soc_amd import fused
+    g = torch.Generator().manual_seed(0)
+    x, p = torch.randn(7, 32, generator=g), torch.randn(7, 32, generator=g)
+    lin = torch.nn.Linear(32, 24)
+    assert not fused.is_small(x)          # K7 is GPU-only
+    assert torch.equal(fused.linear(x, lin.weight, lin.bias, add=p, relu=True), F.relu(lin(x + p)))
+    a, b = fused.linear_multi(x, [(lin.weight, lin.bias, True), (lin.weight, None, False)], p)
+    assert torch.equal(a, lin(x + p)) and torch.equal(b, F.linear(x, lin.weight))
+    assert torch.equal(fused.linear_gelu(x, lin), F.gelu(lin(x)))
