@@ -180,17 +180,34 @@ class VideoClipCache:
         self._loader = ThreadPoolExecutor(max_workers=1)     # decodes the NEXT clip while the GPU runs this one
         self._inflight: Dict[Tuple[str, ...], "object"] = {}
         self._pool = PinnedPool()
+        self._copy_stream = None
 
     def close(self) -> None:
         """Stop the background decoder thread (pending prefetches are dropped)."""
         self._loader.shutdown(wait=False, cancel_futures=True)
         self._inflight.clear()
 
+    def _load_and_upload(self, paths):
+        """Background thread: decode into pinned memory, then -- on the cache's own copy stream, so the DMA
+        and K9 overlap the forward running on the main stream -- upload and pre-process.  Returns the item and
+        the event the consumer's stream has to wait for."""
+        entry = load_frames(paths, self.workers, self._pool)
+        if not (torch.cuda.is_available() and self.pre.device.type == "cuda"):
+            return self.pre(entry[0]), None
+        if self._copy_stream is None:
+            self._copy_stream = torch.cuda.Stream(device=self.pre.device)
+        with torch.cuda.stream(self._copy_stream):
+            item = self.pre(entry[0])
+            ready = torch.cuda.Event()
+            ready.record()
+        entry[1] = ready                     # the staging buffer may be refilled once this copy has left it
+        return item, ready
+
     def prefetch(self, paths: Sequence[str]) -> None:
-        """Start decoding `paths` on the host in the background (no GPU work, no effect on results)."""
+        """Start decoding / uploading `paths` in the background (no effect on results)."""
         key = tuple(paths)
         if key and key not in self._items and key not in self._inflight:
-            self._inflight[key] = self._loader.submit(load_frames, list(paths), self.workers, self._pool)
+            self._inflight[key] = self._loader.submit(self._load_and_upload, list(paths))
 
     def get(self, paths: Sequence[str]) -> Tuple[torch.Tensor, Tuple[int, int]]:
         key = tuple(paths)
@@ -200,11 +217,17 @@ class VideoClipCache:
             return self._items[key]
         self.misses += 1
         fut = self._inflight.pop(key, None)
-        entry = fut.result() if fut is not None else load_frames(paths, self.workers, self._pool)
-        item = self.pre(entry[0])
-        if item[0].is_cuda:                  # the staging buffer may be refilled once this copy has left it
-            entry[1] = torch.cuda.Event()
-            entry[1].record()
+        if fut is not None:
+            item, ready = fut.result()
+            if ready is not None:            # produced on the copy stream: order the consumer after it
+                torch.cuda.current_stream(self.pre.device).wait_event(ready)
+                item[0].record_stream(torch.cuda.current_stream(self.pre.device))
+        else:
+            entry = load_frames(paths, self.workers, self._pool)
+            item = self.pre(entry[0])
+            if item[0].is_cuda:
+                entry[1] = torch.cuda.Event()
+                entry[1].record()
         self._items[key] = item
         self._bytes += item[0].numel() * 4
         while self._bytes > self.max_bytes and len(self._items) > 1:

@@ -79,6 +79,8 @@ def run(model, tokenize: Tokenize, root: str, out_dir: str, rank: int = 0, world
             pinned[key] = torch.empty(tuple(shape), dtype=torch.bool, pin_memory=True)
         return pinned[key]
 
+    d2h = torch.cuda.Stream(device=device)    # mask download overlaps the next clip's forward
+
     with ThreadPoolExecutor(max_workers=writer_workers) as writers:
         prev = None
         for vi, video in enumerate(todo):
@@ -93,9 +95,12 @@ def run(model, tokenize: Tokenize, root: str, out_dir: str, rank: int = 0, world
                 t2 = time.perf_counter()
                 masks = engine(clip, ids, orig)["masks"]                       # [T,H0,W0] bool, still in flight
                 host = host_buffer(masks.shape, stats["expressions"] % 2)
-                host.copy_(masks, non_blocking=True)
-                done = torch.cuda.Event()
-                done.record()
+                d2h.wait_stream(torch.cuda.current_stream(device))
+                with torch.cuda.stream(d2h):
+                    host.copy_(masks, non_blocking=True)
+                    masks.record_stream(d2h)
+                    done = torch.cuda.Event()
+                    done.record()
                 save_dir = os.path.join(out_dir, video, exp_id)
                 os.makedirs(save_dir, exist_ok=True)
                 if prev is not None:
