@@ -235,36 +235,51 @@ class SOC(nn.Module):
         T = pos[-1].shape[0] // B
         text_pos = self.text_pos(text).permute(2, 0, 1)
 
-        srcs, masks, poses, lang_last = [], [], [], None
         levels = list(zip(backbone_out[-3:], pos[-3:]))
-        for l, (feat, pos_l) in enumerate(levels):
-            src, mask = feat.decompose()
-            h, w = src.shape[-2:]
-            seq = self._project_level(l, src, B, T)
+        n_levels = self.num_feature_levels
+        if n_levels > len(levels) + 1:
+            raise NotImplementedError("more than one extra feature level is not used by any shipped config")
+        unpadded = bool(getattr(samples, "unpadded", False))
+
+        def fuse_level(l):
+            """input_proj + vision<-language fusion of level l -> (tokens '(b t) (h w) c', mask, pos, lang | None)"""
+            lang = None
+            if l < len(levels):
+                feat, pos_l = levels[l]
+                src, mask = feat.decompose()
+                h, w = src.shape[-2:]
+                seq = self._project_level(l, src, B, T)
+                if l == len(levels) - 1:  # only langs[-1] is read downstream
+                    lang = self.lvf(tgt=words, memory=seq,
+                                    memory_key_padding_mask=mask.view(B, T, h, w).reshape(B, -1),
+                                    pos=self._seq(pos_l, B, T))
+            else:                          # the extra level: 3x3 / stride-2 conv of the coarsest backbone map
+                src = self.input_proj[l](backbone_out[-1].tensors)
+                mask = resize_pad_mask(samples.mask, src.shape[-2:])
+                pos_l = self.backbone.position_encoding(NestedTensor(src, mask), unpadded)
+                h, w = src.shape[-2:]
+                seq = self._seq(src, B, T)
             fused = self.vlf(tgt=seq, memory=words, memory_key_padding_mask=word_pad, pos=text_pos)
-            if l == len(levels) - 1:  # only langs[-1] is read downstream
-                lang_last = self.lvf(tgt=words, memory=seq,
-                                     memory_key_padding_mask=mask.view(B, T, h, w).reshape(B, -1),
-                                     pos=self._seq(pos_l, B, T))
-            srcs.append(self._tokens(fused, B, T, h, w))
-            masks.append(mask)
-            poses.append(pos_l)
-        for l in range(len(levels), self.num_feature_levels):
-            if l > len(levels):
-                raise NotImplementedError("more than one extra feature level is not used by any shipped config")
-            src = self.input_proj[l](backbone_out[-1].tensors)
-            mask = resize_pad_mask(samples.mask, src.shape[-2:])
-            pos_l = self.backbone.position_encoding(NestedTensor(src, mask), bool(getattr(samples, "unpadded", False)))
-            h, w = src.shape[-2:]
-            fused = self.vlf(tgt=self._seq(src, B, T), memory=words, memory_key_padding_mask=word_pad, pos=text_pos)
-            srcs.append(self._tokens(fused, B, T, h, w))
-            masks.append(mask)
-            poses.append(pos_l)
+            return self._tokens(fused, B, T, h, w), mask, pos_l, lang
+
+        # The levels are independent of each other: the finest one (75 % of the tokens) runs on the main
+        # stream while the coarser ones -- short, latency-bound launches -- run beside it on the side stream.
+        if side is not None and n_levels > 1:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                rest = [fuse_level(l) for l in range(1, n_levels)]
+            per_level = [fuse_level(0)] + rest
+            main.wait_stream(side)
+        else:
+            per_level = [fuse_level(l) for l in range(n_levels)]
+        srcs = [p[0] for p in per_level]
+        masks = [p[1] for p in per_level]
+        poses = [p[2] for p in per_level]
+        lang_last = next(p[3] for p in per_level if p[3] is not None)
 
         Q = self.num_queries
         tgt = words.new_zeros(B, T, Q, words.shape[-1])
-        memory, ctx = self.transformer.encode(srcs, masks, poses, token_major=True,
-                                              unpadded=bool(getattr(samples, "unpadded", False)))
+        memory, ctx = self.transformer.encode(srcs, masks, poses, token_major=True, unpadded=unpadded)
 
         # Fork again: the FPN spatial decoder (convs over the memory maps) only meets the query branch
         # (decoder -> VOC -> heads -> controller, ~250 small latency-bound launches) at the dynamic
