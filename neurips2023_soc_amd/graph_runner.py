@@ -50,11 +50,17 @@ class ClipGraph:
         CP.pack_record(self.record, idx, out["pred_cls"][:, 0, :, 0], masks)
         return out
 
-    def run(self, clip: torch.Tensor, ids: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
-        """clip [T,3,H,W] or [T,1,3,H,W] on the device; returns the static output dict (valid until
-        the next run) -- `self.record` holds the packed (query, scores, selected masks) result."""
+    def run(self, clip: torch.Tensor, ids: Optional[torch.Tensor] = None,
+            attn: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+        """clip [T,3,H,W] or [T,1,3,H,W] on the device; ids / attn [1,L] token ids and attention mask (ones
+        when omitted); returns the static output dict (valid until the next run) -- `self.record` holds the
+        packed (query, scores, selected masks) result."""
         self.clip.copy_(clip.view(self.clip.shape), non_blocking=True)
         if ids is not None:
             self.ids.copy_(ids.view(self.ids.shape), non_blocking=True)
+            if attn is None:
+                self.attn.fill_(1)
+            else:
+                self.attn.copy_(attn.view(self.attn.shape), non_blocking=True)
         self.graph.replay()
         return self.out

@@ -29,9 +29,16 @@ class ClipInferencer:
     masks.  use_graphs=True pays off on streams of one geometry (bench, DAVIS 36-frame clips); whole-video
     clips with free-form expressions (Ref-YouTube-VOS: T and L change per call) run eagerly."""
 
-    def __init__(self, model, device="cuda", use_graphs: bool = True, max_graphs: int = 4):
+    PAD_ID = 1            # RoBERTa <pad>
+
+    def __init__(self, model, device="cuda", use_graphs: bool = True, max_graphs: int = 4,
+                 pad_tokens_to: Optional[int] = None):
+        """pad_tokens_to: with graphs, pad every expression to this many tokens (<pad> + attention mask 0), so
+        that the graph geometry does not depend on the expression.  The reference's outputs are exactly
+        invariant to such padding (checked on the reference itself; tests/test_host_plumbing.py checks the
+        oracle), which is what tokenizer(..., padding="longest") does to the shorter expressions of a batch."""
         self.model, self.device = model, torch.device(device)
-        self.use_graphs, self.max_graphs = use_graphs, max_graphs
+        self.use_graphs, self.max_graphs, self.pad_tokens_to = use_graphs, max_graphs, pad_tokens_to
         self._graphs: Dict[Tuple[int, int, int, int], ClipGraph] = {}
 
     def graph_for(self, T: int, H: int, W: int, L: int) -> ClipGraph:
@@ -48,8 +55,14 @@ class ClipInferencer:
         """-> (reference output dict, packed record or None)"""
         T, _, H, W = clip.shape
         if self.use_graphs:
-            g = self.graph_for(T, H, W, token_ids.shape[-1])
-            return g.run(clip, token_ids), g.record
+            ids, attn = token_ids.view(1, -1), None
+            L = ids.shape[-1]
+            if self.pad_tokens_to is not None and L < self.pad_tokens_to:
+                extra = self.pad_tokens_to - L
+                attn = torch.cat([torch.ones_like(ids), ids.new_zeros(1, extra)], 1)
+                ids = torch.cat([ids, ids.new_full((1, extra), self.PAD_ID)], 1)
+            g = self.graph_for(T, H, W, ids.shape[-1])
+            return g.run(clip, ids, attn), g.record
         samples = NestedTensor(clip[:, None], torch.zeros(T, 1, H, W, dtype=torch.bool, device=clip.device),
                                unpadded=True)
         ids = token_ids.view(1, -1)
@@ -108,7 +121,7 @@ def _run_dataset(a):
         tokenize = synthetic_dataset.HashTokenizer()
     driver = infer_refytb if a.dataset == "refytb" else infer_davis
     model = model.to(dev).eval()
-    engine = ClipInferencer(model, dev, use_graphs=a.graphs)      # shared across passes: graphs stay captured
+    engine = ClipInferencer(model, dev, use_graphs=a.graphs, pad_tokens_to=32)   # shared across passes
     for _ in range(max(a.repeat, 1)):
         stats = driver.run(model, tokenize, a.root, a.out, rank, world, dev, engine=engine)
     stats["clips_per_s"] = stats["expressions"] / stats["seconds"]

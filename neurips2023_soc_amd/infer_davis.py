@@ -54,7 +54,7 @@ def run(model, tokenize: Tokenize, root: str, out_dir: str, rank: int = 0, world
         split: str = "valid", size: int = 360, max_size: Optional[int] = 640, use_graphs: bool = False,
         decode_workers: int = 8, writer_workers: int = 16, palette: Optional[Sequence[int]] = None,
         videos: Optional[Sequence[str]] = None, annotators: int = 4,
-        engine: Optional[ClipInferencer] = None) -> Dict:
+        engine: Optional[ClipInferencer] = None, pad_tokens_to: Optional[int] = 32) -> Dict:
     img_folder, data = load_meta(root, split)
     if palette is None:
         ref_png = os.path.join(root, split, "Annotations", "blackswan", "00000.png")
@@ -64,7 +64,7 @@ def run(model, tokenize: Tokenize, root: str, out_dir: str, rank: int = 0, world
         else:
             palette = davis_palette()
     todo = split_videos(sorted(data.keys()) if videos is None else list(videos), rank, world)
-    engine = engine or ClipInferencer(model, device, use_graphs=use_graphs)
+    engine = engine or ClipInferencer(model, device, use_graphs=use_graphs, pad_tokens_to=pad_tokens_to)
     cache = clip_io.VideoClipCache(clip_io.FramePreprocessor(device, size, max_size), workers=decode_workers)
     stats = {"videos": 0, "expressions": 0, "frames": 0, "seconds_input": 0.0, "seconds_model": 0.0}
     pending = []

@@ -51,12 +51,12 @@ def load_meta(root: str, split: str = "valid"):
 def run(model, tokenize: Tokenize, root: str, out_dir: str, rank: int = 0, world: int = 1, device="cuda",
         split: str = "valid", size: int = 360, max_size: Optional[int] = 640, use_graphs: bool = False,
         decode_workers: int = 8, writer_workers: int = 16, videos: Optional[Sequence[str]] = None,
-        engine: Optional[ClipInferencer] = None) -> Dict:
+        engine: Optional[ClipInferencer] = None, pad_tokens_to: Optional[int] = 32) -> Dict:
     """Process this rank's videos; returns counters + timings.  `tokenize(expression) -> int64 [1,L]`
     (RobertaTokenizerFast in production; no vocabulary files exist offline, so the caller supplies it)."""
     img_folder, data = load_meta(root, split)
     todo = split_videos(sorted(data.keys()) if videos is None else list(videos), rank, world)
-    engine = engine or ClipInferencer(model, device, use_graphs=use_graphs)
+    engine = engine or ClipInferencer(model, device, use_graphs=use_graphs, pad_tokens_to=pad_tokens_to)
     cache = clip_io.VideoClipCache(clip_io.FramePreprocessor(device, size, max_size), workers=decode_workers)
     stats = {"videos": 0, "expressions": 0, "frames": 0, "seconds_input": 0.0, "seconds_model": 0.0}
     pending = []

@@ -189,3 +189,19 @@ def test_odd_geometries_match_reference(gpu_model, golden, case):
     assert maxdiff(out["pred_cls"], g[f"c{case}_pred_cls"]) < 1e-4
     assert maxdiff(out["pred_boxes"], g[f"c{case}_pred_boxes"]) < 1e-5
     assert maxdiff(out["pred_logit"], g[f"c{case}_pred_logit"]) < 1e-4
+
+
+def test_clip_inferencer_pads_expressions_for_graph_reuse(gpu_model, golden):
+    """Two expressions of different length share one graph (padded to 16 tokens) and give the eager results."""
+    from neurips2023_soc_amd.infer import ClipInferencer
+    T, H, Wd = 3, 96, 128
+    clip = W.synthetic_clip(9, T, H, Wd).cuda()
+    eager = ClipInferencer(gpu_model, "cuda", use_graphs=False)
+    graphs = ClipInferencer(gpu_model, "cuda", use_graphs=True, pad_tokens_to=16)
+    for L in (5, 11):
+        ids = W.synthetic_token_ids(30 + L, L).cuda()
+        a, b = eager(clip, ids, (H, Wd)), graphs(clip, ids, (H, Wd))
+        assert int(a["query"]) == int(b["query"])
+        assert maxdiff(b["mask_logits"], a["mask_logits"].cpu()) < 1e-4
+        assert float((a["masks"] != b["masks"]).float().mean()) < 1e-4
+    assert len(graphs._graphs) == 1

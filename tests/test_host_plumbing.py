@@ -133,6 +133,20 @@ def test_plumbing_padded_batch_of_two(cpu_model, oracle_kernels, golden):
     check_padded_b2(run_padded_b2(cpu_model, g), g)
 
 
+def test_expression_padding_does_not_change_the_outputs(synthetic_sd):
+    """<pad> tokens with attention mask 0 behind the expression leave every output unchanged (exactly so for the
+    reference, checked in the build container): ClipInferencer relies on it to key hipGraphs on (T, H, W) only."""
+    from oracle import soc_oracle as O
+    T, H, Wd = 2, 64, 96
+    clip, ids = W.synthetic_clip(5, T, H, Wd), W.synthetic_token_ids(5, 6)
+    a = O.soc_forward(synthetic_sd, clip, ids, torch.ones_like(ids), (H, Wd))
+    padded = torch.cat([ids, torch.ones(1, 4, dtype=torch.long)], 1)
+    attn = torch.cat([torch.ones_like(ids), torch.zeros(1, 4, dtype=torch.long)], 1)
+    b = O.soc_forward(synthetic_sd, clip, padded, attn, (H, Wd))
+    for k in ("pred_masks", "pred_cls", "pred_boxes", "pred_logit", "text_sentence_feature"):
+        assert maxdiff(a[k], b[k]) < 1e-6, k
+
+
 def test_plumbing_t10_temporal_shift(cpu_model, oracle_kernels, golden):
     """T=10 > window: temporal shift 4 and D padded to 16 ('next')."""
     from tests.golden_utils import sub
