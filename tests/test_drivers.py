@@ -125,3 +125,22 @@ def test_davis_driver_matches_reference_recipe(gpu_model, tmp_path):
             total += bad.size
             wrong += int(bad.sum())
     assert wrong <= 2e-4 * total
+
+
+def test_png_writers_formats(tmp_path):
+    """8-bit 'L' 0/255 masks (infer_refytb.py:272-277) and palette label maps (infer_davis.py:285-291)."""
+    from PIL import Image
+    from neurips2023_soc_amd.infer_davis import save_label_map
+    from neurips2023_soc_amd.infer_refytb import save_binary_mask
+    mask = np.zeros((5, 7), dtype=bool)
+    mask[1:3, 2:6] = True
+    save_binary_mask(mask, str(tmp_path / "m.png"))
+    # the reference's own conversion: float32 mask * 255 -> convert('L')
+    ref = Image.fromarray(mask.astype(np.float32) * 255).convert("L")
+    got = Image.open(tmp_path / "m.png")
+    assert got.mode == "L" and np.array_equal(np.array(got), np.array(ref))
+    labels = np.array([[0, 1, 2], [2, 1, 0]], dtype=np.uint8)
+    save_label_map(labels, str(tmp_path / "l.png"), davis_palette())
+    png = Image.open(tmp_path / "l.png")
+    assert png.mode == "P" and np.array_equal(np.array(png), labels)
+    assert png.getpalette()[:9] == [0, 0, 0, 128, 0, 0, 0, 128, 0]
