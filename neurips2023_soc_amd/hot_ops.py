@@ -308,7 +308,7 @@ def upsample_threshold(mask_logits: Tensor, size: Sequence[int], threshold_logit
     return out.view(torch.bool)
 
 
-SMALL_LINEAR_MAX_ROWS = 512
+SMALL_LINEAR_MAX_ROWS = 1024
 
 
 def _broadcast_rows(add: Tensor, lead: Sequence[int], K: int):
