@@ -83,7 +83,7 @@ def run(model, tokenize: Tokenize, root: str, out_dir: str, rank: int = 0, world
                 orig = None
                 for obj in range(num_obj):
                     text = exps[exp_ids[obj * annotators + anno]]["exp"]
-                    ids = tokenize(" ".join(text.lower().split())).to(device)
+                    ids = tokenize(text).to(device)
                     chunks = []
                     for c0 in range(0, len(frames), CLIP_LEN):
                         t1 = time.perf_counter()

@@ -91,7 +91,7 @@ def run(model, tokenize: Tokenize, root: str, out_dir: str, rank: int = 0, world
             for exp_id, item in data[video]["expressions"].items():
                 t1 = time.perf_counter()
                 clip, orig = cache.get(paths)                                  # decoded / resized once per video
-                ids = tokenize(" ".join(item["exp"].lower().split())).pin_memory().to(device, non_blocking=True)
+                ids = tokenize(item["exp"]).pin_memory().to(device, non_blocking=True)
                 t2 = time.perf_counter()
                 masks = engine(clip, ids, orig)["masks"]                       # [T,H0,W0] bool, still in flight
                 host = host_buffer(masks.shape, stats["expressions"] % 2)

@@ -78,7 +78,7 @@ def test_refytb_driver_matches_reference_recipe(gpu_model, tmp_path):
     total = wrong = 0
     for video, item in data.items():
         for exp_id, e in item["expressions"].items():
-            logits, (H0, W0) = _oracle_clip_outputs(sd, root, video, item["frames"], " ".join(e["exp"].lower().split()), tok)
+            logits, (H0, W0) = _oracle_clip_outputs(sd, root, video, item["frames"], e["exp"], tok)
             up = F.interpolate(logits[None], size=(H0, W0), mode="bilinear", align_corners=False)[0]
             want = (up.sigmoid() > 0.5).numpy()
             for j, name in enumerate(item["frames"]):
@@ -113,7 +113,7 @@ def test_davis_driver_matches_reference_recipe(gpu_model, tmp_path):
         scores = []
         for obj in range(2):
             text = item["expressions"][exp_ids[obj * 4 + anno]]["exp"]
-            logits, (H0, W0) = _oracle_clip_outputs(sd, root, video, item["frames"], " ".join(text.lower().split()), tok)
+            logits, (H0, W0) = _oracle_clip_outputs(sd, root, video, item["frames"], text, tok)
             scores.append(F.interpolate(logits[None], size=(H0, W0), mode="bilinear", align_corners=False)[0].sigmoid())
         m = torch.stack(scores)
         m[m < 0.5] = 0.0
