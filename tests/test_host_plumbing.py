@@ -5,7 +5,6 @@ plumbing around the kernels here, the four hot-op entry points are monkeypatched
 only -- with the oracle's kernel-boundary functions; the result must reproduce the reference's
 golden outputs, which proves module wiring, layouts and state_dict naming independently of HIP.
 """
-import json
 import os
 
 import numpy as np

@@ -1,6 +1,5 @@
 """Where does the dataset driver's host time go?  Replays infer_refytb's loop on a synthetic dataset with a
 timer around every host step.  Usage: python tools/e2e_probe.py ROOT"""
-import os
 import sys
 import time
 from collections import defaultdict
