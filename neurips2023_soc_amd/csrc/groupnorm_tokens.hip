@@ -65,21 +65,33 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
                                                        float* __restrict__ out, int S, int C, int G, int chunks,
                                                        float eps) {
     __shared__ float mean_s[64], rstd_s[64];
+    __shared__ double part_s[4][64], part_q[4][64];
     const int n = blockIdx.y, chunk = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nvec = C >> 2, cpg = C / G, cpg4 = cpg >> 2;
     const float* xn = x + (long)n * S * C;
-    if (threadIdx.x < G) {
+    // fold the chunk partials of this frame: lane = group, the 4 waves take every 4th chunk (independent loads,
+    // a fixed order -> bit-identical from run to run), then one thread per group adds the 4 slices
+    {
         double s = 0.0, q = 0.0;
-        for (int c = 0; c < chunks; ++c) {
-            const float2 p = partial[((long)n * chunks + c) * G + threadIdx.x];
-            s += p.x; q += p.y;
+        if (lane < G) {
+            for (int c = wave; c < chunks; c += 4) {
+                const float2 p = partial[((long)n * chunks + c) * G + lane];
+                s += p.x; q += p.y;
+            }
         }
+        part_s[wave][lane] = s; part_q[wave][lane] = q;
+    }
+    __syncthreads();
+    if (threadIdx.x < G) {
+        const int t = threadIdx.x;
+        const double s = (part_s[0][t] + part_s[1][t]) + (part_s[2][t] + part_s[3][t]);
+        const double q = (part_q[0][t] + part_q[1][t]) + (part_q[2][t] + part_q[3][t]);
         const double cnt = (double)S * cpg;
         const double md = s / cnt;                                  // mean of (x - pivot)
         const double var = fmax(q / cnt - md * md, 0.0);
-        mean_s[threadIdx.x] = (float)((double)xn[threadIdx.x * cpg] + md);
-        rstd_s[threadIdx.x] = (float)(1.0 / sqrt(var + (double)eps));
+        mean_s[t] = (float)((double)xn[t * cpg] + md);
+        rstd_s[t] = (float)(1.0 / sqrt(var + (double)eps));
     }
     __syncthreads();
     if (lane >= nvec) return;
