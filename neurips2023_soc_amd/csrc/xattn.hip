@@ -31,24 +31,33 @@ __global__ __launch_bounds__(256) void xattn_kernel(
     const int lane = threadIdx.x & 63;
     const int h = blockIdx.y % H;
     const int b = blockIdx.y / H;
-    const int qi = (blockIdx.x * 4 + wave) * 64 + lane;
-    const bool live = qi < Lq;
-    const int qc = live ? qi : Lq - 1;
+    const int qc = min((int)(blockIdx.x * 4 + wave) * 64 + lane, Lq - 1);   // this lane's query row (clamped)
     const int E = H * HD;
     const int k0 = 0, k1 = Lk;
     // element offset of row (l, b): sequence-first (l*B + b)*E, batch-first (b*L + l)*E
     const long q_ls = batch_first ? E : (long)B * E, q_bs = batch_first ? (long)Lq * E : E;
     const long kstride = batch_first ? E : (long)B * E, k_bs = batch_first ? (long)Lk * E : E;
 
-    float qr[HD];
-    {
-        const float4* qp = reinterpret_cast<const float4*>(q + qc * q_ls + b * q_bs + h * HD);
+    // q rows (and later the output rows) go through a per-wave LDS tile: global accesses are 8 rows x 128 B per
+    // instruction (one fully used line per row) instead of 64 lanes each touching its own row
+    __shared__ __attribute__((aligned(16))) float tile_s[4][64 * 36];
+    float* tile = tile_s[wave];
+    const int q0 = (blockIdx.x * 4 + wave) * 64;
+    const int sub_r = lane >> 3, sub_c = lane & 7;
 #pragma unroll
-        for (int i = 0; i < HD / 4; ++i) {
-            const float4 t = qp[i];
-            qr[4 * i] = t.x * scale; qr[4 * i + 1] = t.y * scale;
-            qr[4 * i + 2] = t.z * scale; qr[4 * i + 3] = t.w * scale;
-        }
+    for (int i = 0; i < 8; ++i) {
+        const int row = i * 8 + sub_r;
+        const int qq = min(q0 + row, Lq - 1);
+        const float4 t = *reinterpret_cast<const float4*>(q + qq * q_ls + b * q_bs + h * HD + sub_c * 4);
+        *reinterpret_cast<float4*>(tile + row * 36 + sub_c * 4) = t;
+    }
+    __builtin_amdgcn_wave_barrier();
+    float qr[HD];
+#pragma unroll
+    for (int i = 0; i < HD / 4; ++i) {
+        const float4 t = *reinterpret_cast<const float4*>(tile + lane * 36 + 4 * i);   // same wave: no barrier needed
+        qr[4 * i] = t.x * scale; qr[4 * i + 1] = t.y * scale;
+        qr[4 * i + 2] = t.z * scale; qr[4 * i + 3] = t.w * scale;
     }
     const float* kb = k + b * k_bs + h * HD;  // + j*kstride, wave-uniform
     const float* vb = v + b * k_bs + h * HD;
@@ -83,13 +92,19 @@ __global__ __launch_bounds__(256) void xattn_kernel(
 #pragma unroll
         for (int d = 0; d < HD; ++d) acc[d] += p * vr[d];
     }
-    if (!live) return;
     const float inv = 1.f / l;  // l == 0 (all keys padded) -> NaN, as torch.softmax gives
-    float4* op = reinterpret_cast<float4*>(out + qi * q_ls + b * q_bs + h * HD);
 #pragma unroll
     for (int i = 0; i < HD / 4; ++i)
-        op[i] = make_float4(acc[4 * i] * inv, acc[4 * i + 1] * inv, acc[4 * i + 2] * inv,
-                            acc[4 * i + 3] * inv);
+        *reinterpret_cast<float4*>(tile + lane * 36 + 4 * i) =
+            make_float4(acc[4 * i] * inv, acc[4 * i + 1] * inv, acc[4 * i + 2] * inv, acc[4 * i + 3] * inv);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = i * 8 + sub_r;
+        if (q0 + row < Lq)
+            *reinterpret_cast<float4*>(out + (q0 + row) * q_ls + b * q_bs + h * HD + sub_c * 4) =
+                *reinterpret_cast<const float4*>(tile + row * 36 + sub_c * 4);
+    }
 }
 
 // few queries (decoder / VOC / lvf): one 256-thread workgroup per (query, b, head) row.
