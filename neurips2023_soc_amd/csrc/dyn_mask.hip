@@ -20,7 +20,7 @@ constexpr int NPARAM = (CF + 2) * CH + CH * CH + CH + CH + CH + 1;  // 169
 __global__ __launch_bounds__(256) void dyn_mask_kernel(
     const float* __restrict__ feats, const float* __restrict__ params,
     const float* __restrict__ refs, float* __restrict__ out, int Q, int hw, int w, float img_h,
-    float img_w, int stride) {
+    float img_w, int stride, int q_per_block) {
     const int t = blockIdx.y;
     const int pix = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = pix < hw;
@@ -34,7 +34,10 @@ __global__ __launch_bounds__(256) void dyn_mask_kernel(
 #pragma unroll
     for (int c = 0; c < CF; ++c) f[c] = fp[(long)c * hw];
 
-    for (int q = 0; q < Q; ++q) {
+    // blockIdx.z picks a slice of the frame's instances: with all Q per thread the launch has < 2 waves per
+    // SIMD at the BASELINE config and the scalar parameter loads are fully exposed
+    const int q_lo = blockIdx.z * q_per_block, q_hi = min(Q, q_lo + q_per_block);
+    for (int q = q_lo; q < q_hi; ++q) {
         const int inst = t * Q + q;
         const float* __restrict__ P = params + (long)inst * NPARAM;  // wave-uniform
         const float rx = refs[inst * 2] * img_w - px;
@@ -79,8 +82,13 @@ extern "C" int soc_dyn_mask_f32(const float* feats, const float* params, const f
     if (C != CF) return SOC_EUNSUPPORTED;
     if (T == 0 || Q == 0) return SOC_OK;
     const int hw = h * w;
-    dim3 grid(soc_ceil_div(hw, 256), T);
+    // enough workgroups for ~8 waves per SIMD (256 CUs x 4 SIMDs): split the Q instances over grid.z
+    const long base_waves = (long)soc_ceil_div(hw, 256) * 4 * T;
+    int groups = (int)((8192 + base_waves - 1) / base_waves);
+    groups = groups < 1 ? 1 : (groups > Q ? Q : groups);
+    const int q_per_block = soc_ceil_div(Q, groups);
+    dim3 grid(soc_ceil_div(hw, 256), T, soc_ceil_div(Q, q_per_block));
     hipLaunchKernelGGL(dyn_mask_kernel, grid, dim3(256), 0, (hipStream_t)stream, feats, params,
-                       refs, out, Q, hw, w, img_h, img_w, stride);
+                       refs, out, Q, hw, w, img_h, img_w, stride, q_per_block);
     return soc_check_launch();
 }
