@@ -239,6 +239,15 @@ int soc_patch_merge_layernorm_f32(const float* x, const float* gamma, const floa
  */
 int soc_linear_act_f32(const float* x, const float* w, const float* bias, float* out, int M, int N, int K, int act,
                        void* stream);
+/*
+ * The same with the input formed as x + x_add (x_add [M, K] or NULL: the positional term of with_pos_embed) and
+ * one or two layers that read it (HOST arrays of length nseg <= 2, as in soc_linear_small_multi_f32): the
+ * deformable encoder's sampling_offsets + attention_weights on `src + pos`
+ * (models/ops/modules/ms_deform_attn.py:96-97, models/deformable_transformer.py:245-249) as one launch.
+ */
+int soc_linear_act_multi_f32(const float* x, const float* x_add, int nseg, const float* const* w,
+                             const float* const* bias, float* const* out, const int* N, int M, int K, int act,
+                             void* stream);
 
 /*
  * K7 -- small-M linear layer out = act((x [+ x_add]) W^T + bias)  ("next": the

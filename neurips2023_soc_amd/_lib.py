@@ -16,7 +16,8 @@ EXPORTS = ("soc_hip_abi_version", "soc_hip_error_string", "soc_msda_fwd_f32", "s
            "soc_linear_small_f32", "soc_linear_small_multi_f32", "soc_box_refine_f32",
            "soc_upsample_merge_labels_u8", "soc_resize_workspace_bytes", "soc_resize_normalize_u8_f32",
            "soc_msda_bwd_f32", "soc_msda_bwd_f64", "soc_groupnorm_tokens_workspace_bytes",
-           "soc_groupnorm_tokens_f32", "soc_patch_merge_layernorm_f32", "soc_linear_act_f32")
+           "soc_groupnorm_tokens_f32", "soc_patch_merge_layernorm_f32", "soc_linear_act_f32",
+           "soc_linear_act_multi_f32")
 ABI_VERSION = 2
 
 _lib = None
@@ -82,6 +83,8 @@ def load() -> C.CDLL:
     lib.soc_patch_merge_layernorm_f32.argtypes = [p, p, p, p, i, i, i, i, f, p]
     lib.soc_linear_act_f32.restype = i
     lib.soc_linear_act_f32.argtypes = [p, p, p, p, i, i, i, i, p]
+    lib.soc_linear_act_multi_f32.restype = i
+    lib.soc_linear_act_multi_f32.argtypes = [p, p, i, p, p, p, p, i, i, i, p]
     if lib.soc_hip_abi_version() != ABI_VERSION:
         raise SocHipError("libsoc_hip.so ABI version mismatch; rebuild it")
     _lib = lib

@@ -26,25 +26,41 @@ constexpr int PLANE = BM * 4 + 4;     // floats per kq plane (+4: shifts banks b
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
 
-template <int ACT, int KP>   // ACT: 0 none, 1 relu, 2 gelu(erf);  KP: 4-wide k planes per step (BK = 4*KP)
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const float* __restrict__ A, const float* __restrict__ W,
-                                                         const float* __restrict__ bias, float* __restrict__ C,
-                                                         int M, int N, int K) {
+// up to two layers that read the same input: column tiles [0, tile1) belong to segment 0, the rest to segment 1
+struct Seg2 {
+    const float* w[2];
+    const float* bias[2];
+    float* out[2];
+    int N[2];
+    int tile1;       // first column tile of segment 1 (== total tiles when there is one segment)
+};
+
+// ACT: 0 none, 1 relu, 2 gelu(erf);  KP: 4-wide k planes per step (BK = 4*KP);  HAS_ADD: A = x + x_add
+template <int ACT, int KP, bool HAS_ADD>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const float* __restrict__ A, const float* __restrict__ ADD,
+                                                         const Seg2 sg, int M, int K) {
+    const int seg = (int)blockIdx.x >= sg.tile1 ? 1 : 0;
+    const float* __restrict__ W = sg.w[seg];
+    const float* __restrict__ bias = sg.bias[seg];
+    float* __restrict__ C = sg.out[seg];
+    const int N = sg.N[seg];
     constexpr int BK = 4 * KP;
     constexpr int RPP = 256 / KP;              // rows covered per load pass
     constexpr int NP = BM / RPP;               // load passes per operand
     __shared__ __attribute__((aligned(16))) float lds[2][2][KP * PLANE];   // [buf][A|W][k plane][row][4]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int m0 = blockIdx.y * BM, n0 = ((int)blockIdx.x - (seg ? sg.tile1 : 0)) * BN;
     const int r = lane & 15, kq = lane >> 4;
     const int lrow = tid / KP, lkq = tid % KP;
     const float* ap[NP];
+    const float* pp[NP];
     const float* wp[NP];
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
         const int ra = min(m0 + lrow + RPP * i, M - 1), rw = min(n0 + lrow + RPP * i, N - 1);
         ap[i] = A + (long)ra * K + 4 * lkq;
+        pp[i] = HAS_ADD ? ADD + (long)ra * K + 4 * lkq : nullptr;
         wp[i] = W + (long)rw * K + 4 * lkq;
     }
     float4 ga[NP], gw[NP];
@@ -56,6 +72,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const float* __restrict
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
         ga[i] = *reinterpret_cast<const float4*>(ap[i]);
+        if (HAS_ADD) {
+            const float4 t = *reinterpret_cast<const float4*>(pp[i]);
+            ga[i].x += t.x; ga[i].y += t.y; ga[i].z += t.z; ga[i].w += t.w;
+        }
         gw[i] = *reinterpret_cast<const float4*>(wp[i]);
     }
 #pragma unroll
@@ -71,6 +91,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const float* __restrict
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             ga[i] = *reinterpret_cast<const float4*>(ap[i] + knext);
+            if (HAS_ADD) {
+                const float4 t = *reinterpret_cast<const float4*>(pp[i] + knext);
+                ga[i].x += t.x; ga[i].y += t.y; ga[i].z += t.z; ga[i].w += t.w;
+            }
             gw[i] = *reinterpret_cast<const float4*>(wp[i] + knext);
         }
 #pragma unroll
@@ -118,23 +142,44 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const float* __restrict
 }
 
 
-template <int KP>
-int launch(const float* A, const float* W, const float* bias, float* C, int M, int N, int K, int act, hipStream_t st) {
-    dim3 grid(soc_ceil_div(N, BN), soc_ceil_div(M, BM));
-    if (act == 0) hipLaunchKernelGGL((gemm_nt_kernel<0, KP>), grid, dim3(256), 0, st, A, W, bias, C, M, N, K);
-    else if (act == 1) hipLaunchKernelGGL((gemm_nt_kernel<1, KP>), grid, dim3(256), 0, st, A, W, bias, C, M, N, K);
-    else hipLaunchKernelGGL((gemm_nt_kernel<2, KP>), grid, dim3(256), 0, st, A, W, bias, C, M, N, K);
+template <bool HAS_ADD>
+int launch(const float* x, const float* x_add, const Seg2& sg, int tiles, int M, int K, int act, hipStream_t st) {
+    dim3 grid(tiles, soc_ceil_div(M, BM));
+    if (act == 0) hipLaunchKernelGGL((gemm_nt_kernel<0, 4, HAS_ADD>), grid, dim3(256), 0, st, x, x_add, sg, M, K);
+    else if (act == 1) hipLaunchKernelGGL((gemm_nt_kernel<1, 4, HAS_ADD>), grid, dim3(256), 0, st, x, x_add, sg, M, K);
+    else hipLaunchKernelGGL((gemm_nt_kernel<2, 4, HAS_ADD>), grid, dim3(256), 0, st, x, x_add, sg, M, K);
     return soc_check_launch();
 }
 
 }  // namespace
 
+extern "C" int soc_linear_act_multi_f32(const float* x, const float* x_add, int nseg, const float* const* w,
+                                        const float* const* bias, float* const* out, const int* N, int M, int K,
+                                        int act, void* stream) {
+    if (M < 0 || K <= 0 || act < 0 || act > 2 || nseg < 1 || !w || !out || !N) return SOC_EINVAL;
+    if (nseg > 2) return SOC_EUNSUPPORTED;
+    if (M == 0) return SOC_OK;
+    if (!x) return SOC_EINVAL;
+    if (K % 16 != 0) return SOC_EUNSUPPORTED;
+    Seg2 sg;
+    int tiles = 0;
+    for (int i = 0; i < 2; ++i) {
+        const int j = i < nseg ? i : 0;
+        if (!w[j] || !out[j] || N[j] <= 0) return SOC_EINVAL;
+        if (N[j] % 4 != 0) return SOC_EUNSUPPORTED;
+        const float* b = bias ? bias[j] : nullptr;
+        if ((((uintptr_t)w[j] | (uintptr_t)out[j] | (uintptr_t)b) & 15) != 0) return SOC_EUNSUPPORTED;
+        sg.w[i] = w[j]; sg.bias[i] = b; sg.out[i] = out[j]; sg.N[i] = N[j];
+        if (i == 1) sg.tile1 = nseg > 1 ? tiles : (1 << 30);
+        if (i < nseg) tiles += soc_ceil_div(N[j], BN);
+    }
+    if ((((uintptr_t)x | (uintptr_t)x_add) & 15) != 0) return SOC_EUNSUPPORTED;
+    if (x_add) return launch<true>(x, x_add, sg, tiles, M, K, act, (hipStream_t)stream);
+    return launch<false>(x, x_add, sg, tiles, M, K, act, (hipStream_t)stream);
+}
+
 extern "C" int soc_linear_act_f32(const float* x, const float* w, const float* bias, float* out, int M, int N, int K,
                                   int act, void* stream) {
-    if (M < 0 || N <= 0 || K <= 0 || act < 0 || act > 2) return SOC_EINVAL;
-    if (M == 0) return SOC_OK;
-    if (!x || !w || !out) return SOC_EINVAL;
-    if (K % 16 != 0 || N % 4 != 0) return SOC_EUNSUPPORTED;
-    if ((((uintptr_t)x | (uintptr_t)w | (uintptr_t)out | (uintptr_t)bias) & 15) != 0) return SOC_EUNSUPPORTED;
-    return launch<4>(x, w, bias, out, M, N, K, act, (hipStream_t)stream);
+    if (N <= 0) return SOC_EINVAL;
+    return soc_linear_act_multi_f32(x, nullptr, 1, &w, &bias, &out, &N, M, K, act, stream);
 }

@@ -29,8 +29,8 @@ class DeformableTransformerEncoderLayer(nn.Module):
 
     def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None,
                 pad_flag=None):
-        a, _, _ = self.self_attn(src + pos, reference_points, src, spatial_shapes, level_start_index, padding_mask,
-                                 pad_flag=pad_flag, return_sampling=False)
+        a, _, _ = self.self_attn(src, reference_points, src, spatial_shapes, level_start_index, padding_mask,
+                                 pad_flag=pad_flag, return_sampling=False, query_pos=pos)
         src = _add_norm(src, a, self.norm1)
         return _add_norm(src, fused.apply(self.linear2, linear_relu(src, self.linear1)), self.norm2)
 

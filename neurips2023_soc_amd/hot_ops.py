@@ -499,3 +499,30 @@ def linear_act(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, act: st
                                       out.data_ptr(), M, N, K, {"none": 0, "relu": 1, "gelu": 2}[act], _stream())
     _lib.check(code, "soc_linear_act_f32")
     return out
+
+
+def linear_act_multi(x: Tensor, layers: Sequence[Tuple[Tensor, Optional[Tensor]]], add: Optional[Tensor] = None,
+                     act: str = "none") -> List[Tensor]:
+    """K12, several outputs.  [act((x + add) @ w.T + b) for (w, b) in layers] (at most two layers) in one tiled
+    MFMA GEMM launch; `add` (optional) has x's shape."""
+    _need_gpu(x, add, *(w for w, _ in layers))
+    lib = _lib.load()
+    x = _f32c(x)
+    K = x.shape[-1]
+    M = x.numel() // K
+    add_ptr = None
+    if add is not None:
+        add = _f32c(add.expand_as(x))
+        add_ptr = add.data_ptr()
+    n = len(layers)
+    ws = [_f32c(w) for w, _ in layers]
+    bs = [None if b is None else _f32c(b) for _, b in layers]
+    outs = [torch.empty(*x.shape[:-1], w.shape[0], dtype=torch.float32, device=x.device) for w in ws]
+    vp = C.c_void_p * n
+    with _timed("linear_act", (M * K * (1 + (add is not None)) + sum(w.numel() + M * w.shape[0] for w in ws)) * 4):
+        code = lib.soc_linear_act_multi_f32(x.data_ptr(), add_ptr, n, vp(*(w.data_ptr() for w in ws)),
+                                            vp(*(None if b is None else b.data_ptr() for b in bs)),
+                                            vp(*(o.data_ptr() for o in outs)), (C.c_int * n)(*(w.shape[0] for w in ws)),
+                                            M, K, {"none": 0, "relu": 1, "gelu": 2}[act], _stream())
+    _lib.check(code, "soc_linear_act_multi_f32")
+    return outs

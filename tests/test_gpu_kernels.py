@@ -526,3 +526,19 @@ def test_linear_act_rejects_unsupported(ops):
         ops.linear_act(torch.zeros(8, 24).cuda(), torch.zeros(8, 24).cuda())       # K % 16
     with pytest.raises(RuntimeError):
         ops.linear_act(torch.zeros(8, 32).cuda(), torch.zeros(6, 32).cuda())       # N % 4
+
+
+def test_linear_act_multi_with_add(ops):
+    """K12 with the x + pos prologue and two output segments (encoder sampling offsets + attention weights)."""
+    g = torch.Generator().manual_seed(3)
+    M, K = 4000, 256
+    x, pos = torch.randn(M, K, generator=g), torch.randn(M, K, generator=g)
+    w0, b0 = torch.randn(256, K, generator=g) / 16, torch.randn(256, generator=g)
+    w1, b1 = torch.randn(132, K, generator=g) / 16, None
+    o0, o1 = ops.linear_act_multi(dev(x), [(dev(w0), dev(b0)), (dev(w1), None)], dev(pos))
+    for got, w, b in ((o0, w0, b0), (o1, w1, b1)):
+        want = O.linear_core(x.double(), w.double(), None if b is None else b.double(), pos.double()).float()
+        assert got.shape == want.shape and maxdiff(got, want) < 3e-5 * max(1.0, float(want.abs().max()))
+    from neurips2023_soc_amd import fused
+    a0, a1 = fused.linear_multi(dev(x), [(dev(w0), dev(b0), True), (dev(w1), None, True)], dev(pos))
+    assert torch.equal(a0, o0) and torch.equal(a1, o1)
