@@ -241,7 +241,7 @@ int soc_linear_act_f32(const float* x, const float* w, const float* bias, float*
                        void* stream);
 /*
  * The same with the input formed as x + x_add (x_add [M, K] or NULL: the positional term of with_pos_embed) and
- * one or two layers that read it (HOST arrays of length nseg <= 2, as in soc_linear_small_multi_f32): the
+ * one to four layers that read it (HOST arrays of length nseg <= 4, as in soc_linear_small_multi_f32): the
  * deformable encoder's sampling_offsets + attention_weights on `src + pos`
  * (models/ops/modules/ms_deform_attn.py:96-97, models/deformable_transformer.py:245-249) as one launch.
  */

@@ -26,20 +26,25 @@ constexpr int PLANE = BM * 4 + 4;     // floats per kq plane (+4: shifts banks b
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
 
-// up to two layers that read the same input: column tiles [0, tile1) belong to segment 0, the rest to segment 1
+// up to four layers that read the same input: segment i owns the column tiles [tile0[i], tile0[i+1])
+constexpr int MAX_SEG = 4;
 struct Seg2 {
-    const float* w[2];
-    const float* bias[2];
-    float* out[2];
-    int N[2];
-    int tile1;       // first column tile of segment 1 (== total tiles when there is one segment)
+    const float* w[MAX_SEG];
+    const float* bias[MAX_SEG];
+    float* out[MAX_SEG];
+    int N[MAX_SEG];
+    int tile0[MAX_SEG];
+    int nseg;
 };
 
 // ACT: 0 none, 1 relu, 2 gelu(erf);  KP: 4-wide k planes per step (BK = 4*KP);  HAS_ADD: A = x + x_add
 template <int ACT, int KP, bool HAS_ADD>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const float* __restrict__ A, const float* __restrict__ ADD,
                                                          const Seg2 sg, int M, int K) {
-    const int seg = (int)blockIdx.x >= sg.tile1 ? 1 : 0;
+    int seg = 0;
+#pragma unroll
+    for (int i = 1; i < MAX_SEG; ++i)
+        if (i < sg.nseg && (int)blockIdx.x >= sg.tile0[i]) seg = i;
     const float* __restrict__ W = sg.w[seg];
     const float* __restrict__ bias = sg.bias[seg];
     float* __restrict__ C = sg.out[seg];
@@ -50,7 +55,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const float* __restrict
     __shared__ __attribute__((aligned(16))) float lds[2][2][KP * PLANE];   // [buf][A|W][k plane][row][4]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * BM, n0 = ((int)blockIdx.x - (seg ? sg.tile1 : 0)) * BN;
+    const int m0 = blockIdx.y * BM, n0 = ((int)blockIdx.x - sg.tile0[seg]) * BN;
     const int r = lane & 15, kq = lane >> 4;
     const int lrow = tid / KP, lkq = tid % KP;
     const float* ap[NP];
@@ -157,22 +162,23 @@ extern "C" int soc_linear_act_multi_f32(const float* x, const float* x_add, int 
                                         const float* const* bias, float* const* out, const int* N, int M, int K,
                                         int act, void* stream) {
     if (M < 0 || K <= 0 || act < 0 || act > 2 || nseg < 1 || !w || !out || !N) return SOC_EINVAL;
-    if (nseg > 2) return SOC_EUNSUPPORTED;
+    if (nseg > MAX_SEG) return SOC_EUNSUPPORTED;
     if (M == 0) return SOC_OK;
     if (!x) return SOC_EINVAL;
     if (K % 16 != 0) return SOC_EUNSUPPORTED;
     Seg2 sg;
     int tiles = 0;
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < MAX_SEG; ++i) {
         const int j = i < nseg ? i : 0;
         if (!w[j] || !out[j] || N[j] <= 0) return SOC_EINVAL;
         if (N[j] % 4 != 0) return SOC_EUNSUPPORTED;
         const float* b = bias ? bias[j] : nullptr;
         if ((((uintptr_t)w[j] | (uintptr_t)out[j] | (uintptr_t)b) & 15) != 0) return SOC_EUNSUPPORTED;
         sg.w[i] = w[j]; sg.bias[i] = b; sg.out[i] = out[j]; sg.N[i] = N[j];
-        if (i == 1) sg.tile1 = nseg > 1 ? tiles : (1 << 30);
+        sg.tile0[i] = tiles;
         if (i < nseg) tiles += soc_ceil_div(N[j], BN);
     }
+    sg.nseg = nseg;
     if ((((uintptr_t)x | (uintptr_t)x_add) & 15) != 0) return SOC_EUNSUPPORTED;
     if (x_add) return launch<true>(x, x_add, sg, tiles, M, K, act, (hipStream_t)stream);
     return launch<false>(x, x_add, sg, tiles, M, K, act, (hipStream_t)stream);

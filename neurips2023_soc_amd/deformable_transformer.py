@@ -80,12 +80,12 @@ class DeformableTransformerDecoderLayer(nn.Module):
         self.norm3 = nn.LayerNorm(d_model)
 
     def forward(self, tgt, query_pos, reference_points, src, spatial_shapes, level_start_index, src_padding_mask=None,
-                pad_flag=None):
+                pad_flag=None, value=None):
         tgt = _add_norm(tgt, self.self_attn(tgt, tgt, tgt, query_add=query_pos, key_add=query_pos,
                                             batch_first=True), self.norm2)
         c, loc, w = self.cross_attn(tgt, reference_points, src, spatial_shapes, level_start_index,
                                     src_padding_mask, pad_flag=pad_flag, return_sampling=False,
-                                    query_pos=query_pos)
+                                    query_pos=query_pos, value=value)
         tgt = _add_norm(tgt, c, self.norm1)
         tgt = _add_norm(tgt, fused.apply(self.linear2, linear_relu(tgt, self.linear1)), self.norm3)
         return tgt, loc, w
@@ -100,7 +100,7 @@ class DeformableTransformerDecoder(nn.Module):
         self.class_embed = None
 
     def forward(self, tgt, reference_points, src, spatial_shapes, level_start_index, valid_ratios,
-                query_pos=None, src_padding_mask=None, pad_flag=None):
+                query_pos=None, src_padding_mask=None, pad_flag=None, values=None):
         out = tgt
         inter, inter_refs = [], []
         ref_in = None
@@ -111,7 +111,7 @@ class DeformableTransformerDecoder(nn.Module):
                 else:
                     ref_in = reference_points[:, :, None] * valid_ratios[:, None]
             out, _, _ = layer(out, query_pos, ref_in, src, spatial_shapes, level_start_index, src_padding_mask,
-                              pad_flag)
+                              pad_flag, value=None if values is None else values[lid])
             ref_in = None
             # (the reference's top-30 sample bookkeeping :383-389 feeds nothing in SOC.forward)
             if self.bbox_embed is not None:
@@ -223,14 +223,15 @@ class DeformableTransformer(nn.Module):
             at += h * w
         return maps, (memory, spatial_shapes, level_start, ratios, mask, pad_flag)
 
-    def decode(self, ctx, tgt, query_embed):
+    def decode(self, ctx, tgt, query_embed, values=None):
         """tgt [b,t,q,c], query_embed [q,c] -> hs [l,(b t),q,c], init_ref [(b t),q,2], inter_refs [l,(b t),q,4]"""
         memory, spatial_shapes, level_start, ratios, mask, pad_flag = ctx
         b, t, q, c = tgt.shape
         tgt = tgt.reshape(b * t, q, c)
         qpos = query_embed.unsqueeze(0).expand(b * t, -1, -1)
         ref = self.reference_points(query_embed).sigmoid().unsqueeze(0).expand(b * t, -1, -1)
-        hs, inter_refs, _ = self.decoder(tgt, ref, memory, spatial_shapes, level_start, ratios, qpos, mask, pad_flag)
+        hs, inter_refs, _ = self.decoder(tgt, ref, memory, spatial_shapes, level_start, ratios, qpos, mask, pad_flag,
+                                         values=values)
         return hs, ref, inter_refs
 
     def forward(self, srcs, tgt, masks, pos_embeds, query_embed=None):

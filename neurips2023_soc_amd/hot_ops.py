@@ -503,7 +503,7 @@ def linear_act(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, act: st
 
 def linear_act_multi(x: Tensor, layers: Sequence[Tuple[Tensor, Optional[Tensor]]], add: Optional[Tensor] = None,
                      act: str = "none") -> List[Tensor]:
-    """K12, several outputs.  [act((x + add) @ w.T + b) for (w, b) in layers] (at most two layers) in one tiled
+    """K12, several outputs.  [act((x + add) @ w.T + b) for (w, b) in layers] (at most four layers) in one tiled
     MFMA GEMM launch; `add` (optional) has x's shape."""
     _need_gpu(x, add, *(w for w, _ in layers))
     lib = _lib.load()

@@ -88,15 +88,17 @@ class MSDeformAttn(nn.Module):
 
     def forward(self, query, reference_points, input_flatten, input_spatial_shapes,
                 input_level_start_index, input_padding_mask=None, pad_flag=None, return_sampling=True,
-                query_pos=None):
+                query_pos=None, value=None):
         """Reference signature plus optional arguments used by this package's own layers
-        (``query_pos``: added to ``query`` inside the offset / weight projections):
+        (``query_pos``: added to ``query`` inside the offset / weight projections; ``value``: the already
+        projected ``value_proj(input_flatten)`` when the caller computed it ahead of time):
         ``return_sampling=False`` (SOC never reads the sampling locations / weights) allows the fused
         kernel, which needs ``pad_flag`` = int32[1] device tensor "the padding mask has any True"."""
         N, Lq, _ = query.shape
         _, S, _ = input_flatten.shape
         M, L, P = self.n_heads, self.n_levels, self.n_points
-        value = self.value_proj(input_flatten)
+        if value is None:
+            value = self.value_proj(input_flatten)
         offsets_raw, logits_raw = fused.linear_multi(
             query, [(self.sampling_offsets.weight, self.sampling_offsets.bias, True),
                     (self.attention_weights.weight, self.attention_weights.bias, True)], query_pos)
