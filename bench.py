@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="time eager launches instead of hipGraph replay")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="one clip per graph replay (ClipGraph) instead of the software-pipelined PipelinedClipGraph")
     return ap.parse_args()
 
 
@@ -82,19 +84,40 @@ def main():
         return out
 
     graph = None
+    pipelined = False
     if not a.eager:
-        from neurips2023_soc_amd.graph_runner import ClipGraph
-        try:
-            graph = ClipGraph(model, T, H, Wd, L, dev)   # one capture, replayed per clip
-        except Exception as exc:  # capture is an optimisation: never let it take the benchmark down
+        from neurips2023_soc_amd.graph_runner import ClipGraph, PipelinedClipGraph
+        try:   # capture is an optimisation: never let it take the benchmark down
+            if not a.no_pipeline:
+                graph = PipelinedClipGraph(model, T, H, Wd, L, dev)   # tail of clip i beside the head of clip i+1
+                pipelined = True
+            else:
+                graph = ClipGraph(model, T, H, Wd, L, dev)            # one capture, replayed per clip
+        except Exception as exc:
             print(f"[bench] hipGraph capture failed ({type(exc).__name__}: {exc}); timing eager launches",
                   file=sys.stderr, flush=True)
             torch.cuda.synchronize()
-            graph = None
+            graph, pipelined = None, False
 
     def gstep(i, record):
         graph.run(clips[i % n_pool], text["input_ids"])
         record.copy_(graph.record, non_blocking=True)
+
+    def run_steps(n, out):
+        """n clips through the chosen path, results into out[i % len(out)]."""
+        m = out.shape[0]
+        if graph is None:
+            for i in range(n):
+                step(i, out[i % m])
+        elif not pipelined:
+            for i in range(n):
+                gstep(i, out[i % m])
+        else:   # software pipeline: replay i returns clip i-1's record; the last one comes from flush()
+            for i in range(n):
+                if graph.run(clips[i % n_pool], text["input_ids"]) is not None:
+                    out[(i - 1) % m].copy_(graph.record, non_blocking=True)
+            if n and graph.flush() is not None:
+                out[(n - 1) % m].copy_(graph.record, non_blocking=True)
 
     def fence():
         torch.cuda.synchronize()
@@ -102,9 +125,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    run = gstep if graph is not None else step
-    for i in range(a.warmup):
-        run(i, results[0])
+    run_steps(a.warmup, results)
     if use_dist:
         CP.gather_results(results)  # RCCL warm-up, outside the timed region
 
@@ -112,8 +133,7 @@ def main():
     if graph is None:
         hot_ops.profile_begin()
     t0 = time.perf_counter()
-    for i in range(a.steps):
-        run(i, results[i])
+    run_steps(a.steps, results)          # exactly K clips, pipeline drained inside the timed region
     gathered = CP.gather_results(results)
     torch.cuda.synchronize()
     if use_dist:
@@ -150,7 +170,9 @@ def main():
             "config": {"workload": f"SOC eval forward + query selection, {a.backbone}, T={T}, {H}x{Wd}, B=1, "
                                    f"L={L} tokens, random deterministic weights (seed {WEIGHT_SEED})",
                        "clips_per_rank": a.steps, "parallelism": f"clip-parallel x{world}, one result all_gather",
-                       "launch": "eager" if graph is None else "hipGraph replay (one graph per clip geometry)"},
+                       "launch": "eager" if graph is None else (
+                           "hipGraph replay, software-pipelined: tail of clip i beside the head of clip i+1"
+                           if pipelined else "hipGraph replay (one graph per clip geometry)")},
         }
         # HBM bytes per clip from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE collected
         # separately and corrected as MI355X_MICROARCH.md prescribes): profiles/r01_hbm_traffic_pmc.json

@@ -192,7 +192,7 @@ class DeformableTransformer(nn.Module):
             }
         return cache[key]
 
-    def encode(self, srcs, masks, pos_embeds, token_major=False, unpadded=False):
+    def encode(self, srcs, masks, pos_embeds, token_major=False, unpadded=False, maps=True):
         """Flatten the levels and run the deformable encoder.  Returns (memory maps of the 3 finest
         levels as '(b t) c h w', context for decode()).  Split from forward() so that SOC can run the
         FPN spatial decoder (needs only the maps) concurrently with the query decoder.
@@ -216,16 +216,22 @@ class DeformableTransformer(nn.Module):
             ref = None
         memory = self.encoder(src, spatial_shapes, level_start, ratios, pos, mask, shapes_list=shapes,
                               pad_flag=pad_flag, reference_points=ref)
+        ctx = (memory, spatial_shapes, level_start, ratios, mask, pad_flag, tuple(shapes))
+        return (self.memory_maps(ctx) if maps else None), ctx
+
+    def memory_maps(self, ctx):
+        """The encoder output of the 3 finest levels as '(b t) c h w' maps (what the FPN spatial decoder reads)."""
+        memory, shapes = ctx[0], ctx[6]
         n, _, c = memory.shape
         maps, at = [], 0
         for (h, w) in shapes[:self.num_feature_level - 1]:
             maps.append(memory[:, at:at + h * w].reshape(n, h, w, c).permute(0, 3, 1, 2).contiguous())
             at += h * w
-        return maps, (memory, spatial_shapes, level_start, ratios, mask, pad_flag)
+        return maps
 
     def decode(self, ctx, tgt, query_embed, values=None):
         """tgt [b,t,q,c], query_embed [q,c] -> hs [l,(b t),q,c], init_ref [(b t),q,2], inter_refs [l,(b t),q,4]"""
-        memory, spatial_shapes, level_start, ratios, mask, pad_flag = ctx
+        memory, spatial_shapes, level_start, ratios, mask, pad_flag = ctx[:6]
         b, t, q, c = tgt.shape
         tgt = tgt.reshape(b * t, q, c)
         qpos = query_embed.unsqueeze(0).expand(b * t, -1, -1)

@@ -210,6 +210,12 @@ class SOC(nn.Module):
         targets[0][b]['size'] = (H,W) of the model input.  Returns the reference's output dict:
         pred_masks [T,B,Q,H/4,W/4], pred_cls [T,B,Q,K], pred_boxes [T,B,Q,4], pred_logit [B,Q,C],
         text_sentence_feature [B,C], aux_outputs []."""
+        return self.forward_tail(self.forward_head(samples, valid_indices, text_queries), targets)
+
+    @torch.no_grad()
+    def forward_head(self, samples: NestedTensor, valid_indices, text_queries):
+        """First part of forward: text encoder ‖ Video-Swin, vision-language fusion, deformable encoder.  Returns the
+        state forward_tail needs; graph_runner.PipelinedClipGraph runs the tail of clip i beside the head of clip i+1."""
         if self.training:
             raise RuntimeError("this build of SOC is inference-only: call model.eval()")
         if valid_indices is not None:
@@ -276,16 +282,28 @@ class SOC(nn.Module):
         masks = [p[1] for p in per_level]
         poses = [p[2] for p in per_level]
         lang_last = next(p[3] for p in per_level if p[3] is not None)
+        _, ctx = self.transformer.encode(srcs, masks, poses, token_major=True, unpadded=unpadded, maps=False)
+        return {"ctx": ctx, "feats0": backbone_out[0].tensors, "lang_last": lang_last, "word_pad": word_pad,
+                "sentence": sentence, "B": B, "T": T}
 
+    @torch.no_grad()
+    def forward_tail(self, state, targets, fork: bool = True):
+        """Second part of forward: FPN spatial decoder ‖ query decoder -> VOC -> heads, dynamic mask head.
+        ``fork=False`` keeps everything on the calling stream (used when the caller already runs the tail beside
+        another clip's head)."""
+        ctx, feats0, lang_last = state["ctx"], state["feats0"], state["lang_last"]
+        word_pad, sentence, B, T = state["word_pad"], state["sentence"], state["B"], state["T"]
+        device = feats0.device
         Q = self.num_queries
-        tgt = words.new_zeros(B, T, Q, words.shape[-1])
-        memory, ctx = self.transformer.encode(srcs, masks, poses, token_major=True, unpadded=unpadded)
+        tgt = lang_last.new_zeros(B, T, Q, lang_last.shape[-1])
+        memory = self.transformer.memory_maps(ctx)
 
-        # Fork again: the FPN spatial decoder (convs over the memory maps) only meets the query branch
-        # (decoder -> VOC -> heads -> controller, ~250 small latency-bound launches) at the dynamic
-        # mask head, so it runs on the side stream meanwhile.
-        feats0 = backbone_out[0].tensors
+        # The FPN spatial decoder (convs over the memory maps) only meets the query branch (decoder -> VOC ->
+        # heads -> controller, ~150 small latency-bound launches) at the dynamic mask head, so it runs on the
+        # side stream meanwhile.
+        side = self._side_stream(device) if (device.type == "cuda" and fork) else None
         if side is not None:
+            main = torch.cuda.current_stream(device)
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 fpn = self.spatial_decoder(memory[-1], [memory[1], memory[0], feats0])  # '(b t) 8 h/4 w/4'

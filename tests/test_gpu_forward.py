@@ -205,3 +205,32 @@ def test_clip_inferencer_pads_expressions_for_graph_reuse(gpu_model, golden):
         assert maxdiff(b["mask_logits"], a["mask_logits"].cpu()) < 1e-4
         assert float((a["masks"] != b["masks"]).float().mean()) < 1e-4
     assert len(graphs._graphs) == 1
+
+
+def test_pipelined_graph_matches_plain_graph(gpu_model):
+    """PipelinedClipGraph (tail of clip i beside the head of clip i+1) returns ClipGraph's records, one call late."""
+    from neurips2023_soc_amd.graph_runner import ClipGraph, PipelinedClipGraph
+    T, H, Wd, L = 3, 96, 128, 6
+    clips = [W.synthetic_clip(40 + i, T, H, Wd).cuda() for i in range(5)]
+    ids = [W.synthetic_token_ids(40 + i, L).cuda() for i in range(5)]
+    plain = ClipGraph(gpu_model, T, H, Wd, L, "cuda")
+    want = []
+    for c, t in zip(clips, ids):
+        plain.run(c, t)
+        want.append(plain.record.clone())
+    pipe = PipelinedClipGraph(gpu_model, T, H, Wd, L, "cuda")
+    assert pipe.flush() is None
+    got = []
+    for c, t in zip(clips, ids):
+        r = pipe.run(c, t)
+        if r is not None:
+            got.append(r.clone())
+    got.append(pipe.flush().clone())
+    assert pipe.flush() is None and len(got) == len(want)
+    for a, b in zip(got, want):
+        assert int(a[0]) == int(b[0])                       # selected query
+        assert maxdiff(a, b.cpu()) < 1e-4
+    # a second round through the same graphs (state buffers reused) gives the same answers
+    again = [pipe.run(c, t) is not None and pipe.record.clone() for c, t in zip(clips, ids)][1:] + [pipe.flush().clone()]
+    for a, b in zip(again, want):
+        assert maxdiff(a, b.cpu()) < 1e-4
