@@ -112,12 +112,16 @@ def main():
         elif not pipelined:
             for i in range(n):
                 gstep(i, out[i % m])
-        else:   # software pipeline: replay i returns clip i-1's record; the last one comes from flush()
+        else:   # software pipeline: a replay returns the record of an earlier clip; flush() drains the rest
+            done = 0
             for i in range(n):
                 if graph.run(clips[i % n_pool], text["input_ids"]) is not None:
-                    out[(i - 1) % m].copy_(graph.record, non_blocking=True)
-            if n and graph.flush() is not None:
-                out[(n - 1) % m].copy_(graph.record, non_blocking=True)
+                    out[done % m].copy_(graph.record, non_blocking=True)
+                    done += 1
+            for rec in graph.flush():
+                out[done % m].copy_(rec, non_blocking=True)
+                done += 1
+            assert done == n
 
     def fence():
         torch.cuda.synchronize()

@@ -67,20 +67,27 @@ class ClipGraph:
 
 
 class PipelinedClipGraph:
-    """Two clips in flight inside ONE stream of graph replays: graph k runs the TAIL of the previous clip (FPN,
-    query decoder, VOC, heads, mask head, selection -- ~150 short, latency-bound launches that leave most of the GPU
-    idle) on a side branch while the HEAD of the next clip (text ‖ Video-Swin, fusion, deformable encoder -- chip-
-    filling kernels) runs on the main branch.  The head hands over through a double-buffered static state (encoder
-    memory, stride-4 backbone map, text features), so graphs 0 / 1 alternate and are never replayed concurrently
-    (concurrent replays hang on this stack, tools/experiments/README.md).  Results are those of ClipGraph: same
-    kernels, same order inside each clip; only which clip's kernels share the GPU changes.
+    """Several clips in flight inside ONE stream of graph replays (software pipeline across clips).
 
-        for clip in clips:  prev = g.run(clip, ids)      # -> packed record of the PREVIOUS clip (None at first)
-        last = g.flush()                                  # -> record of the last clip
+    depth 2: graph k runs the TAIL of the previous clip (FPN, query decoder, VOC, heads, mask head, selection --
+    ~150 short, latency-bound launches that leave most of the GPU idle) on a side branch while the HEAD of the next
+    clip (text ‖ Video-Swin, fusion, deformable encoder -- chip-filling kernels) runs on the main branch.
+    (A depth-3 variant -- Video-Swin of clip i ‖ fusion + encoder of clip i-1 ‖ tail of clip i-2 -- was not faster
+    and hung at the BASELINE size after a few dozen replays; tools/experiments/README.md.  Not offered.)
+    Stages hand over through double-buffered static states, so graphs 0 / 1 alternate and are never replayed
+    concurrently (concurrent replays hang on this stack, tools/experiments/README.md); every side branch forks
+    directly from the capture stream (nested forks crash the capture).  Per clip the kernels and their order are
+    those of ClipGraph; only which clips' kernels share the GPU changes.
+
+        for clip in clips:
+            rec = g.run(clip, ids)        # packed record of the clip submitted depth-1 calls earlier, or None
+        rest = g.flush()                  # list of the remaining depth-1 records (clones)
     """
 
-    def __init__(self, model, T: int, H: int, W: int, L: int, device, warmup: int = 2):
-        self.model, self.T, self.H, self.W, self.L = model, T, H, W, L
+    def __init__(self, model, T: int, H: int, W: int, L: int, device, warmup: int = 2, depth: int = 2):
+        if depth != 2:
+            raise ValueError("only the two-stage pipeline (tail ‖ head) is supported")
+        self.model, self.T, self.H, self.W, self.L, self.depth = model, T, H, W, L, depth
         dev = self.device = torch.device(device)
         self.clip = torch.zeros(T, 1, 3, H, W, device=dev)
         self.pad = torch.zeros(T, 1, H, W, dtype=torch.bool, device=dev)
@@ -93,63 +100,103 @@ class PipelinedClipGraph:
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
-            for _ in range(warmup):
-                st = self._head()
-                self._tail(st)
-            # static, double-buffered hand-over state (only what changes from clip to clip; geometry constants
-            # inside ctx are shared)
-            self.state = [self._clone_state(st), self._clone_state(st)]
+            for _ in range(max(warmup, 1)):
+                sa = self._stage_a()
+                sb = self._stage_b(sa, fork=False)
+                self._stage_c(sb, fork=False)
+            # static, double-buffered hand-over states (only what changes from clip to clip is copied; geometry
+            # constants are shared)
+            self.sa = [self._clone(sa, self._VARY_A), self._clone(sa, self._VARY_A)]
+            self.sb = [self._clone(sb, self._VARY_B), self._clone(sb, self._VARY_B)]
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
-        self._pipe = torch.cuda.Stream(device=dev, priority=-1)   # the short tail kernels jump the queue
-        self.graphs, self.tails = [], []
-        for k in (0, 1):
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                cur = torch.cuda.current_stream(dev)
-                self._pipe.wait_stream(cur)
-                with torch.cuda.stream(self._pipe):          # previous clip's tail, beside ...
-                    self._tail(self.state[1 - k], fork=False)
-                self._store_state(self._head(), self.state[k])   # ... this clip's head
-                cur.wait_stream(self._pipe)
-            self.graphs.append(g)
-        for k in (0, 1):
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self._tail(self.state[k])
-            self.tails.append(g)
-        self._k = 0            # graph of the next run()
-        self._pending = False  # a head has run whose tail has not
+        self._pb = torch.cuda.Stream(device=dev)
+        self._pc = torch.cuda.Stream(device=dev)
 
-    # -- pieces ------------------------------------------------------------------------------------------
-    def _head(self):
+        def capture(body):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                body()
+            return g
+
+        def fork_join(branches, main_body):
+            cur = torch.cuda.current_stream(dev)
+            for stream, body in branches:
+                stream.wait_stream(cur)
+                with torch.cuda.stream(stream):
+                    body()
+            main_body()
+            for stream, _ in branches:
+                cur.wait_stream(stream)
+
+        self.steady, self.drain = [], []
+        for k in (0, 1):
+            if depth == 2:    # C(i-1) ‖ [A+B](i)
+                self.steady.append(capture(lambda k=k: fork_join(
+                    [(self._pc, lambda: self._stage_c(self.sb[1 - k], fork=False))],
+                    lambda: self._store(self._stage_b(self._stage_a(), fork=True), self.sb[k], self._VARY_B))))
+                self.drain.append([capture(lambda k=k: self._stage_c(self.sb[k], fork=True))])
+            else:             # C(i-2) ‖ B(i-1) ‖ A(i)
+                self.steady.append(capture(lambda k=k: fork_join(
+                    [(self._pc, lambda: self._stage_c(self.sb[1 - k], fork=False)),
+                     (self._pb, lambda: self._store(self._stage_b(self.sa[1 - k], fork=False), self.sb[k], self._VARY_B))],
+                    lambda: self._store(self._stage_a(), self.sa[k], self._VARY_A))))
+                self.drain.append([
+                    capture(lambda k=k: fork_join(
+                        [(self._pc, lambda: self._stage_c(self.sb[1 - k], fork=False))],
+                        lambda: self._store(self._stage_b(self.sa[1 - k], fork=True), self.sb[k], self._VARY_B))),
+                    capture(lambda k=k: self._stage_c(self.sb[k], fork=True))])
+        self._n = 0            # clips submitted since the last flush
+
+    # -- stages ------------------------------------------------------------------------------------------
+    def _stage_a(self):
         samples = NestedTensor(self.clip, self.pad, unpadded=True)
-        return self.model.forward_head(samples, None, {"input_ids": self.ids, "attention_mask": self.attn})
+        return self.model.forward_backbone(samples, None, {"input_ids": self.ids, "attention_mask": self.attn})
 
-    def _tail(self, state, fork: bool = True):
-        out = self.model.forward_tail(state, self.targets, fork=fork)
+    def _stage_b(self, sa, fork: bool):
+        return self.model.forward_fuse_encode(sa, fork=fork)
+
+    def _stage_c(self, sb, fork: bool):
+        out = self.model.forward_tail(sb, self.targets, fork=fork)
         idx, masks = P.select_trajectory(out)
         CP.pack_record(self.record, idx, out["pred_cls"][:, 0, :, 0], masks)
 
-    _VARYING = ("feats0", "lang_last", "word_pad", "sentence")
+    _VARY_A = ("feats", "words", "word_pad", "sentence")
+    _VARY_B = ("ctx", "feats0", "lang_last", "word_pad", "sentence")
 
-    def _clone_state(self, st):
-        new = dict(st)
-        for k in self._VARYING:
-            new[k] = torch.empty_strided(st[k].shape, st[k].stride(), dtype=st[k].dtype, device=st[k].device)
-            new[k].copy_(st[k])
-        new["ctx"] = (st["ctx"][0].clone(),) + tuple(st["ctx"][1:])
+    @staticmethod
+    def _like(t):
+        new = torch.empty_strided(t.shape, t.stride(), dtype=t.dtype, device=t.device)
+        new.copy_(t)
         return new
 
-    def _store_state(self, st, dst):
-        for k in self._VARYING:
-            dst[k].copy_(st[k])
-        dst["ctx"][0].copy_(st["ctx"][0])
+    def _clone(self, st, keys):
+        new = dict(st)
+        for k in keys:
+            v = st[k]
+            if k == "ctx":
+                new[k] = (self._like(v[0]),) + tuple(v[1:])
+            elif isinstance(v, (list, tuple)):
+                new[k] = [self._like(t) for t in v]
+            else:
+                new[k] = self._like(v)
+        return new
+
+    def _store(self, st, dst, keys):
+        for k in keys:
+            v = st[k]
+            if k == "ctx":
+                dst[k][0].copy_(v[0])
+            elif isinstance(v, (list, tuple)):
+                for d, t in zip(dst[k], v):
+                    d.copy_(t)
+            else:
+                dst[k].copy_(v)
 
     # -- driving -----------------------------------------------------------------------------------------
     def run(self, clip: torch.Tensor, ids: Optional[torch.Tensor] = None, attn: Optional[torch.Tensor] = None):
-        """Enqueue `clip`; returns self.record holding the PREVIOUS clip's result once this replay has run
-        (None for the very first clip).  Copy the record out before the next run()."""
+        """Submit `clip`.  Returns self.record if this replay finished the clip submitted depth-1 calls earlier
+        (copy it out before the next call), else None."""
         self.clip.copy_(clip.view(self.clip.shape), non_blocking=True)
         if ids is not None:
             self.ids.copy_(ids.view(self.ids.shape), non_blocking=True)
@@ -157,16 +204,24 @@ class PipelinedClipGraph:
                 self.attn.fill_(1)
             else:
                 self.attn.copy_(attn.view(self.attn.shape), non_blocking=True)
-        had = self._pending
-        self.graphs[self._k].replay()       # tail(state[1-k]) ‖ head -> state[k]
-        self._k ^= 1
-        self._pending = True
-        return self.record if had else None
+        self.steady[self._n % 2].replay()
+        self._n += 1
+        return self.record if self._n >= self.depth else None
 
     def flush(self):
-        """Run the tail of the last enqueued clip; returns self.record (or None if nothing is pending)."""
-        if not self._pending:
-            return None
-        self.tails[self._k ^ 1].replay()
-        self._pending = False
-        return self.record
+        """Drain the pipeline: clones of the records of the clips still in flight (oldest first)."""
+        out = []
+        n, k = self._n, self._n % 2
+        if n == 0:
+            return out
+        if self.depth == 2:
+            self.drain[k ^ 1][0].replay()            # the last head wrote sb[(n-1) % 2]
+            out.append(self.record.clone())
+        else:
+            self.drain[k][0].replay()                # C(sb[1-k]) = clip n-2  ‖  B(sa[1-k]) = clip n-1 -> sb[k]
+            if n >= 2:
+                out.append(self.record.clone())
+            self.drain[k][1].replay()                # C(sb[k]) = clip n-1
+            out.append(self.record.clone())
+        self._n = 0
+        return out

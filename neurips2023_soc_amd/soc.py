@@ -216,6 +216,11 @@ class SOC(nn.Module):
     def forward_head(self, samples: NestedTensor, valid_indices, text_queries):
         """First part of forward: text encoder ‖ Video-Swin, vision-language fusion, deformable encoder.  Returns the
         state forward_tail needs; graph_runner.PipelinedClipGraph runs the tail of clip i beside the head of clip i+1."""
+        return self.forward_fuse_encode(self.forward_backbone(samples, valid_indices, text_queries))
+
+    @torch.no_grad()
+    def forward_backbone(self, samples: NestedTensor, valid_indices, text_queries, fork: bool = True):
+        """Stage A: RoBERTa ‖ Video-Swin.  -> state for forward_fuse_encode."""
         if self.training:
             raise RuntimeError("this build of SOC is inference-only: call model.eval()")
         if valid_indices is not None:
@@ -225,7 +230,7 @@ class SOC(nn.Module):
         # The text branch (RoBERTa: ~150 latency-bound launches on 10 tokens) and the video backbone
         # are independent until the first vision-language fusion: run them on two HIP streams so the
         # small text kernels hide under the Swin kernels (also captured as a fork/join in ClipGraph).
-        side = self._side_stream(device) if device.type == "cuda" else None
+        side = self._side_stream(device) if (device.type == "cuda" and fork) else None
         if side is not None:
             main = torch.cuda.current_stream(device)
             side.wait_stream(main)
@@ -237,22 +242,32 @@ class SOC(nn.Module):
             text, sentence = self.forward_text(text_queries, device)
             backbone_out, pos = self.backbone(samples)
         words, word_pad = text.decompose()
+        return {"feats": [f.tensors for f in backbone_out], "masks": [f.mask for f in backbone_out], "pos": pos,
+                "words": words, "word_pad": word_pad, "sentence": sentence, "sample_mask": samples.mask,
+                "unpadded": bool(getattr(samples, "unpadded", False))}
+
+    @torch.no_grad()
+    def forward_fuse_encode(self, sa, fork: bool = True):
+        """Stage B: input_proj + vision-language fusion of every level, deformable encoder.  -> state for forward_tail."""
+        feats, fmasks, pos = sa["feats"], sa["masks"], sa["pos"]
+        words, word_pad, sentence, unpadded = sa["words"], sa["word_pad"], sa["sentence"], sa["unpadded"]
+        device = words.device
+        side = self._side_stream(device) if (device.type == "cuda" and fork) else None
+        main = torch.cuda.current_stream(device) if side is not None else None
         B = words.shape[1]
         T = pos[-1].shape[0] // B
-        text_pos = self.text_pos(text).permute(2, 0, 1)
+        text_pos = self.text_pos(NestedTensor(words, word_pad)).permute(2, 0, 1)
 
-        levels = list(zip(backbone_out[-3:], pos[-3:]))
+        levels = list(zip(feats[-3:], fmasks[-3:], pos[-3:]))
         n_levels = self.num_feature_levels
         if n_levels > len(levels) + 1:
             raise NotImplementedError("more than one extra feature level is not used by any shipped config")
-        unpadded = bool(getattr(samples, "unpadded", False))
 
         def fuse_level(l):
             """input_proj + vision<-language fusion of level l -> (tokens '(b t) (h w) c', mask, pos, lang | None)"""
             lang = None
             if l < len(levels):
-                feat, pos_l = levels[l]
-                src, mask = feat.decompose()
+                src, mask, pos_l = levels[l]
                 h, w = src.shape[-2:]
                 seq = self._project_level(l, src, B, T)
                 if l == len(levels) - 1:  # only langs[-1] is read downstream
@@ -260,8 +275,8 @@ class SOC(nn.Module):
                                     memory_key_padding_mask=mask.view(B, T, h, w).reshape(B, -1),
                                     pos=self._seq(pos_l, B, T))
             else:                          # the extra level: 3x3 / stride-2 conv of the coarsest backbone map
-                src = self.input_proj[l](backbone_out[-1].tensors)
-                mask = resize_pad_mask(samples.mask, src.shape[-2:])
+                src = self.input_proj[l](feats[-1])
+                mask = resize_pad_mask(sa["sample_mask"], src.shape[-2:])
                 pos_l = self.backbone.position_encoding(NestedTensor(src, mask), unpadded)
                 h, w = src.shape[-2:]
                 seq = self._seq(src, B, T)
@@ -283,7 +298,7 @@ class SOC(nn.Module):
         poses = [p[2] for p in per_level]
         lang_last = next(p[3] for p in per_level if p[3] is not None)
         _, ctx = self.transformer.encode(srcs, masks, poses, token_major=True, unpadded=unpadded, maps=False)
-        return {"ctx": ctx, "feats0": backbone_out[0].tensors, "lang_last": lang_last, "word_pad": word_pad,
+        return {"ctx": ctx, "feats0": feats[0], "lang_last": lang_last, "word_pad": word_pad,
                 "sentence": sentence, "B": B, "T": T}
 
     @torch.no_grad()

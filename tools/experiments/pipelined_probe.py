@@ -22,16 +22,17 @@ for c in clips:
     g.run(c, ids)
     ref.append(g.record.clone())
 print("plain graph ok", flush=True)
-pg = PipelinedClipGraph(model, T, H, Wd, 10, "cuda")
-print("pipelined graphs captured", flush=True)
+DEPTH = int(sys.argv[4]) if len(sys.argv) > 4 else 2
+pg = PipelinedClipGraph(model, T, H, Wd, 10, "cuda", depth=DEPTH)
+print(f"pipelined graphs captured (depth {DEPTH})", flush=True)
 got = []
 for c in clips:
     r = pg.run(c, ids)
     if r is not None:
         got.append(r.clone())
-got.append(pg.flush().clone())
+got += pg.flush()
 torch.cuda.synchronize()
-print("max |record diff| per clip:", [float((a - b).abs().max()) for a, b in zip(got, ref)], flush=True)
+print("max |record diff| per clip:", [float((a - b).abs().max()) for a, b in zip(got, ref)], len(got), flush=True)
 for name, fn, fl in (("plain", lambda c: g.run(c, ids), None), ("pipelined", lambda c: pg.run(c, ids), pg.flush)):
     for n in (8, 40):
         torch.cuda.synchronize()
