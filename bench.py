@@ -1,7 +1,11 @@
 #!/usr/bin/env python
 """Headline benchmark: clips/s of SOC's per-clip inference hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 without an outer launcher: this process starts N ranks itself (one per GPU, before it touches the GPU,
+clip_parallel.spawn_ranks = the reference's mp.Process fan-out, infer_refytb.py:84-109) and only waits; under
+`python -m torch.distributed.run --nproc-per-node N` the ranks already exist and WORLD_SIZE must equal --gpus.
 
 A step = one eval forward of Video-Swin-T SOC on one synthetic clip [T=8,3,360,640] (random
 deterministic weights, pre-tokenised 10-token expression) + query selection, i.e. the body of
@@ -44,21 +48,44 @@ def parse():
     return ap.parse_args()
 
 
+def _cpu_topology():
+    """(physical cores this process may run on, CPU model string) from /proc/cpuinfo."""
+    allowed = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else set(range(os.cpu_count() or 1))
+    cores, model, cpu = set(), "unknown", None
+    phys_id = core_id = None
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f.read().split("\n") + [""]:
+                if ln.startswith("processor"):
+                    cpu = int(ln.split(":")[1])
+                elif ln.startswith("model name") and model == "unknown":
+                    model = ln.split(":", 1)[1].strip()
+                elif ln.startswith("physical id"):
+                    phys_id = int(ln.split(":")[1])
+                elif ln.startswith("core id"):
+                    core_id = int(ln.split(":")[1])
+                elif not ln.strip() and cpu is not None:
+                    if cpu in allowed:
+                        cores.add((phys_id, core_id if core_id is not None else cpu))
+                    cpu = phys_id = core_id = None
+    except OSError:
+        pass
+    return max(len(cores), 1), model
+
+
 def main():
     a = parse()
-    rank = int(os.environ.get("RANK", 0))
-    local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
+    from neurips2023_soc_amd import clip_parallel as CP
+    if a.gpus > 1 and not CP.launched_as_rank():
+        # fan out BEFORE any GPU call in this process; the parent never execs, it waits and relays the exit code
+        return CP.spawn_ranks(a.gpus, [sys.executable, os.path.abspath(__file__), *sys.argv[1:]])
     assert torch.cuda.is_available(), "bench.py measures the HIP path; it needs an MI355X"
-    torch.cuda.set_device(local_rank)
+    rank, local_rank, world = CP.init_rank("cuda", expect_world=a.gpus)   # "nccl" is RCCL on ROCm
     dev = torch.device("cuda", local_rank)
-    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)  # launched by torchrun
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+    use_dist = dist.is_initialized()
 
     import neurips2023_soc_amd as S
-    from neurips2023_soc_amd import clip_parallel as CP, hot_ops, postprocessing as P, weights as W
+    from neurips2023_soc_amd import hot_ops, postprocessing as P, weights as W
 
     model, _, _ = S.build_model(S.default_args(a.backbone, text_encoder_random_init=True))
     sd = W.load_synthetic(model, WEIGHT_SEED)
@@ -87,17 +114,12 @@ def main():
     pipelined = False
     if not a.eager:
         from neurips2023_soc_amd.graph_runner import ClipGraph, PipelinedClipGraph
-        try:   # capture is an optimisation: never let it take the benchmark down
-            if not a.no_pipeline:
-                graph = PipelinedClipGraph(model, T, H, Wd, L, dev)   # tail of clip i beside the head of clip i+1
-                pipelined = True
-            else:
-                graph = ClipGraph(model, T, H, Wd, L, dev)            # one capture, replayed per clip
-        except Exception as exc:
-            print(f"[bench] hipGraph capture failed ({type(exc).__name__}: {exc}); timing eager launches",
-                  file=sys.stderr, flush=True)
-            torch.cuda.synchronize()
-            graph, pipelined = None, False
+        # a failed capture fails the run: the headline is the graph replay, never a silent eager timing
+        if not a.no_pipeline:
+            graph = PipelinedClipGraph(model, T, H, Wd, L, dev)   # tail of clip i beside the head of clip i+1
+            pipelined = True
+        else:
+            graph = ClipGraph(model, T, H, Wd, L, dev)            # one capture, replayed per clip
 
     def gstep(i, record):
         graph.run(clips[i % n_pool], text["input_ids"])
@@ -123,27 +145,18 @@ def main():
                 done += 1
             assert done == n
 
-    def fence():
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     run_steps(a.warmup, results)
     if use_dist:
         CP.gather_results(results)  # RCCL warm-up, outside the timed region
+    torch.cuda.synchronize()
+    results.zero_()                 # what is checked below can only have been written by the timed region
 
-    fence()
     if graph is None:
         hot_ops.profile_begin()
-    t0 = time.perf_counter()
-    run_steps(a.steps, results)          # exactly K clips, pipeline drained inside the timed region
-    gathered = CP.gather_results(results)
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    # barrier + sync | exactly K clips (pipeline drained) + the one result all_gather | barrier + sync; max over ranks
+    timed = CP.timed_sharded_run(lambda out: run_steps(a.steps, out), results, dev)
+    gathered, dt = timed["gathered"], timed["seconds"]
+    timed_records = results[:min(a.steps, n_pool)].cpu()      # clip i of the pool <-> record i
     if graph is None:
         prof = hot_ops.profile_end()
     else:
@@ -158,17 +171,14 @@ def main():
             step(i, results[i])
         prof = hot_ops.profile_end()
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if use_dist:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
-    assert gathered.shape[0] == world
+    assert gathered.shape[0] == world == a.gpus and timed["ranks_seen"] == list(range(world)), timed["ranks_seen"]
 
     if rank == 0:
         line = {
             "metric": "clips/s (T=8, 360x640, Video-Swin-T)" if (a.backbone, T, H, Wd) == ("video-swin-t", 8, 360, 640)
                       else f"clips/s (T={T}, {H}x{Wd}, {a.backbone})",
-            "value": world * a.steps / dt, "unit": "clips/s", "n_gpus": world, "steps": a.steps,
+            "value": world * a.steps / dt, "unit": "clips/s", "n_gpus": world, "ranks_seen": timed["ranks_seen"],
+            "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"SOC eval forward + query selection, {a.backbone}, T={T}, {H}x{Wd}, B=1, "
@@ -213,47 +223,87 @@ def main():
         line["kernel_ms_per_clip"] = {name: {"launches_per_clip": r["launches"] / a.steps, "ms": r["ms"] / a.steps}
                                       for name, r in sorted(prof.items())}
 
+        golden_path = os.path.join(ROOT, "tests", "golden", "full_forward.npz")
+        if default_cfg and os.path.exists(golden_path):
+            # What the timed region itself produced: record 0 of rank 0 is pool clip 0 = seed 1 = the clip of the
+            # reference-generated golden tests/golden/full_forward.npz (committed data, not /root/reference).
+            import numpy as np
+            with np.load(golden_path) as z:
+                g = {k: z[k] for k in ("selected_query", "selected_masks", "pred_cls")}
+            q, cls, masks = CP.unpack_record(timed_records[0], T, Q, hm, wm)
+            want = torch.from_numpy(g["selected_masks"]).reshape(T, hm, wm)
+            flip = (masks > 0) != (want > 0)
+            line["parity"] = {
+                "timed_path_checked": "record 0 of the timed region vs tests/golden/full_forward.npz (reference output)",
+                "timed_path_selected_query": q, "timed_path_selected_query_ref": int(g["selected_query"]),
+                "timed_path_mask_logit_max_abs_diff": float((masks - want).abs().max()),
+                "timed_path_pred_cls_max_abs_diff": float((cls - torch.from_numpy(g["pred_cls"]).reshape(T, Q)).abs().max()),
+                "timed_path_thresholded_mask_flips": int(flip.sum()),
+                "timed_path_max_abs_ref_logit_at_flips": float(want[flip].abs().max()) if bool(flip.any()) else 0.0,
+                "timed_path_pixels": flip.numel(),
+                "flip_window": "a thresholded pixel may differ only where |reference logit| < 1e-4 "
+                               "(reference 1-vs-8-thread self-noise: 6e-5 at this logit scale)"}
+            assert q == int(g["selected_query"]) and line["parity"]["timed_path_mask_logit_max_abs_diff"] < 1e-3, \
+                line["parity"]
+            assert line["parity"]["timed_path_max_abs_ref_logit_at_flips"] < 1e-4, line["parity"]
+            # the records of clips 1..3 have no reference golden; they must at least be finite and distinct
+            assert bool(torch.isfinite(timed_records).all())
+
         if world == 1 and not a.no_cpu_baseline:
             from oracle import soc_oracle as O
             enc = O.build_text_encoder(sd)
             ones = torch.ones_like(ids_cpu)
-            # pick the intra-op thread count on a small proxy clip (T=3, 250x300): more threads than
-            # the pod really owns makes torch-CPU dramatically slower (256 threads: 373 s/clip)
             avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            phys, model_name = _cpu_topology()
             proxy = W.synthetic_clip(7, 3, 250, 300)
-            best_n, best_t = 1, float("inf")
-            for n in (8, 16, 32, 64):
-                if n > avail:
-                    break
-                torch.set_num_threads(n)
-                t1 = time.perf_counter()
-                O.soc_forward(sd, proxy, ids_cpu, ones, (250, 300), backbone=a.backbone, text_encoder=enc)
-                t = time.perf_counter() - t1
-                if t < best_t:
-                    best_n, best_t = n, t
-                if t > 1.5 * best_t:
-                    break
-            torch.set_num_threads(best_n)
-            t1 = time.perf_counter()
-            ref = O.soc_forward(sd, clips_cpu[0], ids_cpu, ones, (H, Wd), backbone=a.backbone, text_encoder=enc)
-            cpu_s = time.perf_counter() - t1
-            line["cpu_baseline"] = {"value": 1.0 / cpu_s, "unit": "clips/s", "cores": best_n, "kind": "port",
-                                    "sample": "1 forward of the same workload (oracle/soc_oracle.py, torch-CPU "
-                                              f"fp32); thread count chosen on a T=3 250x300 proxy among 8..64 "
-                                              f"(host exposes {avail} logical CPUs)"}
+
+            def timed_forwards(n_threads, clip, size, reps):
+                torch.set_num_threads(n_threads)
+                ts, ref = [], None
+                for r in range(reps + 1):       # first one is the warm-up
+                    t1 = time.perf_counter()
+                    ref = O.soc_forward(sd, clip, ids_cpu, ones, size, backbone=a.backbone, text_encoder=enc)
+                    ts.append(time.perf_counter() - t1)
+                ts = sorted(ts[1:])
+                return ts[len(ts) // 2], ref
+
+            runs, ref, best = [], None, None
+            proxy8 = None
+            for n in sorted({min(8, avail), min(phys, avail)}):
+                tp, _ = timed_forwards(n, proxy, (250, 300), 1)
+                proxy8 = proxy8 or tp
+                entry = {"threads": n, "proxy_T3_250x300_s": tp}
+                # the pod may expose far more logical CPUs than its cgroup grants (256 threads: 373 s per clip in
+                # round 1): a thread count whose small proxy is already >2x slower than 8 threads is not run at size
+                if tp <= 2.0 * proxy8:
+                    med, ref = timed_forwards(n, clips_cpu[0], (H, Wd), 3)
+                    entry.update(seconds_per_clip_median_of_3=med, clips_per_s=1.0 / med)
+                    if best is None or med < best[1]:
+                        best = (n, med)
+                else:
+                    entry["skipped"] = "oversubscribed: proxy > 2x the 8-thread proxy"
+                runs.append(entry)
+            line["cpu_baseline"] = {"value": 1.0 / best[1], "unit": "clips/s", "cores": best[0], "kind": "port",
+                                    "cpu_model": model_name, "physical_cores_visible": phys, "logical_cpus": avail,
+                                    "runs": runs,
+                                    "sample": "same workload (oracle/soc_oracle.py, torch-CPU fp32): 1 warm-up + 3 timed "
+                                              "forwards, median, at 8 threads and at the physical-core count"}
+            d = (timed_records[0][1 + T * Q:].view(T, hm, wm) - P.select_trajectory(ref)[1]).abs().max().item()
+            line.setdefault("parity", {})["timed_path_mask_logit_max_abs_diff_vs_cpu_oracle"] = d
             got = step(0)
             torch.cuda.synchronize()
             d = (got["pred_masks"].cpu() - ref["pred_masks"]).abs().max().item()
             flip = (got["pred_masks"].cpu() > 0) != (ref["pred_masks"] > 0)
-            line["parity"] = {"mask_logit_max_abs_diff_vs_cpu_oracle": d,
-                              "max_abs_logit": ref["pred_masks"].abs().max().item(),
-                              "thresholded_mask_flips": int(flip.sum()),
-                              "max_abs_ref_logit_at_flips": float(ref["pred_masks"][flip].abs().max()) if bool(flip.any()) else 0.0,
-                              "pixels": flip.numel()}
+            line["parity"].update({"eager_all_queries_mask_logit_max_abs_diff_vs_cpu_oracle": d,
+                                   "max_abs_logit": ref["pred_masks"].abs().max().item(),
+                                   "eager_all_queries_thresholded_mask_flips": int(flip.sum()),
+                                   "eager_all_queries_max_abs_ref_logit_at_flips":
+                                       float(ref["pred_masks"][flip].abs().max()) if bool(flip.any()) else 0.0,
+                                   "eager_all_queries_pixels": flip.numel()})
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.destroy_process_group()
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

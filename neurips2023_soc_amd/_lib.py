@@ -35,6 +35,15 @@ def load() -> C.CDLL:
         raise SocHipError(
             f"{LIB_PATH} is missing: build it with `python -m neurips2023_soc_amd.build_ext` "
             "(hipcc --offload-arch=gfx950).  The SOC hot path has no CPU/PyTorch fallback.")
+    from . import build_ext
+    if build_ext.stale():
+        # csrc/*.hip or include/*.h are newer than the .so: running it would test / time stale kernels.
+        # Rebuild through a hipcc child process when the compiler is here, otherwise refuse.
+        try:
+            build_ext.build(verbose=False)
+        except Exception as exc:
+            raise SocHipError(f"{LIB_PATH} is older than its sources and could not be rebuilt ({exc}); "
+                              "run `python -m neurips2023_soc_amd.build_ext`") from exc
     lib = C.CDLL(LIB_PATH)
     for name in EXPORTS:
         if not hasattr(lib, name):

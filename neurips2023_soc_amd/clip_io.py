@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import math
 import os
+import threading
 from collections import OrderedDict
 from concurrent.futures import ThreadPoolExecutor
 from typing import Dict, List, Optional, Sequence, Tuple
@@ -89,30 +90,61 @@ def decode_frame(path: str) -> np.ndarray:
         return np.asarray(im.convert("RGB"))
 
 
+class PinnedEntry:
+    """One pinned staging buffer.  Between `PinnedPool.take()` and `release(event)` it belongs to ONE filler
+    (being decoded into / its H2D copy not yet recorded) and is never handed out again."""
+
+    __slots__ = ("tensor", "busy", "in_use")
+
+    def __init__(self, tensor: torch.Tensor):
+        self.tensor, self.busy, self.in_use = tensor, None, True
+
+    def release(self, event=None) -> None:
+        """The H2D copy out of the buffer has been recorded (`event` fires when it has left the buffer)."""
+        self.busy = event
+        self.in_use = False
+
+    def __getitem__(self, i):          # entry[0] -> tensor (read-only convenience)
+        return (self.tensor, self.busy)[i]
+
+
 class PinnedPool:
     """A few reusable pinned staging buffers per clip shape.  Pinning fresh host memory per video costs
     ~9 ms for a 22 MB clip and stalls the GPU queue while it happens (measured: +3 ms per clip at three
-    expressions per video), so buffers are recycled; `busy` is the event after the last H2D copy out of it."""
+    expressions per video), so buffers are recycled.  take() is called from the prefetch thread and from the
+    main thread (cache miss): the ring is guarded by a lock, an entry stays `in_use` from take() until its
+    release(), and a ring whose entries are all in use grows instead of handing one out twice."""
 
     def __init__(self, depth: int = 3):
         self.depth = depth
-        self._bufs: Dict[Tuple[int, ...], List[list]] = {}
+        self._bufs: Dict[Tuple[int, ...], List[PinnedEntry]] = {}
         self._turn: Dict[Tuple[int, ...], int] = {}
+        self._lock = threading.Lock()
 
-    def take(self, shape: Sequence[int]) -> list:
-        """-> [tensor, busy_event_or_None]; waits until the buffer's previous copy has left it"""
+    def take(self, shape: Sequence[int]) -> PinnedEntry:
+        """-> an entry owned by the caller until entry.release(); waits until the buffer's previous copy has left it"""
         key = tuple(int(v) for v in shape)
-        ring = self._bufs.setdefault(key, [])
-        if len(ring) < self.depth:
+        entry = None
+        with self._lock:
+            ring = self._bufs.setdefault(key, [])
+            if len(ring) >= self.depth:
+                turn = self._turn.get(key, 0)
+                for step in range(len(ring)):
+                    cand = ring[(turn + step) % len(ring)]
+                    if not cand.in_use:
+                        cand.in_use = True
+                        self._turn[key] = (turn + step + 1) % len(ring)
+                        entry = cand
+                        break
+        if entry is None:                          # ring not full yet, or every buffer is with a filler
             buf = torch.empty(key, dtype=torch.uint8)
-            ring.append([buf.pin_memory() if torch.cuda.is_available() else buf, None])
-            return ring[-1]
-        turn = self._turn.get(key, 0)
-        self._turn[key] = (turn + 1) % self.depth
-        entry = ring[turn]
-        if entry[1] is not None:
-            entry[1].synchronize()
-            entry[1] = None
+            entry = PinnedEntry(buf.pin_memory() if torch.cuda.is_available() else buf)
+            with self._lock:
+                self._bufs[key].append(entry)
+            return entry
+        if entry.busy is not None:                 # outside the lock: may block on the GPU
+            entry.busy.synchronize()
+            entry.busy = None
         return entry
 
 
@@ -132,7 +164,7 @@ def load_frames(paths: Sequence[str], workers: int = 8, pool: Optional[PinnedPoo
     entry = None
     if pool is not None:
         entry = pool.take((len(arrays), *shape))
-        out = entry[0]
+        out = entry.tensor
     else:
         out = torch.empty((len(arrays), *shape), dtype=torch.uint8)
         if torch.cuda.is_available():
@@ -193,14 +225,16 @@ class VideoClipCache:
         the event the consumer's stream has to wait for."""
         entry = load_frames(paths, self.workers, self._pool)
         if not (torch.cuda.is_available() and self.pre.device.type == "cuda"):
-            return self.pre(entry[0]), None
+            item = self.pre(entry.tensor)
+            entry.release()
+            return item, None
         if self._copy_stream is None:
             self._copy_stream = torch.cuda.Stream(device=self.pre.device)
         with torch.cuda.stream(self._copy_stream):
-            item = self.pre(entry[0])
+            item = self.pre(entry.tensor)
             ready = torch.cuda.Event()
             ready.record()
-        entry[1] = ready                     # the staging buffer may be refilled once this copy has left it
+        entry.release(ready)                 # the staging buffer may be refilled once this copy has left it
         return item, ready
 
     def prefetch(self, paths: Sequence[str]) -> None:
@@ -224,10 +258,12 @@ class VideoClipCache:
                 item[0].record_stream(torch.cuda.current_stream(self.pre.device))
         else:
             entry = load_frames(paths, self.workers, self._pool)
-            item = self.pre(entry[0])
+            item = self.pre(entry.tensor)
+            done = None
             if item[0].is_cuda:
-                entry[1] = torch.cuda.Event()
-                entry[1].record()
+                done = torch.cuda.Event()
+                done.record()
+            entry.release(done)
         self._items[key] = item
         self._bytes += item[0].numel() * 4
         while self._bytes > self.max_bytes and len(self._items) > 1:

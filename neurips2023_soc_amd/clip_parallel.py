@@ -8,7 +8,11 @@ fixed-size per-clip result records at the end (RCCL over xGMI when the backend i
 """
 from __future__ import annotations
 
-from typing import List, Tuple
+import os
+import socket
+import subprocess
+import time
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -52,3 +56,146 @@ def interleave(gathered: torch.Tensor, n_clips: int) -> torch.Tensor:
     """[world, n_local, R] -> [n_clips, R] in original clip order (inverse of shard_clips)."""
     world, n_local, R = gathered.shape
     return gathered.transpose(0, 1).reshape(world * n_local, R)[:n_clips]
+
+
+# ---------------------------------------------------------------------------------------------------
+# process fan-out and the measured rank loop (shared by bench.py, infer.py and the gloo tests)
+# ---------------------------------------------------------------------------------------------------
+
+def free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launched_as_rank() -> bool:
+    """True when an outer launcher (torch.distributed.run, spawn_ranks) already made this process a rank."""
+    return "RANK" in os.environ and "WORLD_SIZE" in os.environ
+
+
+def spawn_ranks(n: int, argv: Sequence[str], extra_env: Optional[Dict[str, str]] = None,
+                timeout: Optional[float] = None) -> int:
+    """Start ``n`` fresh processes running ``argv``, one per GPU, with RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT set -- the reference's ``mp.Process`` fan-out from ``-ng N``
+    (infer_refytb.py:84-109).  The caller must not have touched the GPU yet and is never replaced (no exec):
+    it only waits.  stdout / stderr are inherited, so rank 0's JSON line is the parent's.  If a rank dies the
+    others are terminated (by PID) instead of hanging in a collective.  Returns the worst exit code."""
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this driver (RCCL needs it)
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen(list(argv), env=env))
+    deadline = None if timeout is None else time.monotonic() + timeout
+    worst = 0
+    live = list(procs)
+    while live:
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0:
+                worst = worst or code
+                for q in live:             # a dead rank would leave the others waiting in the all_gather
+                    q.terminate()
+        if live and deadline is not None and time.monotonic() > deadline:
+            for q in live:
+                q.kill()
+            worst = worst or 124
+        if live:
+            time.sleep(0.05)
+    return worst
+
+
+def init_rank(device_type: str = "cuda", expect_world: Optional[int] = None) -> Tuple[int, int, int]:
+    """(rank, local_rank, world) from the launcher's environment; joins the process group when there is one
+    ("nccl" = RCCL over xGMI for GPU ranks, "gloo" for the CPU tests).  ``expect_world`` (the ``--gpus`` /
+    ``-ng`` value) must match WORLD_SIZE: a mismatch fails instead of silently measuring fewer ranks."""
+    rank = int(os.environ.get("RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK", rank))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if expect_world is not None and expect_world != world:
+        raise RuntimeError(f"--gpus {expect_world} but WORLD_SIZE={world}: launch one rank per requested GPU")
+    if world > 1 or "MASTER_PORT" in os.environ:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if device_type == "cuda":
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo")
+    elif device_type == "cuda":
+        torch.cuda.set_device(local)
+    return rank, local, world
+
+
+def _fence(device) -> None:
+    cuda = device is not None and torch.device(device).type == "cuda"
+    if cuda:
+        torch.cuda.synchronize(device)
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+    if cuda:
+        torch.cuda.synchronize(device)
+
+
+def timed_sharded_run(run_local: Callable[[torch.Tensor], None], results: torch.Tensor, device=None) -> Dict:
+    """The measured body of a clip-parallel job: barrier + sync, this rank's clips (``run_local(results)`` fills
+    the [n_local, R] record buffer), the ONE result all_gather, barrier + sync; then the max over ranks of the
+    elapsed time.  Returns {"gathered": [world, n_local, R], "seconds": max over ranks, "ranks_seen": [...]}.
+    ``ranks_seen`` comes out of the collective itself (each rank contributes its id next to its time), so a job
+    that lost a rank cannot report the full world."""
+    rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+    _fence(device)
+    t0 = time.perf_counter()
+    run_local(results)
+    gathered = gather_results(results)
+    _fence(device)
+    dt = time.perf_counter() - t0
+    mine = torch.tensor([[float(rank), dt]], dtype=torch.float64, device=results.device)
+    per_rank = gather_results(mine)[:, 0]                    # [world, 2]
+    return {"gathered": gathered, "seconds": float(per_rank[:, 1].max()),
+            "ranks_seen": sorted(int(r) for r in per_rank[:, 0].tolist()),
+            "seconds_per_rank": [float(v) for v in per_rank[:, 1].tolist()]}
+
+
+def _selftest(argv=None) -> int:
+    """``python -m neurips2023_soc_amd.clip_parallel --gpus N [--device cpu]``: the fan-out + rank loop with a stub
+    clip step (record i = f(clip id)), no model.  Used by the CPU tests (gloo) and as a quick RCCL check."""
+    import argparse
+    import json
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=2)
+    ap.add_argument("--clips", type=int, default=5)
+    ap.add_argument("--device", default="cpu", choices=["cpu", "cuda"])
+    ap.add_argument("--fail-rank", type=int, default=-1, help="this rank exits 3 before the collective (test)")
+    a = ap.parse_args(argv)
+    if a.gpus > 1 and not launched_as_rank():
+        import sys
+        return spawn_ranks(a.gpus, [sys.executable, "-m", "neurips2023_soc_amd.clip_parallel", *(argv or sys.argv[1:])])
+    rank, local, world = init_rank(a.device, expect_world=a.gpus)
+    dev = torch.device("cuda", local) if a.device == "cuda" else torch.device("cpu")
+    if rank == a.fail_rank:
+        os._exit(3)
+    mine = shard_clips(a.clips, rank, world)
+    results = torch.zeros(-(-a.clips // world), 4, device=dev)
+
+    def run_local(out):
+        for slot, cid in enumerate(mine):
+            out[slot] = torch.tensor([cid, cid * cid, rank, 1.0], device=dev)
+
+    res = timed_sharded_run(run_local, results, dev)
+    allr = interleave(res["gathered"], a.clips).cpu()
+    ok = all(allr[i].tolist() == [i, i * i, i % world, 1.0] for i in range(a.clips))
+    if rank == 0:
+        print(json.dumps({"n_gpus": world, "ranks_seen": res["ranks_seen"], "ok": bool(ok), "clips": a.clips}),
+              flush=True)
+    if dist.is_initialized():
+        dist.destroy_process_group()
+    return 0 if ok else 1
+
+
+if __name__ == "__main__":
+    raise SystemExit(_selftest())

@@ -11,3 +11,13 @@ static inline int soc_check_launch() {
 }
 
 static inline int soc_ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+
+// Per-device one-time state (a process may drive several GPUs: clip-parallel ranks are one process per GPU,
+// but nothing in the C ABI forbids a host that switches devices).  Kernel attributes such as
+// hipFuncAttributeMaxDynamicSharedMemorySize are per device, so "done once" must be keyed by the current device.
+#define SOC_MAX_DEVICES 64
+static inline int soc_current_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SOC_MAX_DEVICES) return -1;
+    return dev;
+}

@@ -22,6 +22,7 @@
 #include "soc_common.h"
 #include <math.h>
 #include <stdlib.h>
+#include <atomic>
 
 namespace {
 
@@ -48,7 +49,6 @@ struct WinParams {
     int n_main;          // pairs [0, n_main) get one workgroup each; the tail pairs are split qsplit ways
     int table_len;
     int shifted;
-    int stagger;         // waves 4-7 start their tile loop this many x 512 cycles late
 #ifdef SOC_K1_STAMPS
     unsigned long long* dbg;  // diagnostic build only: [block][wave][32] s_memtime stamps
 #endif
@@ -216,12 +216,6 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_kernel(
     int qsrc_n = -2;
     int qt = qpart * (THREADS / 64) + wave;
     if (qt < p.NT) load_q(qt, qn, qsrc_n);
-    // Optional stagger of the second wave of each SIMD (waves w and w+4 share a SIMD and run the
-    // same program).  Measured null on MI355X for this kernel (SOC_K1_STAGGER=0..24: +-1 %): f32
-    // MFMA and VALU time add up rather than overlap, so de-phasing the partners buys nothing.
-    if (wave >= THREADS / 128)
-        for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(8);
-
     for (; qt < p.NT; qt += nwaves_total) {
         const int qtok = qt * 16 + r;
         const int qsrc = qsrc_n;
@@ -689,14 +683,16 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_full_kernel(
 int launch_full(const float* qkv, const float* qkv_bias, const float* table, float* out,
                 const WinParams& p, long blocks, hipStream_t st) {
     const size_t lds = (size_t)(2536 + FNP * RS + HD * RSV) * sizeof(float) + (2 * FNP + 8) * sizeof(int);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<bool> attr_set[SOC_MAX_DEVICES];   // per device: the attribute is device state
+    const int dev = soc_current_device();
+    if (dev < 0) return SOC_ELAUNCH;
+    if (!attr_set[dev].load(std::memory_order_acquire)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(win_attn3d_full_kernel<false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(win_attn3d_full_kernel<true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return SOC_ELAUNCH;
-        attr_set = true;
+        attr_set[dev].store(true, std::memory_order_release);   // idempotent: a racing thread just sets it again
     }
     if (p.shifted)
         hipLaunchKernelGGL((win_attn3d_full_kernel<true>), dim3((unsigned)blocks), dim3(THREADS), lds, st, qkv,
@@ -713,14 +709,16 @@ int launch_nt(const float* qkv, const float* qkv_bias, const float* table, float
     const size_t lds = (size_t)(2 * NT * 16 * RS + ((p.table_len + 3) & ~3)) * sizeof(float) +
                        (3 * NT * 16 + 8) * sizeof(int);
     if (lds > 160 * 1024) return SOC_EUNSUPPORTED;
-    static bool attr_set = false;  // per instantiation
-    if (!attr_set) {
+    static std::atomic<bool> attr_set[SOC_MAX_DEVICES];   // per instantiation and per device
+    const int dev = soc_current_device();
+    if (dev < 0) return SOC_ELAUNCH;
+    if (!attr_set[dev].load(std::memory_order_acquire)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(win_attn3d_kernel<NT, NT_PREV, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(win_attn3d_kernel<NT, NT_PREV, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return SOC_ELAUNCH;
-        attr_set = true;
+        attr_set[dev].store(true, std::memory_order_release);
     }
     if (p.shifted)
         hipLaunchKernelGGL((win_attn3d_kernel<NT, NT_PREV, true>), dim3((unsigned)blocks), dim3(THREADS), lds, st,
@@ -732,15 +730,16 @@ int launch_nt(const float* qkv, const float* qkv_bias, const float* table, float
 }
 
 int num_cus() {
-    static const int n = [] {
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) {
-            hipDeviceProp_t prop;
-            if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-                cus = prop.multiProcessorCount;
-        }
-        return cus;
-    }();
+    static std::atomic<int> cached[SOC_MAX_DEVICES];      // 0 = not queried yet; per device
+    const int dev = soc_current_device();
+    if (dev < 0) return 256;
+    int n = cached[dev].load(std::memory_order_relaxed);
+    if (n == 0) {
+        n = 256;
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+        cached[dev].store(n, std::memory_order_relaxed);
+    }
     return n;
 }
 
@@ -768,11 +767,6 @@ extern "C" int soc_win_attn3d_f32(const float* qkv, const float* qkv_bias, const
     p.Dp = p.nwd * win_d; p.Hp = p.nwh * win_h; p.Wp = p.nww * win_w;
     p.table_len = (2 * tab_d - 1) * (2 * tab_h - 1) * (2 * tab_w - 1);
     p.shifted = (shift_d | shift_h | shift_w) != 0;
-    static const int stagger_env = [] {
-        const char* e = getenv("SOC_K1_STAGGER");
-        return e ? atoi(e) : 0;
-    }();
-    p.stagger = stagger_env;
 #ifdef SOC_K1_STAMPS
     p.dbg = g_dbg;
     if (!p.dbg) return SOC_EINVAL;
@@ -802,8 +796,7 @@ extern "C" int soc_win_attn3d_f32(const float* qkv, const float* qkv_bias, const
     hipStream_t st = (hipStream_t)stream;
     // key/query tiles are a compile-time constant (fully unrolled MFMA schedule); a window with
     // fewer tokens runs on the next larger instantiation with the surplus keys masked out.
-    static const bool no_full = getenv("SOC_K1_GENERIC") != nullptr;  // A/B switch for the fast path
-    if (!no_full && win_d == 8 && win_h == 7 && win_w == 7 && tab_d == 8 && tab_h == 7 && tab_w == 7)
+    if (win_d == 8 && win_h == 7 && win_w == 7 && tab_d == 8 && tab_h == 7 && tab_w == 7)
         return launch_full(qkv, qkv_bias, bias_table, out, p, blocks, st);
     if (p.NT <= 7) return launch_nt<7, 0>(qkv, qkv_bias, bias_table, out, p, blocks, st);
     if (p.NT <= 10) return launch_nt<10, 7>(qkv, qkv_bias, bias_table, out, p, blocks, st);

@@ -67,27 +67,25 @@ class ClipGraph:
 
 
 class PipelinedClipGraph:
-    """Several clips in flight inside ONE stream of graph replays (software pipeline across clips).
+    """Two clips in flight inside ONE stream of graph replays (software pipeline across clips).
 
-    depth 2: graph k runs the TAIL of the previous clip (FPN, query decoder, VOC, heads, mask head, selection --
-    ~150 short, latency-bound launches that leave most of the GPU idle) on a side branch while the HEAD of the next
-    clip (text ‖ Video-Swin, fusion, deformable encoder -- chip-filling kernels) runs on the main branch.
-    (A depth-3 variant -- Video-Swin of clip i ‖ fusion + encoder of clip i-1 ‖ tail of clip i-2 -- was not faster
-    and hung at the BASELINE size after a few dozen replays; tools/experiments/README.md.  Not offered.)
-    Stages hand over through double-buffered static states, so graphs 0 / 1 alternate and are never replayed
-    concurrently (concurrent replays hang on this stack, tools/experiments/README.md); every side branch forks
-    directly from the capture stream (nested forks crash the capture).  Per clip the kernels and their order are
-    those of ClipGraph; only which clips' kernels share the GPU changes.
+    Graph k runs the TAIL of the previous clip (FPN, query decoder, VOC, heads, mask head, selection -- ~150 short,
+    latency-bound launches that leave most of the GPU idle) on a side branch while the HEAD of the next clip
+    (text ‖ Video-Swin, fusion, deformable encoder -- chip-filling kernels) runs on the main branch.  The head hands
+    over through a double-buffered static state, so graphs 0 / 1 alternate and are never replayed concurrently
+    (concurrent replays hang on this stack, tools/experiments/README.md, which also records the three-stage variant
+    that was tried and dropped); the side branch forks directly from the capture stream.  Per clip the kernels and
+    their order are those of ClipGraph; only which clips' kernels share the GPU changes.
 
         for clip in clips:
-            rec = g.run(clip, ids)        # packed record of the clip submitted depth-1 calls earlier, or None
-        rest = g.flush()                  # list of the remaining depth-1 records (clones)
+            rec = g.run(clip, ids)        # packed record of the clip submitted one call earlier, or None
+        rest = g.flush()                  # list with the record (a clone) of the clip still in flight
     """
 
-    def __init__(self, model, T: int, H: int, W: int, L: int, device, warmup: int = 2, depth: int = 2):
-        if depth != 2:
-            raise ValueError("only the two-stage pipeline (tail ‖ head) is supported")
-        self.model, self.T, self.H, self.W, self.L, self.depth = model, T, H, W, L, depth
+    DEPTH = 2
+
+    def __init__(self, model, T: int, H: int, W: int, L: int, device, warmup: int = 2):
+        self.model, self.T, self.H, self.W, self.L = model, T, H, W, L
         dev = self.device = torch.device(device)
         self.clip = torch.zeros(T, 1, 3, H, W, device=dev)
         self.pad = torch.zeros(T, 1, H, W, dtype=torch.bool, device=dev)
@@ -101,16 +99,13 @@ class PipelinedClipGraph:
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
             for _ in range(max(warmup, 1)):
-                sa = self._stage_a()
-                sb = self._stage_b(sa, fork=False)
-                self._stage_c(sb, fork=False)
-            # static, double-buffered hand-over states (only what changes from clip to clip is copied; geometry
+                sb = self._head(fork=False)
+                self._tail(sb, fork=False)
+            # static, double-buffered hand-over state (only what changes from clip to clip is copied; geometry
             # constants are shared)
-            self.sa = [self._clone(sa, self._VARY_A), self._clone(sa, self._VARY_A)]
-            self.sb = [self._clone(sb, self._VARY_B), self._clone(sb, self._VARY_B)]
+            self.sb = [self._clone(sb), self._clone(sb)]
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
-        self._pb = torch.cuda.Stream(device=dev)
         self._pc = torch.cuda.Stream(device=dev)
 
         def capture(body):
@@ -119,50 +114,30 @@ class PipelinedClipGraph:
                 body()
             return g
 
-        def fork_join(branches, main_body):
+        def tail_beside_head(k):
             cur = torch.cuda.current_stream(dev)
-            for stream, body in branches:
-                stream.wait_stream(cur)
-                with torch.cuda.stream(stream):
-                    body()
-            main_body()
-            for stream, _ in branches:
-                cur.wait_stream(stream)
+            self._pc.wait_stream(cur)
+            with torch.cuda.stream(self._pc):
+                self._tail(self.sb[1 - k], fork=False)          # clip i-1
+            self._store(self._head(fork=True), self.sb[k])      # clip i
+            cur.wait_stream(self._pc)
 
-        self.steady, self.drain = [], []
-        for k in (0, 1):
-            if depth == 2:    # C(i-1) ‖ [A+B](i)
-                self.steady.append(capture(lambda k=k: fork_join(
-                    [(self._pc, lambda: self._stage_c(self.sb[1 - k], fork=False))],
-                    lambda: self._store(self._stage_b(self._stage_a(), fork=True), self.sb[k], self._VARY_B))))
-                self.drain.append([capture(lambda k=k: self._stage_c(self.sb[k], fork=True))])
-            else:             # C(i-2) ‖ B(i-1) ‖ A(i)
-                self.steady.append(capture(lambda k=k: fork_join(
-                    [(self._pc, lambda: self._stage_c(self.sb[1 - k], fork=False)),
-                     (self._pb, lambda: self._store(self._stage_b(self.sa[1 - k], fork=False), self.sb[k], self._VARY_B))],
-                    lambda: self._store(self._stage_a(), self.sa[k], self._VARY_A))))
-                self.drain.append([
-                    capture(lambda k=k: fork_join(
-                        [(self._pc, lambda: self._stage_c(self.sb[1 - k], fork=False))],
-                        lambda: self._store(self._stage_b(self.sa[1 - k], fork=True), self.sb[k], self._VARY_B))),
-                    capture(lambda k=k: self._stage_c(self.sb[k], fork=True))])
+        self.steady = [capture(lambda k=k: tail_beside_head(k)) for k in (0, 1)]
+        self.drain = [capture(lambda k=k: self._tail(self.sb[k], fork=True)) for k in (0, 1)]
         self._n = 0            # clips submitted since the last flush
 
     # -- stages ------------------------------------------------------------------------------------------
-    def _stage_a(self):
+    def _head(self, fork: bool):
         samples = NestedTensor(self.clip, self.pad, unpadded=True)
-        return self.model.forward_backbone(samples, None, {"input_ids": self.ids, "attention_mask": self.attn})
-
-    def _stage_b(self, sa, fork: bool):
+        sa = self.model.forward_backbone(samples, None, {"input_ids": self.ids, "attention_mask": self.attn})
         return self.model.forward_fuse_encode(sa, fork=fork)
 
-    def _stage_c(self, sb, fork: bool):
+    def _tail(self, sb, fork: bool):
         out = self.model.forward_tail(sb, self.targets, fork=fork)
         idx, masks = P.select_trajectory(out)
         CP.pack_record(self.record, idx, out["pred_cls"][:, 0, :, 0], masks)
 
-    _VARY_A = ("feats", "words", "word_pad", "sentence")
-    _VARY_B = ("ctx", "feats0", "lang_last", "word_pad", "sentence")
+    _VARY = ("ctx", "feats0", "lang_last", "word_pad", "sentence")    # what the head hands to the tail per clip
 
     @staticmethod
     def _like(t):
@@ -170,9 +145,9 @@ class PipelinedClipGraph:
         new.copy_(t)
         return new
 
-    def _clone(self, st, keys):
+    def _clone(self, st):
         new = dict(st)
-        for k in keys:
+        for k in self._VARY:
             v = st[k]
             if k == "ctx":
                 new[k] = (self._like(v[0]),) + tuple(v[1:])
@@ -182,8 +157,8 @@ class PipelinedClipGraph:
                 new[k] = self._like(v)
         return new
 
-    def _store(self, st, dst, keys):
-        for k in keys:
+    def _store(self, st, dst):
+        for k in self._VARY:
             v = st[k]
             if k == "ctx":
                 dst[k][0].copy_(v[0])
@@ -195,7 +170,7 @@ class PipelinedClipGraph:
 
     # -- driving -----------------------------------------------------------------------------------------
     def run(self, clip: torch.Tensor, ids: Optional[torch.Tensor] = None, attn: Optional[torch.Tensor] = None):
-        """Submit `clip`.  Returns self.record if this replay finished the clip submitted depth-1 calls earlier
+        """Submit `clip`.  Returns self.record if this replay finished the clip submitted one call earlier
         (copy it out before the next call), else None."""
         self.clip.copy_(clip.view(self.clip.shape), non_blocking=True)
         if ids is not None:
@@ -206,22 +181,12 @@ class PipelinedClipGraph:
                 self.attn.copy_(attn.view(self.attn.shape), non_blocking=True)
         self.steady[self._n % 2].replay()
         self._n += 1
-        return self.record if self._n >= self.depth else None
+        return self.record if self._n >= self.DEPTH else None
 
     def flush(self):
-        """Drain the pipeline: clones of the records of the clips still in flight (oldest first)."""
-        out = []
-        n, k = self._n, self._n % 2
-        if n == 0:
-            return out
-        if self.depth == 2:
-            self.drain[k ^ 1][0].replay()            # the last head wrote sb[(n-1) % 2]
-            out.append(self.record.clone())
-        else:
-            self.drain[k][0].replay()                # C(sb[1-k]) = clip n-2  ‖  B(sa[1-k]) = clip n-1 -> sb[k]
-            if n >= 2:
-                out.append(self.record.clone())
-            self.drain[k][1].replay()                # C(sb[k]) = clip n-1
-            out.append(self.record.clone())
+        """Drain the pipeline: [clone of the record of the clip still in flight] (empty if none)."""
+        if self._n == 0:
+            return []
+        self.drain[(self._n - 1) % 2].replay()       # the last head wrote sb[(n-1) % 2]
         self._n = 0
-        return out
+        return [self.record.clone()]

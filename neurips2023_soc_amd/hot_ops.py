@@ -58,15 +58,25 @@ class _timed:
 
 
 def _need_gpu(*ts: Tensor) -> None:
+    cur = None
     for x in ts:
-        if x is not None and not x.is_cuda:
+        if x is None:
+            continue
+        if not x.is_cuda:
             raise _lib.SocHipError(
                 "SOC hot ops run only on an MI355X (HIP) device tensor; got a CPU tensor. "
                 "There is no CPU fallback in the product path.")
+        if cur is None:
+            cur = torch.cuda.current_device()
+        if x.device.index != cur:
+            # the kernels are launched on the CURRENT device's stream: a tensor of another device would be
+            # dereferenced on the wrong GPU
+            raise _lib.SocHipError(f"tensor on cuda:{x.device.index} but the current device is cuda:{cur}; "
+                                   "wrap the call in torch.cuda.device(tensor.device)")
 
 
 def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    return torch.cuda.current_stream().cuda_stream      # current device == every argument's device (_need_gpu)
 
 
 def _f32c(x: Tensor) -> Tensor:

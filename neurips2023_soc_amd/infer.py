@@ -3,7 +3,8 @@
 multi-GPU form of its `sub_processor` fan-out (infer_refytb.py:84-109).
 
     python -m neurips2023_soc_amd.infer --clips 16            # synthetic Ref-YouTube-VOS-like stream
-    python -m torch.distributed.run --nproc-per-node 8 -m neurips2023_soc_amd.infer --clips 64
+    python -m neurips2023_soc_amd.infer --clips 64 --gpus 8   # starts its 8 ranks itself (reference: -ng 8)
+    python -m torch.distributed.run --nproc-per-node 8 -m neurips2023_soc_amd.infer --clips 64 --gpus 8
     python -m neurips2023_soc_amd.infer --dataset refytb --root DATA --out RUNS [--tokenizer DIR] [--checkpoint CKPT]
     python -m neurips2023_soc_amd.infer --dataset davis --root DATA --out RUNS --make-synthetic 4   # writes DATA first
 """
@@ -91,6 +92,8 @@ def _run_dataset(a):
     from . import weights as W
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    if a.gpus != world:
+        raise RuntimeError(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if a.make_synthetic and rank == 0:
@@ -146,20 +149,22 @@ def main(argv=None):
     ap.add_argument("--graphs", action="store_true", help="hipGraph replay per clip geometry in the dataset drivers")
     ap.add_argument("--words", type=int, default=0, help="--make-synthetic: fixed number of words per expression")
     ap.add_argument("--repeat", type=int, default=1, help="run the driver this many times, report the last (warm) pass")
+    ap.add_argument("--gpus", "-ng", type=int, default=1,
+                    help="GPUs of this node; >1 without an outer launcher starts one rank per GPU (reference -ng)")
     a = ap.parse_args(argv)
+    if a.gpus > 1 and not CP.launched_as_rank():
+        # one process per GPU, started before this process touches the GPU (reference infer_refytb.py:84-109)
+        import sys
+        return CP.spawn_ranks(a.gpus, [sys.executable, "-m", "neurips2023_soc_amd.infer",
+                                       *(sys.argv[1:] if argv is None else argv)])
     if a.dataset:
         return _run_dataset(a)
     import torch.distributed as dist
     from . import build_model, default_args
     from . import weights as W
 
-    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
-    local = int(os.environ.get("LOCAL_RANK", 0))
-    torch.cuda.set_device(local)
+    rank, local, world = CP.init_rank("cuda", expect_world=a.gpus)
     dev = torch.device("cuda", local)
-    if "MASTER_PORT" in os.environ:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
     model, _, _ = build_model(default_args(a.backbone, text_encoder_random_init=True))
     W.load_synthetic(model, 2023)
     run = ClipInferencer(model.to(dev).eval(), dev)
@@ -173,23 +178,24 @@ def main(argv=None):
     # synthetic stream: clip i / expression i from seeds, like tests/golden (seed 1 == golden clip)
     clips = [W.synthetic_clip(1 + i, T, H, Wd) for i in mine]
     ids = [W.synthetic_token_ids(1 + i, L) for i in mine]
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for slot, (c, t) in enumerate(zip(clips, ids)):
-        res = run(c.to(dev, non_blocking=True), t.to(dev), a.orig)   # H2D inside the loop, like the reference
-        records[slot].copy_(res["record"])
-        fg[slot] = res["masks"].float().mean()
-    gathered = CP.interleave(CP.gather_results(records), a.clips)     # the one collective
+
+    def run_local(out):
+        for slot, (c, t) in enumerate(zip(clips, ids)):
+            res = run(c.to(dev, non_blocking=True), t.to(dev), a.orig)   # H2D inside the loop, like the reference
+            out[slot].copy_(res["record"])
+            fg[slot] = res["masks"].float().mean()
+
+    timed = CP.timed_sharded_run(run_local, records, dev)             # the one collective sits inside
+    gathered, dt = CP.interleave(timed["gathered"], a.clips), timed["seconds"]
     fgs = CP.interleave(CP.gather_results(fg[:, None]), a.clips)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
     if rank == 0:
         qs = [int(gathered[i, 0].item()) for i in range(a.clips)]
-        print(json.dumps({"clips": a.clips, "world": world, "seconds": dt, "clips_per_s": a.clips / dt,
+        print(json.dumps({"clips": a.clips, "world": world, "ranks_seen": timed["ranks_seen"], "seconds": dt,
+                          "clips_per_s": a.clips / dt,
                           "selected_queries": qs, "foreground_fraction": [round(float(v), 4) for v in fgs[:, 0]]}))
     if dist.is_initialized():
         dist.destroy_process_group()
 
 
 if __name__ == "__main__":
-    main()
+    raise SystemExit(main())

@@ -262,4 +262,12 @@ def load_kinetics_weights(body: VideoSwinTransformerBackbone, path: str) -> None
         if k.startswith("norm."):
             continue
         remap[k] = v
-    body.load_state_dict(remap, strict=False)
+    # the reference loads this checkpoint strictly (video_swin_transformer.py:660); the only tolerated differences
+    # here are the buffers this implementation does not keep (relative_position_index, cached attn masks)
+    missing, unexpected = body.load_state_dict(remap, strict=False)
+    derived = ("relative_position_index", "attn_mask")
+    missing = [k for k in missing if not k.endswith(derived)]
+    unexpected = [k for k in unexpected if not k.endswith(derived)]
+    if missing or unexpected:
+        raise RuntimeError(f"Kinetics checkpoint {path} does not match the backbone: missing {missing[:8]} "
+                           f"unexpected {unexpected[:8]}")

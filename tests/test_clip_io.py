@@ -157,3 +157,39 @@ def test_upsample_merge_labels_vs_torch(ops, O, T, h, w, H0, W0):
         top2 = torch.cat([torch.full((1, T, H0, W0), 0.1), m], 0).topk(2, 0)[0]
         assert float((top2[0] - top2[1])[bad].max()) < 1e-6 or float((up - 0.5).abs().min(0)[0][bad].max()) < 1e-6
     assert float(bad.float().mean()) < 1e-4
+
+
+def test_pinned_pool_never_hands_out_a_buffer_twice():
+    """take() runs on the prefetch thread and on the main thread (cache miss): an entry stays with its filler
+    until release(); two concurrent fillers of the same shape must get different buffers, and a ring whose
+    entries are all in use grows."""
+    import threading
+    pool = CI.PinnedPool(depth=2)
+    shape = (2, 4, 4, 3)
+    held, lock, errors = [], threading.Lock(), []
+
+    def filler(tag):
+        for _ in range(200):
+            e = pool.take(shape)
+            with lock:
+                if any(e is h for h in held):
+                    errors.append("entry handed out twice")
+                held.append(e)
+            e.tensor.fill_(tag)
+            if int(e.tensor.max()) != tag or int(e.tensor.min()) != tag:
+                errors.append("buffer overwritten while in use")
+            with lock:
+                held.remove(e)
+            e.release()
+
+    threads = [threading.Thread(target=filler, args=(t,)) for t in (1, 2, 3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:3]
+    ring = pool._bufs[tuple(shape)]
+    assert 2 <= len(ring) <= 3 and not any(e.in_use for e in ring)
+    a, b = pool.take(shape), pool.take(shape)
+    c = pool.take(shape)                      # both ring entries (or all three) busy -> distinct third / fourth
+    assert len({id(a), id(b), id(c)}) == 3

@@ -25,8 +25,14 @@ def _worker(rank, world, port, n_clips, ret):
     local = torch.zeros(n_local, CP.record_size(T, Q, H, W))
     for slot, cid in enumerate(mine):
         CP.pack_record(local[slot], *fake_result(cid))
-    allr = CP.interleave(CP.gather_results(local), n_clips)
-    ok = True
+
+    def run_local(out):                                  # the stub clip step: record = f(clip id)
+        for slot, cid in enumerate(mine):
+            CP.pack_record(out[slot], *fake_result(cid))
+
+    res = CP.timed_sharded_run(run_local, local, "cpu")  # the loop bench.py / infer.py time
+    allr = CP.interleave(res["gathered"], n_clips)
+    ok = res["ranks_seen"] == list(range(world)) and res["seconds"] >= max(res["seconds_per_rank"]) - 1e-12
     for cid in range(n_clips):
         q, cls, m = CP.unpack_record(allr[cid], T, Q, H, W)
         eq, ecls, em = fake_result(cid)
@@ -62,3 +68,45 @@ def test_single_process_gather_is_identity():
     x = torch.arange(6.0).view(2, 3)
     assert torch.equal(CP.gather_results(x), x[None])
     assert torch.equal(CP.interleave(x[None], 2), x)
+
+
+def _run(cmd, timeout=300):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    return subprocess.run([sys.executable, *cmd], cwd=root, capture_output=True, text=True, timeout=timeout)
+
+
+def test_self_launch_starts_one_rank_per_gpu():
+    """`--gpus 2` with no outer launcher: the process fans out by itself (reference infer_refytb.py:84-109),
+    both ranks join the group and rank 0 reports what the collective saw."""
+    import json
+    r = _run(["-m", "neurips2023_soc_amd.clip_parallel", "--gpus", "2", "--clips", "7", "--device", "cpu"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line == {"n_gpus": 2, "ranks_seen": [0, 1], "ok": True, "clips": 7}
+
+
+def test_self_launch_propagates_a_dead_rank():
+    """A rank that dies must fail the job (non-zero exit), not leave the other rank hanging in the all_gather."""
+    r = _run(["-m", "neurips2023_soc_amd.clip_parallel", "--gpus", "2", "--device", "cpu", "--fail-rank", "1"],
+             timeout=120)
+    assert r.returncode == 3
+    assert not any(ln.startswith("{") for ln in r.stdout.splitlines())
+
+
+def test_world_size_must_match_requested_gpus(monkeypatch):
+    import pytest
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.delenv("MASTER_PORT", raising=False)
+    with pytest.raises(RuntimeError, match="--gpus 8 but WORLD_SIZE=1"):
+        CP.init_rank("cpu", expect_world=8)
+
+
+def test_bench_consumes_gpus_flag_without_a_gpu():
+    """No GPU here: `bench.py --gpus 2` must start its two ranks (each then refuses to run without an MI355X)
+    and exit non-zero -- it can no longer silently measure one rank."""
+    r = _run(["bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0"], timeout=600)
+    assert r.returncode != 0
+    assert r.stderr.count("AssertionError: bench.py measures the HIP path") >= 1, r.stderr[-2000:]

@@ -39,6 +39,27 @@ def test_msda_reference_recipe(ops, golden, tag, tol):
     assert torch.allclose(out.cpu(), t(g[f"{tag}_out"]).to(dt), rtol=1e-2, atol=1e-3)
 
 
+@pytest.mark.parametrize("tag,tol", [("a64", 1e-12), ("a32", 1e-7)])
+def test_plugin_module_by_its_reference_name(ops, golden, tag, tol):
+    """`import MultiScaleDeformableAttention as MSDA` -- the binding of the reference
+    (models/ops/functions/ms_deform_attn_func.py:18) -- and the forward recipe of models/ops/test.py:32-60
+    (im2col_step = 2), plus backward through the same module against the reference-generated gradients."""
+    import MultiScaleDeformableAttention as MSDA
+    g = golden("msda_cases.npz")
+    dt = torch.float64 if tag == "a64" else torch.float32
+    args = (dev(g[f"{tag}_value"]).to(dt), dev(g[f"{tag}_shapes"]), dev(g[f"{tag}_lsi"]),
+            dev(g[f"{tag}_loc"]).to(dt), dev(g[f"{tag}_w"]).to(dt))
+    out = MSDA.ms_deform_attn_forward(*args, 2)
+    assert maxdiff(out, g[f"{tag}_out"]) < tol
+    with pytest.raises(RuntimeError, match="im2col_step"):
+        MSDA.ms_deform_attn_forward(*args, 0)
+    gg = golden("msda_grad_cases.npz")
+    a = {k: dev(gg[f"g4_{k}"]) for k in ("value", "shapes", "lsi", "loc", "w", "go")}
+    gv, gl, gw = MSDA.ms_deform_attn_backward(a["value"], a["shapes"], a["lsi"], a["loc"], a["w"], a["go"], 2)
+    for got, key in ((gv, "gvalue"), (gl, "gloc"), (gw, "gw")):
+        assert maxdiff(got, gg[f"g4_{key}"]) <= 1e-12 * max(1.0, float(np.abs(gg[f"g4_{key}"]).max()))
+
+
 def test_msda_model_capture(ops, golden):
     g = golden("tiny_kernels.npz")
     out = ops.msda_forward(dev(g["msda_dec_value"]), dev(g["msda_dec_shapes"]), dev(g["msda_dec_lsi"]),

@@ -118,7 +118,7 @@ def check_padded_b2(out, g):
         assert tuple(out[k].shape) == g[k].shape, k
     assert maxdiff(out["pred_masks"], g["pred_masks"]) < 1e-3
     flips = (out["pred_masks"].cpu().numpy() > 0) != (g["pred_masks"] > 0)
-    assert flips.sum() <= 2 and (not flips.any() or np.abs(g["pred_masks"][flips]).max() < 2.5e-4)
+    assert flips.sum() <= 2 and (not flips.any() or np.abs(g["pred_masks"][flips]).max() < 1e-4)
     assert maxdiff(out["pred_cls"], g["pred_cls"]) < 1e-4
     assert maxdiff(out["pred_boxes"], g["pred_boxes"]) < 1e-5
     assert maxdiff(out["pred_logit"], g["pred_logit"]) < 1e-4

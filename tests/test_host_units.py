@@ -5,6 +5,7 @@ import os
 import re
 
 import numpy as np
+import pytest
 import torch
 
 from neurips2023_soc_amd import config, position_encoding as PE, weights as W
@@ -116,3 +117,17 @@ def test_fused_linear_uses_library_on_cpu():
     a, b = fused.linear_multi(x, [(lin.weight, lin.bias, True), (lin.weight, None, False)], p)
     assert torch.equal(a, lin(x + p)) and torch.equal(b, F.linear(x, lin.weight))
     assert torch.equal(fused.linear_gelu(x, lin), F.gelu(lin(x)))
+
+
+def test_plugin_module_name_and_surface():
+    """The reference imports its native op as `MultiScaleDeformableAttention` (functions/ms_deform_attn_func.py:18)
+    and the extension exports exactly two functions (src/vision.cpp:13-16).  No CPU path, like the reference's
+    (src/cpu/ms_deform_attn_cpu.cpp:26,40): CPU tensors raise."""
+    import MultiScaleDeformableAttention as MSDA
+    assert sorted(MSDA.__all__) == ["ms_deform_attn_backward", "ms_deform_attn_forward"]
+    shapes = torch.tensor([[2, 2]])
+    args = (torch.zeros(1, 4, 1, 4), shapes, torch.tensor([0]), torch.zeros(1, 1, 1, 1, 1, 2), torch.zeros(1, 1, 1, 1, 1))
+    with pytest.raises(RuntimeError, match="im2col_step"):
+        MSDA.ms_deform_attn_forward(*args, 0)
+    with pytest.raises(Exception, match="no CPU fallback|MI355X"):
+        MSDA.ms_deform_attn_forward(*args, 1)

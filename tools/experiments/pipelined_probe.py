@@ -23,7 +23,7 @@ for c in clips:
     ref.append(g.record.clone())
 print("plain graph ok", flush=True)
 DEPTH = int(sys.argv[4]) if len(sys.argv) > 4 else 2
-pg = PipelinedClipGraph(model, T, H, Wd, 10, "cuda", depth=DEPTH)
+pg = PipelinedClipGraph(model, T, H, Wd, 10, "cuda")
 print(f"pipelined graphs captured (depth {DEPTH})", flush=True)
 got = []
 for c in clips:
