@@ -22,7 +22,13 @@
 #include "soc_common.h"
 #include <math.h>
 #include <stdlib.h>
+#include <algorithm>
 #include <atomic>
+#include <functional>
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
 
 namespace {
 
@@ -60,10 +66,24 @@ struct WinParams {
         if (lane == 0 && (slot) < 32)                                                    \
             p.dbg[((long)blockIdx.x * 8 + wave) * 32 + (slot)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
+#define STAMP_RT(slot)                                                                   \
+    do {                                                                                 \
+        if (lane == 0)                                                                   \
+            p.dbg[((long)blockIdx.x * 8 + wave) * 32 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#define STAMP_HWID(slot)                                                                 \
+    do {                                                                                 \
+        if (lane == 0)                                                                   \
+            p.dbg[((long)blockIdx.x * 8 + wave) * 32 + (slot)] =                         \
+                (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)) |          \
+                ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32);  \
+    } while (0)
 static unsigned long long* g_dbg = nullptr;
 extern "C" void soc_debug_set_buffer(void* ptr) { g_dbg = (unsigned long long*)ptr; }
 #else
 #define STAMP(slot) do {} while (0)
+#define STAMP_RT(slot) do {} while (0)
+#define STAMP_HWID(slot) do {} while (0)
 #endif
 
 __device__ __forceinline__ int region1d(int c, int P, int w, int s) {
@@ -214,7 +234,7 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_kernel(
     };
     float qn[8];
     int qsrc_n = -2;
-    int qt = qpart * (THREADS / 64) + wave;
+    int qt = qpart + qsplit * wave;      // part p of q takes tiles p, p+q, p+2q, ...; wave w the w-th, (w+8)-th, ... of them
     if (qt < p.NT) load_q(qt, qn, qsrc_n);
     for (; qt < p.NT; qt += nwaves_total) {
         const int qtok = qt * 16 + r;
@@ -396,24 +416,185 @@ constexpr int FN = 392, FNT = 25, FNP = 400;
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr int RSV = 404;        // row stride (floats) of the transposed V image [32][RSV]
 constexpr int TBL = 169 * 15;   // 2535 entries
+constexpr int PRS = 36;         // row stride of a wave's partial-output scratch (shared last tile)
+constexpr int PWS = 16 * PRS + 32;  // floats per wave: O partial [16][PRS], row max [16], row sum [16]
+constexpr size_t FULL_LDS_BYTES =
+    (size_t)(2536 + FNP * RS + HD * RSV + (THREADS / 64) * PWS) * sizeof(float) + (2 * FNP + 8) * sizeof(int);
+
+// One 16-query tile against ALL 25 key tiles: S^T = K.Q^T on top of the gathered bias, softmax in registers,
+// O^T = V^T.P^T, normalise, scatter.  `qn` holds the (unscaled) Q fragment of this tile on entry and the next
+// tile's on exit (prefetched behind the QK^T phase when next_qt >= 0).
+template <bool SHIFTED, typename LoadQ>
+__device__ __forceinline__ void full_tile(const int qt, const int next_qt, float (&qn)[8], int& qsrc_n,
+                                          const float* Ks, const float* Vt, const int* qcd, const unsigned tbase,
+                                          const int (&gcode)[FNT], const bool has_mask, const int r, const int g,
+                                          const int head, const int C, float* __restrict__ out, LoadQ&& load_q) {
+    const float scale = 0.17677669529663687f * LOG2E;
+    // byte offset of T'[(0,0) rel][dz_rel = 0] in the reversed-temporal layout, minus the +8 bias of both codes
+    const int C0 = ((6 * 13 + 6) * 15 + 7) * 4;
+    const float* kb = Ks + r * RS + 8 * g;           // + 16t*RS : 8 consecutive dims of key 16t + r
+    const float* vb = Vt + r * RSV + 4 * g;          // + 16t (+16*RSV): 4 consecutive keys of dim r
+    const int qtok = qt * 16 + r;
+    const int qsrc = qsrc_n;
+    float qf[8];
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) qf[kk] = qn[kk] * scale;
+    const int qc = qcd[qtok];
+    const unsigned qaddr = tbase + (unsigned)((qc & 0xFFFF) + C0);
+    const int qreg = qc >> 16;
+
+    // accumulators start from the bias: keys 16t+4g+i (i = 0..3) are frames 4(g&1)+i of one column = 4
+    // ASCENDING words of the reversed table row, landing in the accumulator registers in order
+    f32x4 acc[FNT];
+#pragma unroll
+    for (int t = 0; t < FNT; ++t) {
+        lds_cfloat* bp = (lds_cfloat*)(uintptr_t)(qaddr - (unsigned)(gcode[t] & 0xFFFF));
+        acc[t][0] = bp[0]; acc[t][1] = bp[1]; acc[t][2] = bp[2]; acc[t][3] = bp[3];
+    }
+    // S^T = K . Q^T, two key tiles interleaved so consecutive MFMAs hit different accumulators;
+    // K fragments (2 x b128 per tile) double-buffered across tile pairs
+    {
+        float ka[2][8], kc[2][8];
+        auto kload = [&](int t, float (&f)[8]) {
+            const float4 a = *reinterpret_cast<const float4*>(kb + 16 * t * RS);
+            const float4 c = *reinterpret_cast<const float4*>(kb + 16 * t * RS + 4);
+            f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = c.x; f[5] = c.y; f[6] = c.z; f[7] = c.w;
+        };
+        kload(0, ka[0]); kload(1, ka[1]);
+#pragma unroll
+        for (int tp = 0; tp < FNT; tp += 4) {
+            if (tp + 2 < FNT) kload(tp + 2, kc[0]);
+            if (tp + 3 < FNT) kload(tp + 3, kc[1]);
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                acc[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[0][kk], qf[kk], acc[tp], 0, 0, 0);
+                if (tp + 1 < FNT)
+                    acc[tp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[1][kk], qf[kk], acc[tp + 1], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (tp + 2 < FNT) {
+                if (tp + 4 < FNT) kload(tp + 4, ka[0]);
+                if (tp + 5 < FNT) kload(tp + 5, ka[1]);
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) {
+                    acc[tp + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(kc[0][kk], qf[kk], acc[tp + 2], 0, 0, 0);
+                    if (tp + 3 < FNT)
+                        acc[tp + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(kc[1][kk], qf[kk], acc[tp + 3], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    if (next_qt >= 0) load_q(next_qt, qn, qsrc_n);  // next tile's Q, hidden behind softmax + PV
+
+    if (has_mask) {
+#pragma unroll
+        for (int t = 0; t < FNT; ++t) {
+            const float pen = ((gcode[t] >> 16) != qreg) ? -100.0f * LOG2E : 0.f;
+            acc[t] += (f32x4){pen, pen, pen, pen};
+        }
+    }
+    if (g >= 2) acc[FNT - 1] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};  // slots 392..399
+    float mx = vmax3(acc[0][0], acc[0][1], acc[0][2]);
+    mx = fmaxf(mx, acc[0][3]);
+#pragma unroll
+    for (int t = 1; t < FNT; ++t) {
+        mx = vmax3(mx, acc[t][0], acc[t][1]);
+        mx = vmax3(mx, acc[t][2], acc[t][3]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    // softmax is shift-invariant: p = 2^(s - c) / sum 2^(s - c) for ANY c.  The reference's c = row max only
+    // guards the exponent range, so when every row max of the wave is within +-64 (log2 units; f32 holds 2^+-126)
+    // c = 0 is used and the 100 subtractions are not executed -- VALU time is matrix-pipe time on this part.
+    // Scores outside that range (possible with arbitrary weights) take the subtracting path.
+    if (!__all(fabsf(mx) < 64.f)) {
+        const f32x2 mx2 = (f32x2){mx, mx};
+#pragma unroll
+        for (int t = 0; t < FNT; ++t) {
+            const f32x2 d0 = pk_sub((f32x2){acc[t][0], acc[t][1]}, mx2);
+            const f32x2 d1 = pk_sub((f32x2){acc[t][2], acc[t][3]}, mx2);
+            acc[t] = (f32x4){d0[0], d0[1], d1[0], d1[1]};
+        }
+    }
+    f32x2 sum2 = (f32x2){0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < FNT; ++t) {
+        f32x4 e;
+        e[0] = __builtin_amdgcn_exp2f(acc[t][0]); e[1] = __builtin_amdgcn_exp2f(acc[t][1]);
+        e[2] = __builtin_amdgcn_exp2f(acc[t][2]); e[3] = __builtin_amdgcn_exp2f(acc[t][3]);
+        acc[t] = e;
+        sum2 += (f32x2){e[0], e[1]};
+        sum2 += (f32x2){e[2], e[3]};
+    }
+    float sum = sum2[0] + sum2[1];
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+
+    // O^T = V^T . P^T: A = V^T[dim r (+16)][keys 16t+4g .. +3] (one b128 each), B = acc[t][s]
+    f32x4 o0 = (f32x4){0.f, 0.f, 0.f, 0.f}, o1 = o0;
+    {
+        float4 va0, va1, vc0, vc1;
+        va0 = *reinterpret_cast<const float4*>(vb);
+        va1 = *reinterpret_cast<const float4*>(vb + 16 * RSV);
+#pragma unroll
+        for (int t = 0; t < FNT; t += 2) {
+            if (t + 1 < FNT) {
+                vc0 = *reinterpret_cast<const float4*>(vb + 16 * (t + 1));
+                vc1 = *reinterpret_cast<const float4*>(vb + 16 * (t + 1) + 16 * RSV);
+            }
+            o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(va0.x, acc[t][0], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(va1.x, acc[t][0], o1, 0, 0, 0);
+            o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(va0.y, acc[t][1], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(va1.y, acc[t][1], o1, 0, 0, 0);
+            o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(va0.z, acc[t][2], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(va1.z, acc[t][2], o1, 0, 0, 0);
+            o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(va0.w, acc[t][3], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(va1.w, acc[t][3], o1, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 1 < FNT) {
+                if (t + 2 < FNT) {
+                    va0 = *reinterpret_cast<const float4*>(vb + 16 * (t + 2));
+                    va1 = *reinterpret_cast<const float4*>(vb + 16 * (t + 2) + 16 * RSV);
+                }
+                o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(vc0.x, acc[t + 1][0], o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(vc1.x, acc[t + 1][0], o1, 0, 0, 0);
+                o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(vc0.y, acc[t + 1][1], o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(vc1.y, acc[t + 1][1], o1, 0, 0, 0);
+                o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(vc0.z, acc[t + 1][2], o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(vc1.z, acc[t + 1][2], o1, 0, 0, 0);
+                o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(vc0.w, acc[t + 1][3], o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(vc1.w, acc[t + 1][3], o1, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    if (qsrc >= 0) {
+        const float inv = 1.f / sum;
+        float* orow = out + (long)qsrc * C + head * HD + 4 * g;
+        *reinterpret_cast<float4*>(orow) = make_float4(o0[0] * inv, o0[1] * inv, o0[2] * inv, o0[3] * inv);
+        *reinterpret_cast<float4*>(orow + 16) = make_float4(o1[0] * inv, o1[1] * inv, o1[2] * inv, o1[3] * inv);
+    }
+}
 
 template <bool SHIFTED>
 __global__ __launch_bounds__(THREADS, 2) void win_attn3d_full_kernel(
     const float* __restrict__ qkv, const float* __restrict__ qkv_bias,
     const float* __restrict__ table, float* __restrict__ out, const WinParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* Tb = reinterpret_cast<float*>(smem_raw);            // [2535 (+1 pad)] T'[(yy,xx)][zz] * log2e
+    float* Tb = reinterpret_cast<float*>(smem_raw);            // [2535 (+1 pad)] T'[(yy,xx)][14 - zz] * log2e
     float* Ks = Tb + 2536;                                      // [400][RS]   K, slot-major
     float* Vt = Ks + FNP * RS;                                  // [32][RSV]   V transposed
-    int* src = reinterpret_cast<int*>(Vt + HD * RSV);           // [400] token row offset or <0
+    float* Pw = Vt + HD * RSV;                                  // [8][PWS]    per-wave partials of the shared last tile
+    int* src = reinterpret_cast<int*>(Pw + (THREADS / 64) * PWS);  // [400] token row offset or <0
     int* qcd = src + FNP;                                       // [400] 4*(c(q)) | region << 16
     int* wflag = qcd + FNP;                                     // [8]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // the last (pairs mod #CU) pairs would leave most CUs idle in the final round of workgroups, so
-    // those tail pairs are split over several workgroups (each re-stages K/V for a slice of the tiles)
+    // pairs [0, n_main) get one workgroup each; the pairs behind them are split qsplit ways over query tiles
+    // (plan_schedule(): the last round of workgroups would otherwise leave most CUs idle)
     int bid = blockIdx.x;
     int qpart = 0, qsplit = 1;
     if (bid >= p.n_main) {
@@ -429,8 +610,11 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_full_kernel(
     const int b = bid;
     const int C3 = 3 * p.C;
     const int r = lane & 15, g = lane >> 4;
+    STAMP_RT(30);
+    STAMP_HWID(29);
+    STAMP(0);
 
-    // ---- stage 0: slot metadata (slot = col*8 + dz, col = dy*7 + dx) --------------------------
+    // slot = col*8 + dz, col = dy*7 + dx (temporal index fastest)
     auto slot_info = [&](int i, int& reg, int& ccode) -> int {
         const int col = i >> 3, dz = i & 7;
         const int dy = col / 7, dx = col - dy * 7;
@@ -439,48 +623,34 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_full_kernel(
         int y = ys + p.sh; if (y >= p.Hp) y -= p.Hp;
         int x = xs + p.sw; if (x >= p.Wp) x -= p.Wp;
         reg = (region1d(zs, p.Dp, 8, p.sd) * 3 + region1d(ys, p.Hp, 7, p.sh)) * 3 + region1d(xs, p.Wp, 7, p.sw);
-        ccode = ((dy * 13 + dx) * 15 + dz) * 4;  // byte offset of T'[(dy,dx)][dz]
+        ccode = ((dy * 13 + dx) * 15 - dz + 8) * 4;  // byte code of the slot in the reversed-temporal table
         return (z < p.D && y < p.H && x < p.W) ? ((b * p.D + z) * p.H + y) * p.W + x : -1;
     };
-    int differs = 0;
-    int reg0, c0;
-    (void)slot_info(0, reg0, c0);
-    for (int i = tid; i < FNP; i += THREADS) {
-        int s = -2, reg = 0, cc = 0;
-        if (i < FN) {
-            s = slot_info(i, reg, cc);
-            differs |= (reg != reg0);
-        }
-        src[i] = s;
-        qcd[i] = cc | (reg << 16);
-    }
-    // bias column, re-laid-out with dz_rel fastest: T'[((yy*13)+xx)*15 + zz] = table[(zz*169 + yy*13 + xx)][head]
-    for (int i = tid; i < TBL; i += THREADS) {
-        const int yx = i / 15, zz = i - yx * 15;
-        Tb[i] = table[(long)(zz * 169 + yx) * p.nH + head] * LOG2E;
-    }
-    if (SHIFTED && lane == 0) wflag[wave] = 0;
-    if (SHIFTED && __any(differs) && lane == 0) wflag[wave] = 1;
-    __syncthreads();
-    bool has_mask = false;
-    if (SHIFTED) {
-        int f = 0;
-#pragma unroll
-        for (int w8 = 0; w8 < THREADS / 64; ++w8) f |= wflag[w8];
-        has_mask = f != 0;
-    }
 
-    // ---- stage 1: K -> [slot][36], V -> transposed [dim][404] -----------------------------------
+    // ---- stage 0+1: every thread derives the metadata of the K/V rows it stages (8 threads x float4 per row)
+    // and issues their global loads at once; the bias column is fetched behind them.  K -> [slot][36],
+    // V -> transposed [dim][404].  ONE barrier for metadata, bias column, K and V.
     {
         const int part = tid & 7;
         const float4 kbias = *reinterpret_cast<const float4*>(qkv_bias + p.C + head * HD + part * 4);
         const float4 vbias = *reinterpret_cast<const float4*>(qkv_bias + 2 * p.C + head * HD + part * 4);
         constexpr int ROWS = THREADS / 8, PASSES = (FNP + ROWS - 1) / ROWS;
         float4 kv[PASSES], vv[PASSES];
+        int differs = 0;
+        int reg0, c0;
+        (void)slot_info(0, reg0, c0);
 #pragma unroll
         for (int it = 0; it < PASSES; ++it) {
             const int i = it * ROWS + (tid >> 3);
-            const int s = i < FNP ? src[i] : -2;
+            int s = -2, reg = 0, cc = 0;
+            if (i < FN) {
+                s = slot_info(i, reg, cc);
+                differs |= (reg != reg0);
+            }
+            if (i < FNP && part == 0) {
+                src[i] = s;
+                qcd[i] = cc | (reg << 16);
+            }
             if (s >= 0) {
                 const float* row = qkv + (long)s * C3 + head * HD + part * 4;
                 kv[it] = *reinterpret_cast<const float4*>(row + p.C);
@@ -490,6 +660,24 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_full_kernel(
             } else {
                 kv[it] = make_float4(0.f, 0.f, 0.f, 0.f); vv[it] = kv[it];
             }
+        }
+        // bias column with the temporal offset fastest and REVERSED: word yx*15 + (14 - zz) holds
+        // table[(zz*169 + yx)][head], so the 4 frames kz0..kz0+3 of a key group are 4 ascending words
+        constexpr int TPASS = (TBL + THREADS - 1) / THREADS;
+        float tv[TPASS];
+#pragma unroll
+        for (int it = 0; it < TPASS; ++it) {
+            const int i = it * THREADS + tid;
+            const int yx = i / 15, zz = i - yx * 15;
+            tv[it] = i < TBL ? table[(long)(zz * 169 + yx) * p.nH + head] : 0.f;
+        }
+        const int wave_differs = __any(differs);        // all 64 lanes vote (not inside the lane-0 branch)
+        if (SHIFTED && lane == 0) wflag[wave] = wave_differs ? 1 : 0;
+#pragma unroll
+        for (int it = 0; it < TPASS; ++it) {
+            const int i = it * THREADS + tid;
+            const int yx = i / 15, zz = i - yx * 15;
+            if (i < TBL) Tb[yx * 15 + 14 - zz] = tv[it] * LOG2E;
         }
 #pragma unroll
         for (int it = 0; it < PASSES; ++it) {
@@ -503,10 +691,9 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_full_kernel(
             }
         }
     }
+    STAMP(1);
     // per-(tile, lane) key-group codes: group = slots 16t+4g..+3 = column 2t + (g>>1), frames 4(g&1)..+3
-    int gcode[FNT];
-#pragma unroll
-    for (int t = 0; t < FNT; ++t) {
+    auto group_code = [&](int t) -> int {
         const int col = 2 * t + (g >> 1);
         const int dy = col / 7, dx = col - dy * 7;
         int reg = 0;
@@ -514,18 +701,23 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_full_kernel(
             const int zs = wz * 8 + 4 * (g & 1), ys = wy * 7 + dy, xs = wx * 7 + dx;
             reg = (region1d(zs, p.Dp, 8, p.sd) * 3 + region1d(ys, p.Hp, 7, p.sh)) * 3 + region1d(xs, p.Wp, 7, p.sw);
         }
-        gcode[t] = (((dy * 13 + dx) * 15 + 4 * (g & 1)) * 4) | (reg << 16);
-    }
+        return (((dy * 13 + dx) * 15 - 4 * (g & 1) + 8) * 4) | (reg << 16);
+    };
+    int gcode[FNT];
+#pragma unroll
+    for (int t = 0; t < FNT; ++t) gcode[t] = group_code(t);
     __syncthreads();
+    bool has_mask = false;
+    if (SHIFTED) {
+        int f = 0;
+#pragma unroll
+        for (int w8 = 0; w8 < THREADS / 64; ++w8) f |= wflag[w8];
+        has_mask = f != 0;
+    }
+    STAMP(2);
 
-    // ---- stage 2/3: per 16-query tile ---------------------------------------------------------
-    const float scale = 0.17677669529663687f * LOG2E;
-    const int C0 = ((6 * 13 + 6) * 15 + 7 - 3) * 4;  // byte offset of T'[(0,0) rel][dz_rel = 0], minus the 3-word run
-    const int nwaves_total = (THREADS / 64) * qsplit;
-    const float* kb = Ks + r * RS + 8 * g;           // + 16t*RS : 8 consecutive dims of key 16t + r
-    const float* vb = Vt + r * RSV + 4 * g;          // + 16t (+16*RSV): 4 consecutive keys of dim r
+    // ---- stage 2/3: 16-query tiles ---------------------------------------------------------------
     const unsigned tbase = (unsigned)(uintptr_t)(lds_cfloat*)Tb;
-
     auto load_q = [&](int qt, float (&qf)[8], int& qsrc) {
         qsrc = src[qt * 16 + r];
         if (qsrc >= 0) {
@@ -540,149 +732,131 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_full_kernel(
             for (int kk = 0; kk < 8; ++kk) qf[kk] = 0.f;
         }
     };
+    // An unsplit workgroup deals tiles 0..23 three to a wave and SHARES the 25th (8 real queries): every wave
+    // takes 3-4 of its 25 key tiles and the partial results are merged through LDS -- 6.25 tile-times per SIMD
+    // instead of 7/6/6/6.  Split workgroups (a part of the tiles each) keep whole tiles.
+    const bool share_last = qsplit == 1;
+    const int ntile = share_last ? FNT - 1 : FNT;
+    const int stride = (THREADS / 64) * qsplit;
     float qn[8];
     int qsrc_n = -2;
-    int qt = qpart * (THREADS / 64) + wave;
-    if (qt < FNT) load_q(qt, qn, qsrc_n);
+    int qt = qpart + qsplit * wave;   // part p of q owns tiles p, p+q, ...; wave w the w-th, (w+8)-th, ... of them
+    if (qt < ntile) load_q(qt, qn, qsrc_n);
 
-    for (; qt < FNT; qt += nwaves_total) {
-        const int qtok = qt * 16 + r;
-        const int qsrc = qsrc_n;
+    for (; qt < ntile; qt += stride)
+        full_tile<SHIFTED>(qt, qt + stride < ntile ? qt + stride : -1, qn, qsrc_n, Ks, Vt, qcd, tbase, gcode, has_mask,
+                           r, g, head, p.C, out, load_q);
+    STAMP(3);
+
+    if (share_last) {
+        constexpr int QT = FNT - 1;
+        const float scale = 0.17677669529663687f * LOG2E;
+        const int C0 = ((6 * 13 + 6) * 15 + 7) * 4;
         float qf[8];
+        int qsrc;
+        load_q(QT, qf, qsrc);
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) qf[kk] = qn[kk] * scale;
-        const int qc = qcd[qtok];
+        for (int kk = 0; kk < 8; ++kk) qf[kk] *= scale;
+        const int qc = qcd[QT * 16 + r];
         const unsigned qaddr = tbase + (unsigned)((qc & 0xFFFF) + C0);
         const int qreg = qc >> 16;
-
-        // accumulators start from the bias: keys 16t+4g+i (i = 0..3) are frames 4(g&1)+i of one
-        // column, i.e. words qaddr - gcode + (3 - i)
-        f32x4 acc[FNT];
+        const float* kb = Ks + r * RS + 8 * g;
+        const float* vb = Vt + r * RSV + 4 * g;
+        constexpr int NJ = (FNT + THREADS / 64 - 1) / (THREADS / 64);   // key tiles per wave: kt = wave + 8j
+        f32x4 a4[NJ];
 #pragma unroll
-        for (int t = 0; t < FNT; ++t) {
-            lds_cfloat* bp = (lds_cfloat*)(uintptr_t)(qaddr - (unsigned)(gcode[t] & 0xFFFF));
-            acc[t][3] = bp[0]; acc[t][2] = bp[1]; acc[t][1] = bp[2]; acc[t][0] = bp[3];
-        }
-        // S^T = K . Q^T, two key tiles interleaved so consecutive MFMAs hit different accumulators;
-        // K fragments (2 x b128 per tile) double-buffered across tile pairs
-        {
-            float ka[2][8], kc[2][8];
-            auto kload = [&](int t, float (&f)[8]) {
-                const float4 a = *reinterpret_cast<const float4*>(kb + 16 * t * RS);
-                const float4 c = *reinterpret_cast<const float4*>(kb + 16 * t * RS + 4);
-                f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = c.x; f[5] = c.y; f[6] = c.z; f[7] = c.w;
-            };
-            kload(0, ka[0]); kload(1, ka[1]);
-#pragma unroll
-            for (int tp = 0; tp < FNT; tp += 4) {
-                if (tp + 2 < FNT) kload(tp + 2, kc[0]);
-                if (tp + 3 < FNT) kload(tp + 3, kc[1]);
-#pragma unroll
-                for (int kk = 0; kk < 8; ++kk) {
-                    acc[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[0][kk], qf[kk], acc[tp], 0, 0, 0);
-                    if (tp + 1 < FNT)
-                        acc[tp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[1][kk], qf[kk], acc[tp + 1], 0, 0, 0);
+        for (int j = 0; j < NJ; ++j) {
+            const int kt = wave + (THREADS / 64) * j;          // wave-uniform
+            a4[j] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            if (kt < FNT) {
+                const int gc = group_code(kt);
+                lds_cfloat* bp = (lds_cfloat*)(uintptr_t)(qaddr - (unsigned)(gc & 0xFFFF));
+                f32x4 a = (f32x4){bp[0], bp[1], bp[2], bp[3]};
+                const float4 k0 = *reinterpret_cast<const float4*>(kb + 16 * kt * RS);
+                const float4 k1 = *reinterpret_cast<const float4*>(kb + 16 * kt * RS + 4);
+                a = __builtin_amdgcn_mfma_f32_16x16x4f32(k0.x, qf[0], a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x4f32(k0.y, qf[1], a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x4f32(k0.z, qf[2], a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x4f32(k0.w, qf[3], a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x4f32(k1.x, qf[4], a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x4f32(k1.y, qf[5], a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x4f32(k1.z, qf[6], a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x4f32(k1.w, qf[7], a, 0, 0, 0);
+                if (has_mask) {
+                    const float pen = ((gc >> 16) != qreg) ? -100.0f * LOG2E : 0.f;
+                    a += (f32x4){pen, pen, pen, pen};
                 }
-                __builtin_amdgcn_sched_barrier(0);
-                if (tp + 2 < FNT) {
-                    if (tp + 4 < FNT) kload(tp + 4, ka[0]);
-                    if (tp + 5 < FNT) kload(tp + 5, ka[1]);
-#pragma unroll
-                    for (int kk = 0; kk < 8; ++kk) {
-                        acc[tp + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(kc[0][kk], qf[kk], acc[tp + 2], 0, 0, 0);
-                        if (tp + 3 < FNT)
-                            acc[tp + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(kc[1][kk], qf[kk], acc[tp + 3], 0, 0, 0);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+                if (kt == FNT - 1 && g >= 2) a = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};  // slots 392..399
+                a4[j] = a;
             }
         }
-        if (qt + nwaves_total < FNT) load_q(qt + nwaves_total, qn, qsrc_n);  // next tile's Q, hidden
-
-        if (has_mask) {
+        // this wave's keys: local max / exp / sum (merged below with the other waves' by the usual rescaling)
+        float mx = -INFINITY;
 #pragma unroll
-            for (int t = 0; t < FNT; ++t) {
-                const float pen = ((gcode[t] >> 16) != qreg) ? -100.0f * LOG2E : 0.f;
-                acc[t] += (f32x4){pen, pen, pen, pen};
-            }
-        }
-        if (g >= 2) acc[FNT - 1] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};  // slots 392..399
-        float mx = vmax3(acc[0][0], acc[0][1], acc[0][2]);
-        mx = fmaxf(mx, acc[0][3]);
-#pragma unroll
-        for (int t = 1; t < FNT; ++t) {
-            mx = vmax3(mx, acc[t][0], acc[t][1]);
-            mx = vmax3(mx, acc[t][2], acc[t][3]);
-        }
+        for (int j = 0; j < NJ; ++j) mx = fmaxf(fmaxf(mx, fmaxf(a4[j][0], a4[j][1])), fmaxf(a4[j][2], a4[j][3]));
         mx = fmaxf(mx, __shfl_xor(mx, 16));
         mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const f32x2 mx2 = (f32x2){mx, mx};
-        f32x2 sum2 = (f32x2){0.f, 0.f};
+        float sum = 0.f;
 #pragma unroll
-        for (int t = 0; t < FNT; ++t) {
-            const f32x2 d0 = pk_sub((f32x2){acc[t][0], acc[t][1]}, mx2);
-            const f32x2 d1 = pk_sub((f32x2){acc[t][2], acc[t][3]}, mx2);
-            f32x4 e;
-            e[0] = __builtin_amdgcn_exp2f(d0[0]); e[1] = __builtin_amdgcn_exp2f(d0[1]);
-            e[2] = __builtin_amdgcn_exp2f(d1[0]); e[3] = __builtin_amdgcn_exp2f(d1[1]);
-            acc[t] = e;
-            sum2 += (f32x2){e[0], e[1]};
-            sum2 += (f32x2){e[2], e[3]};
-        }
-        float sum = sum2[0] + sum2[1];
-        sum += __shfl_xor(sum, 16);
-        sum += __shfl_xor(sum, 32);
-
-        // O^T = V^T . P^T: A = V^T[dim r (+16)][keys 16t+4g .. +3] (one b128 each), B = acc[t][s]
-        f32x4 o0 = (f32x4){0.f, 0.f, 0.f, 0.f}, o1 = o0;
-        {
-            float4 va0, va1, vc0, vc1;
-            va0 = *reinterpret_cast<const float4*>(vb);
-            va1 = *reinterpret_cast<const float4*>(vb + 16 * RSV);
+        for (int j = 0; j < NJ; ++j) {
 #pragma unroll
-            for (int t = 0; t < FNT; t += 2) {
-                if (t + 1 < FNT) {
-                    vc0 = *reinterpret_cast<const float4*>(vb + 16 * (t + 1));
-                    vc1 = *reinterpret_cast<const float4*>(vb + 16 * (t + 1) + 16 * RSV);
-                }
-                o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(va0.x, acc[t][0], o0, 0, 0, 0);
-                o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(va1.x, acc[t][0], o1, 0, 0, 0);
-                o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(va0.y, acc[t][1], o0, 0, 0, 0);
-                o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(va1.y, acc[t][1], o1, 0, 0, 0);
-                o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(va0.z, acc[t][2], o0, 0, 0, 0);
-                o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(va1.z, acc[t][2], o1, 0, 0, 0);
-                o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(va0.w, acc[t][3], o0, 0, 0, 0);
-                o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(va1.w, acc[t][3], o1, 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (t + 1 < FNT) {
-                    if (t + 2 < FNT) {
-                        va0 = *reinterpret_cast<const float4*>(vb + 16 * (t + 2));
-                        va1 = *reinterpret_cast<const float4*>(vb + 16 * (t + 2) + 16 * RSV);
-                    }
-                    o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(vc0.x, acc[t + 1][0], o0, 0, 0, 0);
-                    o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(vc1.x, acc[t + 1][0], o1, 0, 0, 0);
-                    o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(vc0.y, acc[t + 1][1], o0, 0, 0, 0);
-                    o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(vc1.y, acc[t + 1][1], o1, 0, 0, 0);
-                    o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(vc0.z, acc[t + 1][2], o0, 0, 0, 0);
-                    o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(vc1.z, acc[t + 1][2], o1, 0, 0, 0);
-                    o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(vc0.w, acc[t + 1][3], o0, 0, 0, 0);
-                    o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(vc1.w, acc[t + 1][3], o1, 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+            for (int i = 0; i < 4; ++i) {
+                a4[j][i] = __builtin_amdgcn_exp2f(a4[j][i] - mx);
+                sum += a4[j][i];
             }
         }
-        if (qsrc >= 0) {
-            const float inv = 1.f / sum;
-            float* orow = out + (long)qsrc * p.C + head * HD + 4 * g;
-            *reinterpret_cast<float4*>(orow) = make_float4(o0[0] * inv, o0[1] * inv, o0[2] * inv, o0[3] * inv);
-            *reinterpret_cast<float4*>(orow + 16) = make_float4(o1[0] * inv, o1[1] * inv, o1[2] * inv, o1[3] * inv);
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        f32x4 o0 = (f32x4){0.f, 0.f, 0.f, 0.f}, o1 = o0;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int kt = wave + (THREADS / 64) * j;
+            if (kt < FNT) {
+                const float4 v0 = *reinterpret_cast<const float4*>(vb + 16 * kt);
+                const float4 v1 = *reinterpret_cast<const float4*>(vb + 16 * kt + 16 * RSV);
+                o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v0.x, a4[j][0], o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v1.x, a4[j][0], o1, 0, 0, 0);
+                o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v0.y, a4[j][1], o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v1.y, a4[j][1], o1, 0, 0, 0);
+                o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v0.z, a4[j][2], o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v1.z, a4[j][2], o1, 0, 0, 0);
+                o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v0.w, a4[j][3], o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v1.w, a4[j][3], o1, 0, 0, 0);
+            }
+        }
+        // partial O^T: column = query r, rows = dims 4g..4g+3 (o0) and 16+4g.. (o1)
+        float* pw = Pw + wave * PWS;
+        *reinterpret_cast<float4*>(pw + r * PRS + 4 * g) = make_float4(o0[0], o0[1], o0[2], o0[3]);
+        *reinterpret_cast<float4*>(pw + r * PRS + 16 + 4 * g) = make_float4(o1[0], o1[1], o1[2], o1[3]);
+        if (g == 0) {
+            pw[16 * PRS + r] = mx;
+            pw[16 * PRS + 16 + r] = sum;
+        }
+        __syncthreads();
+        // merge: thread = (query, dim); only queries 0..7 of the tile exist (slots 384..391)
+        const int q = tid >> 5, d = tid & 31;
+        const int osrc = q < FN - QT * 16 ? src[QT * 16 + q] : -1;
+        if (osrc >= 0) {
+            float M = -INFINITY;
+#pragma unroll
+            for (int w8 = 0; w8 < THREADS / 64; ++w8) M = fmaxf(M, Pw[w8 * PWS + 16 * PRS + q]);
+            float num = 0.f, den = 0.f;
+#pragma unroll
+            for (int w8 = 0; w8 < THREADS / 64; ++w8) {
+                const float f = __builtin_amdgcn_exp2f(Pw[w8 * PWS + 16 * PRS + q] - M);
+                num += f * Pw[w8 * PWS + q * PRS + d];
+                den += f * Pw[w8 * PWS + 16 * PRS + 16 + q];
+            }
+            out[(long)osrc * p.C + head * HD + d] = num / den;
         }
     }
+    STAMP(4);
+    STAMP_RT(31);
 }
 
 int launch_full(const float* qkv, const float* qkv_bias, const float* table, float* out,
                 const WinParams& p, long blocks, hipStream_t st) {
-    const size_t lds = (size_t)(2536 + FNP * RS + HD * RSV) * sizeof(float) + (2 * FNP + 8) * sizeof(int);
+    const size_t lds = FULL_LDS_BYTES;
     static std::atomic<bool> attr_set[SOC_MAX_DEVICES];   // per device: the attribute is device state
     const int dev = soc_current_device();
     if (dev < 0) return SOC_ELAUNCH;
@@ -743,7 +917,79 @@ int num_cus() {
     return n;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Workgroup schedule.  One workgroup per (window, head) pair is the efficient form (K/V staged once), but
+// a pair is an indivisible ~48 us of one CU, so a grid that is not a multiple of the CU count idles most
+// of the chip in its last round (897 pairs on 256 CUs: 4 rounds for 3.5 rounds of work).  The last pairs
+// are therefore split q ways over query tiles (each part re-stages K/V).  (n_main, q) are chosen by
+// simulating the dispatcher -- workgroups are handed to CUs in index order as CUs free up -- with a cost
+// model fitted to MI355X measurements (tools/k1_probe.py --stamps / --sweep; the model ranks the forced
+// schedules of the sweep within 2-3 us of their measured times): in units of one tile-slot (four SIMDs x one
+// 16-query tile, ~15.9k cycles), staging a pair's K/V + bias column costs SIGMA = 0.86, a part that owns n whole
+// tiles SIGMA + ceil(n / 4), an unsplit full-window workgroup (25th tile shared) SIGMA + 25/4 + 0.27.
+// ---------------------------------------------------------------------------------------------
+struct Plan { int n_main, qsplit; };
+
+double simulate_tail(long pairs, int NT, int cus, int n_main, int q, bool shared_last, std::vector<double>& heap) {
+    constexpr double SIGMA = 0.86, SHARE = 0.27;
+    const double full = SIGMA + (shared_last ? NT / 4.0 + SHARE : (double)((NT + 3) / 4));
+    const long rounds = n_main / cus, extra = n_main % cus;
+    heap.assign(cus, rounds * full);
+    for (long i = 0; i < extra; ++i) heap[i] += full;
+    std::make_heap(heap.begin(), heap.end(), std::greater<double>());
+    double part_cost[32];
+    for (int pt = 0; pt < q; ++pt) {
+        const int n = (NT - pt + q - 1) / q;              // tiles pt, pt+q, ... < NT
+        part_cost[pt] = n > 0 ? SIGMA + (n + 3) / 4 : 0.05;
+    }
+    double makespan = rounds * full + (extra ? full : 0.0);
+    for (long pr = n_main; pr < pairs; ++pr)
+        for (int pt = 0; pt < q; ++pt) {
+            std::pop_heap(heap.begin(), heap.end(), std::greater<double>());
+            const double t = heap.back() + part_cost[pt];
+            heap.back() = t;
+            std::push_heap(heap.begin(), heap.end(), std::greater<double>());
+            if (t > makespan) makespan = t;
+        }
+    // the real dispatcher is not an ideal list scheduler: among equal makespans prefer fewer workgroups
+    return makespan + 1e-4 * (double)(n_main + (pairs - n_main) * q);
+}
+
+Plan plan_schedule(long pairs, int NT, int cus, bool shared_last) {
+    static std::mutex mu;
+    static std::map<std::tuple<long, int, int, bool>, Plan> cache;     // one entry per launch geometry
+    const auto key = std::make_tuple(pairs, NT, cus, shared_last);
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = cache.find(key);
+        if (it != cache.end()) return it->second;
+    }
+    std::vector<double> heap;
+    Plan best{(int)pairs, 1};
+    double best_t = simulate_tail(pairs, NT, cus, (int)pairs, 1, shared_last, heap);
+    const int max_q = NT < 8 ? NT : 8;
+    // only the last two rounds' worth of pairs are candidates for splitting: earlier rounds are full anyway
+    const long lo = pairs > 2L * cus ? (pairs - 2L * cus) / 8 * 8 : 0;
+    for (int q = 2; q <= max_q; ++q)
+        for (long nm = lo; nm < pairs; nm += 8) {
+            const double t = simulate_tail(pairs, NT, cus, (int)nm, q, shared_last, heap);
+            if (t < best_t - 1e-9) { best_t = t; best = Plan{(int)nm, q}; }
+        }
+    std::lock_guard<std::mutex> lk(mu);
+    cache[key] = best;
+    return best;
+}
+
+#ifdef SOC_K1_TUNE
+int g_force_n_main = 0, g_force_qsplit = 0;
+#endif
+
 }  // namespace
+
+#ifdef SOC_K1_TUNE
+extern "C" void soc_debug_force_k1_plan(int n_main, int qsplit) { g_force_n_main = n_main; g_force_qsplit = qsplit; }
+#endif
 
 extern "C" int soc_win_attn3d_f32(const float* qkv, const float* qkv_bias, const float* bias_table,
                                   float* out, int B, int D, int H, int W, int C, int n_heads,
@@ -773,30 +1019,24 @@ extern "C" int soc_win_attn3d_f32(const float* qkv, const float* qkv_bias, const
 #endif
     if ((long)B * D * H * W * 3 * C >= (1L << 31)) return SOC_EUNSUPPORTED;  // int token offsets
     const long pairs = (long)B * p.nwd * p.nwh * p.nww * n_heads;
-    // Workgroup schedule.  One workgroup per pair is the efficient form (K/V staged once); what it
-    // leaves on the table is the last round of workgroups when pairs is not a multiple of the CU
-    // count.  So only the TAIL pairs (pairs mod #CU, when that is at most half the CUs) are split 2
-    // or 4 ways over query tiles; grids smaller than the chip are split as a whole.
-    const int cus = num_cus();
-    p.qsplit = 1;
-    p.n_main = (int)pairs;
-    if (pairs < cus) {
-        p.n_main = 0;
-        while (pairs * p.qsplit < 2 * cus && p.qsplit < 4 &&
-               (p.NT + (THREADS / 64) * p.qsplit - 1) / ((THREADS / 64) * p.qsplit) > 1)
-            p.qsplit *= 2;
-    } else {
-        const int tail = (int)(pairs % cus);
-        if (tail > 0 && tail <= cus / 2) {
-            p.qsplit = tail <= cus / 4 ? 4 : 2;
-            p.n_main = (int)pairs - tail;
-        }
+    const bool full_window = win_d == 8 && win_h == 7 && win_w == 7 && tab_d == 8 && tab_h == 7 && tab_w == 7;
+    {
+        const Plan pl = plan_schedule(pairs, p.NT, num_cus(), full_window);
+        p.n_main = pl.n_main;
+        p.qsplit = pl.qsplit;
     }
+#ifdef SOC_K1_TUNE   // diagnostic build only (tools/k1_probe.py --sweep): force a schedule
+    if (g_force_qsplit > 0) {
+        p.qsplit = g_force_qsplit;
+        p.n_main = g_force_n_main < 0 ? 0 : (g_force_n_main > pairs ? (int)pairs : g_force_n_main);
+        if (p.qsplit == 1) p.n_main = (int)pairs;
+    }
+#endif
     const long blocks = p.n_main + (pairs - p.n_main) * p.qsplit;
     hipStream_t st = (hipStream_t)stream;
     // key/query tiles are a compile-time constant (fully unrolled MFMA schedule); a window with
     // fewer tokens runs on the next larger instantiation with the surplus keys masked out.
-    if (win_d == 8 && win_h == 7 && win_w == 7 && tab_d == 8 && tab_h == 7 && tab_w == 7)
+    if (full_window)
         return launch_full(qkv, qkv_bias, bias_table, out, p, blocks, st);
     if (p.NT <= 7) return launch_nt<7, 0>(qkv, qkv_bias, bias_table, out, p, blocks, st);
     if (p.NT <= 10) return launch_nt<10, 7>(qkv, qkv_bias, bias_table, out, p, blocks, st);

@@ -21,6 +21,21 @@ Tensor = torch.Tensor
 _prof = None
 
 
+_k1_calls = None   # bench.py: when a list, window_attention3d appends its arguments (tensors are kept alive)
+
+
+def record_window_attention_calls(on: bool):
+    """Start (True) / stop (False, returns the list) recording the arguments of every K1 call, so that
+    bench.py can replay exactly the launches of a forward -- same tensors, same geometry -- back to back
+    between ONE pair of HIP events (per-launch event pairs add host/queue latency to ~50 us kernels)."""
+    global _k1_calls
+    if on:
+        _k1_calls = []
+        return None
+    calls, _k1_calls = _k1_calls, None
+    return calls
+
+
 def profile_begin() -> None:
     global _prof
     _prof = {}
@@ -194,6 +209,8 @@ def window_attention3d(qkv: Tensor, qkv_bias: Tensor, bias_table: Tensor, n_head
     _need_gpu(qkv, qkv_bias, bias_table)
     lib = _lib.load()
     qkv, qkv_bias, bias_table = _f32c(qkv), _f32c(qkv_bias), _f32c(bias_table)
+    if _k1_calls is not None:
+        _k1_calls.append((qkv, qkv_bias, bias_table, n_heads, tuple(window), tuple(shift)))
     B, D, H, W, C3 = qkv.shape
     C = C3 // 3
     win, sh = clamp_window((D, H, W), window, shift)

@@ -97,10 +97,10 @@ def test_msda_rejects_bad_input(ops):
 
 
 # ------------------------------------------------------------------ K1 window attention
-def _win_case(ops, B, D, H, W, nH, shift, seed):
+def _win_case(ops, B, D, H, W, nH, shift, seed, gain=1.0):
     g = torch.Generator().manual_seed(seed)
     C = nH * 32
-    qkv = torch.randn(B, D, H, W, 3 * C, generator=g)
+    qkv = torch.randn(B, D, H, W, 3 * C, generator=g) * gain
     bias = torch.randn(3 * C, generator=g) * 0.5
     table = torch.randn(15 * 13 * 13, nH, generator=g) * 0.5
     ref = O.window_attention_core(qkv, bias, table, nH, O.WINDOW, shift)
@@ -122,6 +122,31 @@ def _win_case(ops, B, D, H, W, nH, shift, seed):
 def test_window_attention_vs_oracle(ops, D, H, W, nH, shift):
     d, scale = _win_case(ops, 1, D, H, W, nH, shift, seed=D * 100 + H)
     assert d < 2e-5 * max(scale, 1.0), (d, scale)
+
+
+@pytest.mark.parametrize("H,W,nH,shift", [
+    (23, 40, 12, (0, 0, 0)),       # stage 2 of the BASELINE config: 288 pairs -> whole pairs + pairs split over tiles
+    (23, 40, 12, (4, 3, 3)),
+    (12, 20, 24, (4, 3, 3)),       # stage 3: 144 pairs, fewer than CUs -> every pair split
+    (45, 80, 6, (4, 3, 3)),        # stage 1: 504 pairs
+])
+def test_window_attention_baseline_stage_geometries(ops, H, W, nH, shift):
+    """Full 8x7x7 windows at the pair counts of the BASELINE config's later stages: exercises the planner's
+    mixed schedule (unsplit workgroups that share their 25th query tile + workgroups that own a part of a pair)."""
+    d, scale = _win_case(ops, 1, 8, H, W, nH, shift, seed=H)
+    assert d < 2e-5 * max(scale, 1.0), (d, scale)
+
+
+@pytest.mark.parametrize("gain", [4.0, 9.0])
+def test_window_attention_large_scores(ops, gain):
+    """Scores far outside +-64 (log2 units): the softmax must take its max-subtracting path (the common path skips
+    the subtraction, legal only while 2^score stays inside the f32 range) -- and rows mixing both regimes."""
+    # scores are ~gain^2 * 6 here: one f32 ulp of a score of 500 is 3e-5, which the exponential turns into a
+    # relative error of the same size -- the bound scales with the score magnitude, not with the output's
+    d, scale = _win_case(ops, 1, 8, 14, 21, 3, (4, 3, 3), seed=77, gain=gain)
+    assert d < 2e-5 * gain * max(scale, 1.0), (d, scale)
+    d, scale = _win_case(ops, 1, 8, 23, 40, 12, (0, 0, 0), seed=78, gain=gain)
+    assert d < 2e-5 * gain * max(scale, 1.0), (d, scale)
 
 
 def test_window_attention_batch_gt1(ops):
