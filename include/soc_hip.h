@@ -92,6 +92,7 @@ int soc_msda_fused_fwd_f32(const float* value, const uint8_t* value_pad_mask, co
                            const float* attn_logits, float* out, int N, int S, int M, int D, int L,
                            int Lq, int P, void* stream);
 
+
 /*
  * K1 -- 3-D (shifted) window attention with relative position bias, fused with the
  * pad / cyclic-roll / window-partition / reverse / un-roll / crop index math.

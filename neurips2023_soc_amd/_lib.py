@@ -19,6 +19,7 @@ EXPORTS = ("soc_hip_abi_version", "soc_hip_error_string", "soc_msda_fwd_f32", "s
            "soc_groupnorm_tokens_f32", "soc_patch_merge_layernorm_f32", "soc_linear_act_f32",
            "soc_linear_act_multi_f32")
 ABI_VERSION = 2
+SOC_EUNSUPPORTED = -2      # include/soc_hip.h: shape outside what the kernel is built for
 
 _lib = None
 

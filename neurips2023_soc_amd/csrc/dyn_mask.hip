@@ -17,22 +17,28 @@ constexpr int CF = 8;    // feature channels (mask_kernels_dim)
 constexpr int CH = 8;    // hidden channels (dynamic_mask_channels)
 constexpr int NPARAM = (CF + 2) * CH + CH * CH + CH + CH + CH + 1;  // 169
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Two horizontally adjacent pixels per lane: every FMA of the three layers is a v_pk_fma_f32 with the
+// (wave-uniform, scalar) weight broadcast to both halves -- half the vector instructions per pixel of the
+// one-pixel form (the kernel is VALU-issue-bound: 152 FMAs per (pixel, instance) against 36 bytes of traffic).
 __global__ __launch_bounds__(256) void dyn_mask_kernel(
     const float* __restrict__ feats, const float* __restrict__ params,
     const float* __restrict__ refs, float* __restrict__ out, int Q, int hw, int w, float img_h,
     float img_w, int stride, int q_per_block) {
     const int t = blockIdx.y;
-    const int pix = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = pix < hw;
-    const int pc = live ? pix : hw - 1;
-    const int y = pc / w, x = pc - y * w;
-    const float px = (float)(stride * x + stride / 2);
-    const float py = (float)(stride * y + stride / 2);
+    const int pix = (blockIdx.x * blockDim.x + threadIdx.x) * 2;    // pixels pix, pix + 1 of the flattened map
+    const bool live0 = pix < hw, live1 = pix + 1 < hw;
+    const int p0 = live0 ? pix : hw - 1, p1 = live1 ? pix + 1 : hw - 1;
+    const int y0 = p0 / w, x0 = p0 - y0 * w;
+    const int y1 = p1 / w, x1 = p1 - y1 * w;
+    const f32x2 px = {(float)(stride * x0 + stride / 2), (float)(stride * x1 + stride / 2)};
+    const f32x2 py = {(float)(stride * y0 + stride / 2), (float)(stride * y1 + stride / 2)};
 
-    float f[CF];
-    const float* fp = feats + (long)t * CF * hw + pc;
+    f32x2 f[CF];
+    const float* fp = feats + (long)t * CF * hw;
 #pragma unroll
-    for (int c = 0; c < CF; ++c) f[c] = fp[(long)c * hw];
+    for (int c = 0; c < CF; ++c) f[c] = (f32x2){fp[(long)c * hw + p0], fp[(long)c * hw + p1]};
 
     // blockIdx.z picks a slice of the frame's instances: with all Q per thread the launch has < 2 waves per
     // SIMD at the BASELINE config and the scalar parameter loads are fully exposed
@@ -40,9 +46,9 @@ __global__ __launch_bounds__(256) void dyn_mask_kernel(
     for (int q = q_lo; q < q_hi; ++q) {
         const int inst = t * Q + q;
         const float* __restrict__ P = params + (long)inst * NPARAM;  // wave-uniform
-        const float rx = refs[inst * 2] * img_w - px;
-        const float ry = refs[inst * 2 + 1] * img_h - py;
-        float h0[CH], h1[CH];
+        const f32x2 rx = refs[inst * 2] * img_w - px;
+        const f32x2 ry = refs[inst * 2 + 1] * img_h - py;
+        f32x2 h0[CH], h1[CH];
         const float* W0 = P;
         const float* W1 = P + (CF + 2) * CH;
         const float* W2 = W1 + CH * CH;
@@ -51,24 +57,30 @@ __global__ __launch_bounds__(256) void dyn_mask_kernel(
         const float* B2 = B1 + CH;
 #pragma unroll
         for (int o = 0; o < CH; ++o) {
-            float a = B0[o];
+            f32x2 a = B0[o];
 #pragma unroll
             for (int c = 0; c < CF; ++c) a += W0[o * (CF + 2) + c] * f[c];
             a += W0[o * (CF + 2) + CF] * rx;
             a += W0[o * (CF + 2) + CF + 1] * ry;
-            h0[o] = fmaxf(a, 0.f);
+            h0[o] = __builtin_elementwise_max(a, (f32x2){0.f, 0.f});
         }
 #pragma unroll
         for (int o = 0; o < CH; ++o) {
-            float a = B1[o];
+            f32x2 a = B1[o];
 #pragma unroll
             for (int c = 0; c < CH; ++c) a += W1[o * CH + c] * h0[c];
-            h1[o] = fmaxf(a, 0.f);
+            h1[o] = __builtin_elementwise_max(a, (f32x2){0.f, 0.f});
         }
-        float r = B2[0];
+        f32x2 r = B2[0];
 #pragma unroll
         for (int c = 0; c < CH; ++c) r += W2[c] * h1[c];
-        if (live) out[(long)inst * hw + pix] = r;
+        float* op = out + (long)inst * hw + pix;
+        if (live1 && ((((long)inst * hw + pix) & 1) == 0)) {
+            *reinterpret_cast<float2*>(op) = make_float2(r[0], r[1]);
+        } else {
+            if (live0) op[0] = r[0];
+            if (live1) op[1] = r[1];
+        }
     }
 }
 
@@ -83,11 +95,11 @@ extern "C" int soc_dyn_mask_f32(const float* feats, const float* params, const f
     if (T == 0 || Q == 0) return SOC_OK;
     const int hw = h * w;
     // enough workgroups for ~8 waves per SIMD (256 CUs x 4 SIMDs): split the Q instances over grid.z
-    const long base_waves = (long)soc_ceil_div(hw, 256) * 4 * T;
+    const long base_waves = (long)soc_ceil_div(hw, 512) * 4 * T;
     int groups = (int)((8192 + base_waves - 1) / base_waves);
     groups = groups < 1 ? 1 : (groups > Q ? Q : groups);
     const int q_per_block = soc_ceil_div(Q, groups);
-    dim3 grid(soc_ceil_div(hw, 256), T, soc_ceil_div(Q, q_per_block));
+    dim3 grid(soc_ceil_div(hw, 512), T, soc_ceil_div(Q, q_per_block));
     hipLaunchKernelGGL(dyn_mask_kernel, grid, dim3(256), 0, (hipStream_t)stream, feats, params,
                        refs, out, Q, hw, w, img_h, img_w, stride, q_per_block);
     return soc_check_launch();

@@ -37,8 +37,10 @@ __device__ __forceinline__ void fma4(float4& a, float w, const float4& v) {
 // the RAW attention logits; the kernel computes softmax over the L*P = 16 logits, the sampling
 // locations ref + off / (W_l, H_l)  (2-d refs) or ref_xy + off / P * ref_wh * 0.5  (4-d refs), and
 // applies the value padding mask per tap (only when the device-side flag says padding exists).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
 template <bool FUSED>
-__global__ __launch_bounds__(256) void msda_fwd_d32p4_kernel(
+__global__ __launch_bounds__(256, 4) void msda_fwd_d32p4_kernel(
     const float* __restrict__ value, const int64_t* __restrict__ shapes,
     const int64_t* __restrict__ lsi, const float* __restrict__ loc,
     const float* __restrict__ attw, float* __restrict__ out, int N, int S, int M, int L, int Lq,
@@ -54,8 +56,12 @@ __global__ __launch_bounds__(256) void msda_fwd_d32p4_kernel(
     const long gi = (long)n * groups_per_frame + g;          // (n, q, m) flat
     const float4* lp = reinterpret_cast<const float4*>(loc + gi * (long)(L * 8));
     const float4* wp = reinterpret_cast<const float4*>(attw + gi * (long)(L * 4));
-    const float* vbase = value + (long)n * S * M * 32 + m * 32 + c4 * 4;
-    const int rstride = M * 32;  // floats between consecutive spatial positions
+    // taps are buffer loads: <frame descriptor> + <scalar level offset> + <32-bit per-lane byte offset>, i.e. one
+    // VALU add per tap instead of 64-bit pointer arithmetic (the host guarantees a frame's value map is < 2 GiB)
+    const __amdgpu_buffer_rsrc_t vframe = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(value + (long)n * S * M * 32), 0, S * M * 32 * 4, 0x00020000);
+    const unsigned lane_off = (unsigned)(m * 32 + c4 * 4) * 4u;
+    const unsigned rstride = (unsigned)M * 32u * 4u;  // bytes between consecutive spatial positions
 
     // FUSED: softmax over the 16 logits of this (query, head) -- L == 4 is enforced by the host
     float4 sm[4];
@@ -84,10 +90,11 @@ __global__ __launch_bounds__(256) void msda_fwd_d32p4_kernel(
     }
 
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 1
     for (int l = 0; l < L; ++l) {
         const int Hl = (int)shapes[2 * l], Wl = (int)shapes[2 * l + 1];
         const int lstart = (int)lsi[l];
-        const float* vl = vbase + (long)lstart * rstride;
+        const unsigned vl = (unsigned)lstart * rstride;       // wave-uniform byte offset of the level
         const float4 la = lp[2 * l], lb = lp[2 * l + 1];
         const float4 wv = FUSED ? sm[l & 3] : wp[l];
         float xs[4] = {la.x, la.z, lb.x, lb.z};
@@ -95,20 +102,24 @@ __global__ __launch_bounds__(256) void msda_fwd_d32p4_kernel(
         if (FUSED) {
             const float rx = rp[l * ref_dim], ry = rp[l * ref_dim + 1];
             if (ref_dim == 2) {
+                // off / (W_l, H_l) as a multiplication by the level's reciprocal (wave-uniform, one division per
+                // level instead of 8 per lane: the IEEE division sequence is ~10 VALU instructions); <= 1 ulp from
+                // the reference's true division, i.e. ~1e-7 of a pixel
+                const float rW = 1.0f / (float)Wl, rH = 1.0f / (float)Hl;
 #pragma unroll
-                for (int p = 0; p < 4; ++p) { xs[p] = rx + xs[p] / (float)Wl; ys[p] = ry + ys[p] / (float)Hl; }
+                for (int p = 0; p < 4; ++p) { xs[p] = rx + xs[p] * rW; ys[p] = ry + ys[p] * rH; }
             } else {
                 const float rw = rp[l * ref_dim + 2], rh = rp[l * ref_dim + 3];
 #pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    xs[p] = rx + xs[p] / 4.0f * rw * 0.5f;
-                    ys[p] = ry + ys[p] / 4.0f * rh * 0.5f;
+                for (int p = 0; p < 4; ++p) {      // / 4 is exact (power of two)
+                    xs[p] = rx + xs[p] * 0.25f * rw * 0.5f;
+                    ys[p] = ry + ys[p] * 0.25f * rh * 0.5f;
                 }
             }
         }
         const float ws[4] = {wv.x, wv.y, wv.z, wv.w};
         float tw[4][4];
-        const float* ptr[4][4];
+        unsigned ptr[4][4];
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const float him = ys[p] * Hl - 0.5f;
@@ -129,10 +140,14 @@ __global__ __launch_bounds__(256) void msda_fwd_d32p4_kernel(
             tw[p][1] = (h0ok && w1ok) ? hh * lw * wgt : 0.f;
             tw[p][2] = (h1ok && w0ok) ? lh * hw * wgt : 0.f;
             tw[p][3] = (h1ok && w1ok) ? lh * lw * wgt : 0.f;
-            ptr[p][0] = vl + (long)(h0c * Wl + w0c) * rstride;
-            ptr[p][1] = vl + (long)(h0c * Wl + w1c) * rstride;
-            ptr[p][2] = vl + (long)(h1c * Wl + w0c) * rstride;
-            ptr[p][3] = vl + (long)(h1c * Wl + w1c) * rstride;
+            // 24-bit multiplies (full rate; v_mul_lo_u32 is quarter rate): positions and the row stride are < 2^24
+            const unsigned r0 = __umul24(__umul24(h0c, Wl), rstride) + lane_off;
+            const unsigned r1 = __umul24(__umul24(h1c, Wl), rstride) + lane_off;
+            const unsigned c0 = __umul24(w0c, rstride), c1 = __umul24(w1c, rstride);
+            ptr[p][0] = r0 + c0;
+            ptr[p][1] = r0 + c1;
+            ptr[p][2] = r1 + c0;
+            ptr[p][3] = r1 + c1;
             if (FUSED && use_pad) {  // value.masked_fill(padding_mask, 0): a padded position samples 0
                 if (padn[lstart + h0c * Wl + w0c]) tw[p][0] = 0.f;
                 if (padn[lstart + h0c * Wl + w1c]) tw[p][1] = 0.f;
@@ -144,7 +159,11 @@ __global__ __launch_bounds__(256) void msda_fwd_d32p4_kernel(
 #pragma unroll
         for (int p = 0; p < 4; ++p)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) tv[p][k] = *reinterpret_cast<const float4*>(ptr[p][k]);
+            for (int k = 0; k < 4; ++k) {
+                const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(vframe, ptr[p][k], vl, 0);
+                tv[p][k] = make_float4(__uint_as_float(raw.x), __uint_as_float(raw.y), __uint_as_float(raw.z),
+                                       __uint_as_float(raw.w));
+            }
 #pragma unroll
         for (int p = 0; p < 4; ++p)
 #pragma unroll
@@ -225,7 +244,7 @@ extern "C" int soc_msda_fwd_f32(const float* value, const int64_t* spatial_shape
                  M, D, L, Lq, P))
         return SOC_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    if (D == 32 && P == 4) {
+    if (D == 32 && P == 4 && (long)S * M * 128 < (1L << 31) && S < (1 << 24) && M * 128 < (1 << 24)) {   // 32-bit tap offsets
         const int gpf = Lq * M;
         const int bpf = soc_ceil_div(gpf, 32);
         hipLaunchKernelGGL(msda_fwd_d32p4_kernel<false>, dim3(bpf * N), dim3(256), 0, st, value,
@@ -261,6 +280,8 @@ extern "C" int soc_msda_fused_fwd_f32(const float* value, const uint8_t* value_p
         !ref_points)
         return SOC_EINVAL;
     if (D != 32 || P != 4 || L != 4 || (ref_dim != 2 && ref_dim != 4)) return SOC_EUNSUPPORTED;
+    if ((long)S * M * 128 >= (1L << 31) || S >= (1 << 24) || M * 128 >= (1 << 24))
+        return SOC_EUNSUPPORTED;   // 32-bit tap offsets inside a frame, 24-bit multiplies
     if ((value_pad_mask == nullptr) != (any_pad == nullptr)) return SOC_EINVAL;
     const int gpf = Lq * M;
     const int bpf = soc_ceil_div(gpf, 32);

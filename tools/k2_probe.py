@@ -1,0 +1,48 @@
+"""K2 (multi-scale deformable attention) at the BASELINE encoder size: plain fused launch vs the LDS-staged encoder form.
+usage: python tools/k2_probe.py [reps]      (run under rocprofv3 --pmc ... for the cache counters)"""
+import sys
+
+import torch
+
+sys.path.insert(0, ".")
+from neurips2023_soc_amd import hot_ops  # noqa: E402
+from neurips2023_soc_amd.deformable_transformer import DeformableTransformerEncoder as E  # noqa: E402
+
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+which = sys.argv[2] if len(sys.argv) > 2 else "both"
+shapes = [[45, 80], [23, 40], [12, 20], [6, 10]]
+N, M = 8, 8
+sh = torch.tensor(shapes).cuda()
+lsi = torch.cat((sh.new_zeros(1), sh.prod(1).cumsum(0)[:-1]))
+S = int(sh.prod(1).sum())
+g = torch.Generator().manual_seed(0)
+value = torch.randn(N, S, M, 32, generator=g).cuda()
+ref = E.get_reference_points(shapes, torch.ones(N, 4, 2), "cpu").cuda()
+# offsets like the model's: a per-(head, level, point) pattern of 1-4 px plus a query-dependent part (std ~2 px)
+scale = float(sys.argv[3]) if len(sys.argv) > 3 else 1.0
+pattern = torch.randn(1, 1, M, 4, 4, 2, generator=g) * 2.0 * scale
+off = (pattern + torch.randn(N, S, M, 4, 4, 2, generator=g) * 1.6 * scale).cuda()
+print(f"offset scale {scale}: mean |off| {float(off.abs().mean()):.2f} px, P(|off| > 5) = {float((off.abs() > 5).float().mean()):.3f}")
+logits = torch.randn(N, S, M, 16, generator=g).cuda()
+algo = (value.numel() + off.numel() + logits.numel() + N * S * M * 32) * 4
+
+
+def timeit(fn):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / reps * 1e3
+
+
+if which in ("both", "plain"):
+    us = timeit(lambda: hot_ops.msda_fused_forward(value, sh, lsi, ref, off, logits))
+    print(f"plain fused launch   : {us:7.1f} us  {algo / us / 1e3:7.1f} GB/s algorithmic ({algo / us / 1e3 / 8000:.3f} of HBM peak)")
+if which in ("both", "patch"):
+    us = timeit(lambda: hot_ops.msda_fused_forward(value, sh, lsi, ref, off, logits, shapes_list=shapes))
+    print(f"encoder form, LDS    : {us:7.1f} us  {algo / us / 1e3:7.1f} GB/s algorithmic ({algo / us / 1e3 / 8000:.3f} of HBM peak)")

@@ -1,0 +1,46 @@
+"""Steady-state timeline of bench.py's graph replays from a rocprofv3 --kernel-trace CSV: per clip (delimited by the
+single dyn_mask launch each forward ends with) the wall time, the time with 0 / 1 / >= 2 kernels in flight and the
+kernel-time sum, plus the longest idle gaps and what ran around them.
+usage: python tools/timeline.py <kernel_trace.csv> [clips_to_skip]"""
+import csv
+import sys
+
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if "spin_kernel" not in r["Kernel_Name"]]
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+skip = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+ends = [int(r["End_Timestamp"]) for r in rows if "dyn_mask" in r["Kernel_Name"]]
+if len(ends) < skip + 6:
+    sys.exit("too few clips in the trace")
+t_lo, t_hi = ends[skip], ends[skip + 10] if len(ends) > skip + 10 else ends[-1]
+n_clips = (skip + 10 if len(ends) > skip + 10 else len(ends) - 1) - skip
+ev = []
+for r in rows:
+    s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+    if e <= t_lo or s >= t_hi:
+        continue
+    ev.append((max(s, t_lo), 1, r["Kernel_Name"]))
+    ev.append((min(e, t_hi), -1, r["Kernel_Name"]))
+ev.sort(key=lambda x: (x[0], x[1]))
+depth, last = 0, t_lo
+hist = {0: 0, 1: 0, 2: 0}
+gaps, prev_name = [], ""
+for t, d, name in ev:
+    hist[min(depth, 2)] += t - last
+    if depth == 0 and t > last:
+        gaps.append((t - last, prev_name, name))
+    depth += d
+    last = t
+    if d < 0:
+        prev_name = name
+busy = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows
+           if t_lo <= int(r["Start_Timestamp"]) and int(r["End_Timestamp"]) <= t_hi)
+wall = t_hi - t_lo
+print(f"{n_clips} steady-state clips: wall {wall / n_clips / 1e6:.3f} ms/clip, kernel-time sum {busy / n_clips / 1e6:.3f} ms/clip")
+print(f"   idle (no kernel)   {hist[0] / n_clips / 1e6:.3f} ms/clip")
+print(f"   exactly one kernel {hist[1] / n_clips / 1e6:.3f} ms/clip")
+print(f"   two or more        {hist[2] / n_clips / 1e6:.3f} ms/clip")
+nk = sum(1 for r in rows if t_lo <= int(r["Start_Timestamp"]) < t_hi)
+print(f"   kernels per clip {nk / n_clips:.0f}; idle gaps: {len(gaps) / n_clips:.0f} per clip, mean {hist[0] / max(len(gaps), 1) / 1e3:.2f} us")
+print("   longest idle gaps (us): after -> before")
+for g, a, b in sorted(gaps, reverse=True)[:12]:
+    print(f"      {g / 1e3:7.1f}  {a[:60]} -> {b[:60]}")
