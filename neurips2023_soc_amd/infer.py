@@ -20,7 +20,7 @@ import torch
 
 from . import clip_parallel as CP
 from . import postprocessing as P
-from .graph_runner import ClipGraph
+from .graph_runner import ClipGraph, PipelinedClipGraph
 from .nested_tensor import NestedTensor
 
 
@@ -41,6 +41,8 @@ class ClipInferencer:
         self.model, self.device = model, torch.device(device)
         self.use_graphs, self.max_graphs, self.pad_tokens_to = use_graphs, max_graphs, pad_tokens_to
         self._graphs: Dict[Tuple[int, int, int, int], ClipGraph] = {}
+        self._pipes: Dict[Tuple[int, int, int, int], PipelinedClipGraph] = {}
+        self._active = None          # (key, pipe, tag of the clip in flight)
 
     def graph_for(self, T: int, H: int, W: int, L: int) -> ClipGraph:
         key = (T, H, W, L)
@@ -50,6 +52,63 @@ class ClipInferencer:
                 self._graphs.pop(next(iter(self._graphs)))
             self._graphs[key] = ClipGraph(self.model, T, H, W, L, self.device)
         return self._graphs[key]
+
+    # -- streaming form: the software-pipelined graph (tail of clip i beside the head of clip i+1) ---------------
+    def _pad_tokens(self, token_ids: torch.Tensor):
+        ids, attn = token_ids.view(1, -1), None
+        L = ids.shape[-1]
+        if self.pad_tokens_to is not None and L < self.pad_tokens_to:
+            extra = self.pad_tokens_to - L
+            attn = torch.cat([torch.ones_like(ids), ids.new_zeros(1, extra)], 1)
+            ids = torch.cat([ids, ids.new_full((1, extra), self.PAD_ID)], 1)
+        return ids, attn
+
+    def _unpack(self, rec: torch.Tensor, key, tag, original_size):
+        T, H, W, _ = key
+        Q = self.model.num_queries
+        hm, wm = -(-H // 4), -(-W // 4)
+        masks = rec[1 + T * Q:].view(T, hm, wm)
+        res = {"tag": tag, "query": rec[0].to(torch.int64), "mask_logits": masks, "pred_cls": rec[1:1 + T * Q].view(T, Q)}
+        if original_size is not None:
+            res["masks"] = P.upsample_and_threshold(masks, original_size)
+        return res
+
+    @torch.no_grad()
+    def submit(self, clip: torch.Tensor, token_ids: torch.Tensor, tag, original_size=None):
+        """Streaming form of __call__ for use_graphs=True: submits `clip` and returns the result dict of the clip
+        submitted BEFORE it (its `tag` and `original_size` were given then), or None for the first clip / after a
+        geometry change has drained the pipeline (then a LIST of one result is returned first by drain()).
+        Results: 'tag', 'query', 'mask_logits' (a view of the graph's record: consume it, e.g. through 'masks', before
+        the next submit), 'pred_cls', 'masks' when original_size was given."""
+        if not self.use_graphs:
+            raise RuntimeError("submit() streams through hipGraphs; construct with use_graphs=True")
+        T, _, H, W = clip.shape
+        ids, attn = self._pad_tokens(token_ids)
+        key = (T, H, W, ids.shape[-1])
+        done = None
+        if self._active is not None and self._active[0] != key:
+            done = self.drain()                                   # geometry change: finish what is in flight
+        if key not in self._pipes:
+            while len(self._pipes) >= self.max_graphs:
+                torch.cuda.synchronize(self.device)
+                self._pipes.pop(next(iter(self._pipes)))
+            self._pipes[key] = PipelinedClipGraph(self.model, T, H, W, ids.shape[-1], self.device)
+        pipe = self._pipes[key]
+        rec = pipe.run(clip, ids, attn)
+        prev = self._active
+        self._active = (key, pipe, tag, original_size)
+        if rec is not None and prev is not None:
+            return self._unpack(rec, prev[0], prev[2], prev[3])
+        return done[0] if done else None
+
+    @torch.no_grad()
+    def drain(self):
+        """Finish the clip still in flight: [result dict] or []."""
+        if self._active is None:
+            return []
+        key, pipe, tag, osz = self._active
+        self._active = None
+        return [self._unpack(rec, key, tag, osz) for rec in pipe.flush()]
 
     @torch.no_grad()
     def forward_clip(self, clip: torch.Tensor, token_ids: torch.Tensor):

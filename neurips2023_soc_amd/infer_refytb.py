@@ -81,6 +81,22 @@ def run(model, tokenize: Tokenize, root: str, out_dir: str, rank: int = 0, world
 
     d2h = torch.cuda.Stream(device=device)    # mask download overlaps the next clip's forward
 
+    streaming = engine.use_graphs        # graphs: software-pipelined replays, results arrive one clip late
+
+    def enqueue_download(res):
+        """masks of a finished clip -> pinned host buffer on the d2h stream; returns the job for flush()"""
+        masks, (save_dir, names) = res["masks"], res["tag"]
+        host = host_buffer(masks.shape, enqueue_download.n % 2)
+        enqueue_download.n += 1
+        d2h.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(d2h):
+            host.copy_(masks, non_blocking=True)
+            masks.record_stream(d2h)
+            done = torch.cuda.Event()
+            done.record()
+        return (host, done, save_dir, names)
+    enqueue_download.n = 0
+
     with ThreadPoolExecutor(max_workers=writer_workers) as writers:
         prev = None
         for vi, video in enumerate(todo):
@@ -93,24 +109,27 @@ def run(model, tokenize: Tokenize, root: str, out_dir: str, rank: int = 0, world
                 clip, orig = cache.get(paths)                                  # decoded / resized once per video
                 ids = tokenize(item["exp"]).pin_memory().to(device, non_blocking=True)
                 t2 = time.perf_counter()
-                masks = engine(clip, ids, orig)["masks"]                       # [T,H0,W0] bool, still in flight
-                host = host_buffer(masks.shape, stats["expressions"] % 2)
-                d2h.wait_stream(torch.cuda.current_stream(device))
-                with torch.cuda.stream(d2h):
-                    host.copy_(masks, non_blocking=True)
-                    masks.record_stream(d2h)
-                    done = torch.cuda.Event()
-                    done.record()
                 save_dir = os.path.join(out_dir, video, exp_id)
                 os.makedirs(save_dir, exist_ok=True)
+                if streaming:
+                    res = engine.submit(clip, ids, (save_dir, frames), orig)   # result of the PREVIOUS clip, or None
+                else:
+                    res = engine(clip, ids, orig)                              # [T,H0,W0] bool, still in flight
+                    res["tag"] = (save_dir, frames)
+                job = enqueue_download(res) if res is not None else None
                 if prev is not None:
                     flush(prev)
-                prev = (host, done, save_dir, frames)
+                prev = job
                 stats["seconds_input"] += t2 - t1
                 stats["seconds_model"] += time.perf_counter() - t2
                 stats["expressions"] += 1
                 stats["frames"] += len(frames)
             stats["videos"] += 1
+        if streaming:
+            for res in engine.drain():
+                if prev is not None:
+                    flush(prev)
+                prev = enqueue_download(res)
         if prev is not None:
             flush(prev)
         t_tail = time.perf_counter()

@@ -64,14 +64,18 @@ def gpu_model():
 
 
 @pytest.mark.gpu
-def test_refytb_driver_matches_reference_recipe(gpu_model, tmp_path):
+@pytest.mark.parametrize("use_graphs", [False, True])
+def test_refytb_driver_matches_reference_recipe(gpu_model, tmp_path, use_graphs):
+    """use_graphs=True: the driver streams through the software-pipelined hipGraph (results one clip late, drained
+    at the end) -- the same PNGs must come out."""
     from PIL import Image
     from neurips2023_soc_amd import infer_refytb
     model, sd = gpu_model
     root = SD.make_dataset(str(tmp_path / "data"), videos=2, frames=3, height=144, width=256, expressions=2, seed=3)
     tok = SD.HashTokenizer()
     out_dir = str(tmp_path / "out")
-    stats = infer_refytb.run(model, tok, root, out_dir, size=SIZE, max_size=MAX_SIZE, decode_workers=2)
+    stats = infer_refytb.run(model, tok, root, out_dir, size=SIZE, max_size=MAX_SIZE, decode_workers=2,
+                             use_graphs=use_graphs)
     assert stats["videos"] == 2 and stats["expressions"] == 4 and stats["frames"] == 12
     assert stats["cache_misses"] == 2 and stats["cache_hits"] == 2      # frames decoded once per video
     _, data = infer_refytb.load_meta(root)

@@ -103,6 +103,28 @@ def test_swin_b_configs_match_reference(gpu_model_b, golden, fixture):
     assert maxdiff(out["pred_boxes"], g["pred_boxes"]) < 1e-5
 
 
+def test_swin_s_matches_reference(golden, ref_shapes):
+    """Video-Swin-S backbone (18 blocks in stage 2; reference models/video_swin_transformer.py:749-763) through the
+    HIP path against the reference's own forward on a 180x320 clip."""
+    shapes = {k: v[0] for k, v in ref_shapes("s").items() if v[1].startswith("float")}
+    model, _, _ = S.build_model(S.default_args("video-swin-s", text_encoder_random_init=True))
+    model.load_state_dict(W.synthetic_state_dict(shapes, seed=2023), strict=False)
+    model = model.cuda().eval()
+    g = golden("full_forward_s.npz")
+    out = run_cfg(model, g["cfg"])
+    idx, masks = P.select_trajectory(out)
+    assert int(idx) == int(g["selected_query"])
+    assert maxdiff(masks, g["selected_masks"]) < 1e-3
+    assert maxdiff(sub(out["pred_masks"], 1 << 14), g["pred_masks_sub"]) < 1e-3
+    ours = (out["pred_masks"] > 0).cpu().numpy().reshape(-1)
+    ref_bits = np.unpackbits(g["pred_masks_signbits"])[:ours.size].astype(bool)
+    near = dict(zip(g["near_zero_idx"].tolist(), g["near_zero_val"].tolist()))
+    flipped = np.nonzero(ours != ref_bits)[0]
+    assert flipped.size <= 8 and all(i in near and abs(near[i]) < FLIP_WINDOW for i in flipped.tolist())
+    assert maxdiff(out["pred_cls"], g["pred_cls"]) < 1e-4
+    assert maxdiff(out["pred_boxes"], g["pred_boxes"]) < 1e-5
+
+
 def test_t10_temporal_shift_matches_reference(gpu_model, golden):
     g = golden("t10_forward.npz")
     out = run_cfg(gpu_model, g["cfg"])

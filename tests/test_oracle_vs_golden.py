@@ -158,6 +158,26 @@ def test_forward_full_config_matches_reference(golden, synthetic_sd):
     assert maxdiff(out["pred_boxes"], g["pred_boxes"]) < 1e-5
 
 
+def test_forward_swin_s_matches_reference(golden, ref_shapes):
+    """Video-Swin-S (depths 2/2/18/2, reference models/video_swin_transformer.py:749-763) on a 180x320 clip:
+    the oracle against the reference's own forward (full_forward_s.npz)."""
+    g = golden("full_forward_s.npz")
+    seed, T, H, Wd, L = (int(v) for v in g["cfg"])
+    shapes = {k: v[0] for k, v in ref_shapes("s").items() if v[1].startswith("float")}
+    sd = W.synthetic_state_dict(shapes, seed=2023)
+    out = O.soc_forward(sd, W.synthetic_clip(seed, T, H, Wd), W.synthetic_token_ids(seed, L),
+                        torch.ones(1, L, dtype=torch.long), (H, Wd), backbone="video-swin-s")
+    qi, masks = O.select_query(out)
+    assert qi == int(g["selected_query"])
+    assert maxdiff(masks, g["selected_masks"]) < 1e-3
+    bits = np.packbits((out["pred_masks"] > 0).numpy().reshape(-1))
+    flips = np.nonzero(np.unpackbits(bits ^ g["pred_masks_signbits"]))[0]
+    near = dict(zip(g["near_zero_idx"].tolist(), g["near_zero_val"].tolist()))
+    assert all(i in near and abs(near[i]) < 1e-4 for i in flips.tolist()), flips[:5]
+    assert maxdiff(out["pred_cls"], g["pred_cls"]) < 1e-4
+    assert maxdiff(out["pred_boxes"], g["pred_boxes"]) < 1e-5
+
+
 @pytest.mark.parametrize("tag,tol", [("g4", 1e-12), ("g30", 1e-12), ("gb", 2e-5)])
 def test_msda_backward_oracle_matches_reference_autograd(golden, tag, tol):
     """Gradients of the reference's ms_deform_attn_core_pytorch (tests/golden/make_goldens.py --only msda_grad)."""
