@@ -505,10 +505,11 @@ __device__ __forceinline__ void full_tile(const int qt, const int next_qt, float
     mx = fmaxf(mx, __shfl_xor(mx, 16));
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     // softmax is shift-invariant: p = 2^(s - c) / sum 2^(s - c) for ANY c.  The reference's c = row max only
-    // guards the exponent range, so when every row max of the wave is within +-64 (log2 units; f32 holds 2^+-126)
+    // guards the exponent range, so when every row max of the wave is within +-96 (log2 units; f32 holds 2^+-126,
+    // a row sums at most 400 terms and terms 2^24 below the row max do not matter)
     // c = 0 is used and the 100 subtractions are not executed -- VALU time is matrix-pipe time on this part.
     // Scores outside that range (possible with arbitrary weights) take the subtracting path.
-    if (!__all(fabsf(mx) < 64.f)) {
+    if (!__all(fabsf(mx) < 96.f)) {
         const f32x2 mx2 = (f32x2){mx, mx};
 #pragma unroll
         for (int t = 0; t < FNT; ++t) {
@@ -628,38 +629,42 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_full_kernel(
     };
 
     // ---- stage 0+1: every thread derives the metadata of the K/V rows it stages (8 threads x float4 per row)
-    // and issues their global loads at once; the bias column is fetched behind them.  K -> [slot][36],
-    // V -> transposed [dim][404].  ONE barrier for metadata, bias column, K and V.
+    // and issues their global loads at once -- all K rows first, then all V rows, then the bias column.
+    // K -> [slot][36], V -> transposed [dim][404], bias column and metadata go to LDS behind ONE barrier.
+    // (Holding V back until the first tile's Q.K^T has run -- loads issued early or late -- shortens this stage by
+    // 4k cycles and lengthens the tile phase by the same 4k: measured null, tools/experiments/README.md.)
+    const int spart = tid & 7;
+    constexpr int SROWS = THREADS / 8, SPASSES = (FNP + SROWS - 1) / SROWS;
+    float4 vv[SPASSES];
     {
-        const int part = tid & 7;
-        const float4 kbias = *reinterpret_cast<const float4*>(qkv_bias + p.C + head * HD + part * 4);
-        const float4 vbias = *reinterpret_cast<const float4*>(qkv_bias + 2 * p.C + head * HD + part * 4);
-        constexpr int ROWS = THREADS / 8, PASSES = (FNP + ROWS - 1) / ROWS;
-        float4 kv[PASSES], vv[PASSES];
+        const float4 kbias = *reinterpret_cast<const float4*>(qkv_bias + p.C + head * HD + spart * 4);
+        const float4 vbias = *reinterpret_cast<const float4*>(qkv_bias + 2 * p.C + head * HD + spart * 4);
+        float4 kv[SPASSES];
+        int sl[SPASSES];
         int differs = 0;
         int reg0, c0;
         (void)slot_info(0, reg0, c0);
 #pragma unroll
-        for (int it = 0; it < PASSES; ++it) {
-            const int i = it * ROWS + (tid >> 3);
+        for (int it = 0; it < SPASSES; ++it) {
+            const int i = it * SROWS + (tid >> 3);
             int s = -2, reg = 0, cc = 0;
             if (i < FN) {
                 s = slot_info(i, reg, cc);
                 differs |= (reg != reg0);
             }
-            if (i < FNP && part == 0) {
+            if (i < FNP && spart == 0) {
                 src[i] = s;
                 qcd[i] = cc | (reg << 16);
             }
-            if (s >= 0) {
-                const float* row = qkv + (long)s * C3 + head * HD + part * 4;
-                kv[it] = *reinterpret_cast<const float4*>(row + p.C);
-                vv[it] = *reinterpret_cast<const float4*>(row + 2 * p.C);
-            } else if (s == -1) {
-                kv[it] = kbias; vv[it] = vbias;
-            } else {
-                kv[it] = make_float4(0.f, 0.f, 0.f, 0.f); vv[it] = kv[it];
-            }
+            sl[it] = s;
+            if (s >= 0) kv[it] = *reinterpret_cast<const float4*>(qkv + (long)s * C3 + head * HD + spart * 4 + p.C);
+            else kv[it] = s == -1 ? kbias : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int it = 0; it < SPASSES; ++it) {
+            const int s = sl[it];
+            if (s >= 0) vv[it] = *reinterpret_cast<const float4*>(qkv + (long)s * C3 + head * HD + spart * 4 + 2 * p.C);
+            else vv[it] = s == -1 ? vbias : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         // bias column with the temporal offset fastest and REVERSED: word yx*15 + (14 - zz) holds
         // table[(zz*169 + yx)][head], so the 4 frames kz0..kz0+3 of a key group are 4 ascending words
@@ -674,21 +679,25 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_full_kernel(
         const int wave_differs = __any(differs);        // all 64 lanes vote (not inside the lane-0 branch)
         if (SHIFTED && lane == 0) wflag[wave] = wave_differs ? 1 : 0;
 #pragma unroll
+        for (int it = 0; it < SPASSES; ++it) {
+            const int i = it * SROWS + (tid >> 3);
+            if (i < FNP) *reinterpret_cast<float4*>(Ks + i * RS + spart * 4) = kv[it];
+        }
+#pragma unroll
         for (int it = 0; it < TPASS; ++it) {
             const int i = it * THREADS + tid;
             const int yx = i / 15, zz = i - yx * 15;
             if (i < TBL) Tb[yx * 15 + 14 - zz] = tv[it] * LOG2E;
         }
+    }
 #pragma unroll
-        for (int it = 0; it < PASSES; ++it) {
-            const int i = it * ROWS + (tid >> 3);
-            if (i < FNP) {
-                *reinterpret_cast<float4*>(Ks + i * RS + part * 4) = kv[it];
-                Vt[(part * 4 + 0) * RSV + i] = vv[it].x;
-                Vt[(part * 4 + 1) * RSV + i] = vv[it].y;
-                Vt[(part * 4 + 2) * RSV + i] = vv[it].z;
-                Vt[(part * 4 + 3) * RSV + i] = vv[it].w;
-            }
+    for (int it = 0; it < SPASSES; ++it) {
+        const int i = it * SROWS + (tid >> 3);
+        if (i < FNP) {
+            Vt[(spart * 4 + 0) * RSV + i] = vv[it].x;
+            Vt[(spart * 4 + 1) * RSV + i] = vv[it].y;
+            Vt[(spart * 4 + 2) * RSV + i] = vv[it].z;
+            Vt[(spart * 4 + 3) * RSV + i] = vv[it].w;
         }
     }
     STAMP(1);

@@ -139,7 +139,7 @@ def test_window_attention_baseline_stage_geometries(ops, H, W, nH, shift):
 
 @pytest.mark.parametrize("gain", [4.0, 9.0])
 def test_window_attention_large_scores(ops, gain):
-    """Scores far outside +-64 (log2 units): the softmax must take its max-subtracting path (the common path skips
+    """Scores far outside +-96 (log2 units): the softmax must take its max-subtracting path (the common path skips
     the subtraction, legal only while 2^score stays inside the f32 range) -- and rows mixing both regimes."""
     # scores are ~gain^2 * 6 here: one f32 ulp of a score of 500 is 3e-5, which the exponential turns into a
     # relative error of the same size -- the bound scales with the score magnitude, not with the output's
