@@ -22,7 +22,15 @@ constexpr int HD = 32;
 // (query, b, head) rows below this count use the block-per-row mapping (few queries, any Lk)
 constexpr long ROWS_BLOCK_PATH = 8192;
 
-// many queries: lane = query row, wave = 64 queries x one head, K/V wave-uniform (scalar cache)
+// many queries: lane = query row, wave = 64 queries x one head, K/V wave-uniform.
+// KV_LDS (Lk <= KV_LDS_MAX, e.g. the <= 32 words of the vlf blocks): the head's K and V rows are staged in LDS once
+// per workgroup with coalesced loads and the key loops read them as broadcast ds_reads -- with K/V fetched through
+// the scalar cache inside the key loops every wave sits through ~2 Lk dependent memory round trips, and since
+// all waves of the launch are resident at once that chain IS the kernel time (42 us for the 59 MB of the 28 800-row
+// level).  Otherwise (long key lists) K/V come through the scalar cache as SGPR operands.
+constexpr int KV_LDS_MAX = 64;
+
+template <bool KV_LDS>
 __global__ __launch_bounds__(256) void xattn_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
     const uint8_t* __restrict__ kpm, const float* __restrict__ amask, int mask_heads,
@@ -61,6 +69,19 @@ __global__ __launch_bounds__(256) void xattn_kernel(
     }
     const float* kb = k + b * k_bs + h * HD;  // + j*kstride, wave-uniform
     const float* vb = v + b * k_bs + h * HD;
+    long kvs = kstride;                        // row stride of the K/V image the key loops read
+    if (KV_LDS) {
+        extern __shared__ __attribute__((aligned(16))) float kv_s[];   // [2][Lk][HD]
+        float* Ksh = kv_s;
+        float* Vsh = kv_s + Lk * HD;
+        for (int idx = threadIdx.x; idx < Lk * 8; idx += 256) {
+            const int j = idx >> 3, c = idx & 7;
+            *reinterpret_cast<float4*>(Ksh + j * HD + c * 4) = *reinterpret_cast<const float4*>(kb + j * kstride + c * 4);
+            *reinterpret_cast<float4*>(Vsh + j * HD + c * 4) = *reinterpret_cast<const float4*>(vb + j * kstride + c * 4);
+        }
+        __syncthreads();
+        kb = Ksh; vb = Vsh; kvs = HD;
+    }
     const uint8_t* mp = kpm ? kpm + (long)b * Lk : nullptr;
     // additive float mask row of this query: [B or B*H, Lq, Lk] (torch attn_mask semantics)
     const float* am = amask ? amask + (((long)b * mask_heads + (mask_heads > 1 ? h : 0)) * Lq + qc) * Lk : nullptr;
@@ -69,7 +90,7 @@ __global__ __launch_bounds__(256) void xattn_kernel(
     float mx = -INFINITY;
     for (int j = k0; j < k1; ++j) {
         if (mp && mp[j]) continue;  // wave-uniform
-        const float* kr = kb + j * kstride;
+        const float* kr = kb + j * kvs;
         float s = am ? am[j] : 0.f;
 #pragma unroll
         for (int d = 0; d < HD; ++d) s += qr[d] * kr[d];
@@ -82,8 +103,8 @@ __global__ __launch_bounds__(256) void xattn_kernel(
     float l = 0.f;
     for (int j = k0; j < k1; ++j) {
         if (mp && mp[j]) continue;
-        const float* kr = kb + j * kstride;
-        const float* vr = vb + j * kstride;
+        const float* kr = kb + j * kvs;
+        const float* vr = vb + j * kvs;
         float s = am ? am[j] : 0.f;
 #pragma unroll
         for (int d = 0; d < HD; ++d) s += qr[d] * kr[d];
@@ -218,7 +239,11 @@ extern "C" int soc_xattn_f32(const float* q, const float* k, const float* v,
         return soc_check_launch();
     }
     dim3 grid(soc_ceil_div(Lq, 256), B * n_heads);
-    hipLaunchKernelGGL(xattn_kernel, grid, dim3(256), 0, st, q, k, v, key_pad_mask, attn_mask, attn_mask_heads,
-                       out, Lq, Lk, B, n_heads, scale, batch_first);
+    if (Lk <= KV_LDS_MAX)
+        hipLaunchKernelGGL(xattn_kernel<true>, grid, dim3(256), (size_t)2 * Lk * HD * sizeof(float), st, q, k, v,
+                           key_pad_mask, attn_mask, attn_mask_heads, out, Lq, Lk, B, n_heads, scale, batch_first);
+    else
+        hipLaunchKernelGGL(xattn_kernel<false>, grid, dim3(256), 0, st, q, k, v, key_pad_mask, attn_mask,
+                           attn_mask_heads, out, Lq, Lk, B, n_heads, scale, batch_first);
     return soc_check_launch();
 }

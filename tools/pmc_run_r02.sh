@@ -1,19 +1,38 @@
+#!/bin/bash
+# Round-2 evidence run on the MI355X box (gpurun): everything lands under gpurun_out/r02/, the summaries are then
+# copied into profiles/.  Counters are collected in their own passes (--pmc with --kernel-trace only), the program
+# directly after `--`.
 set -x
-cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/pmc2
+cd "$GRAFT_REPO_ROOT"
 export TMPDIR=/tmp
-P=gpurun_out/pmc2
-# ---- K2: plain vs encoder-form (one process runs both kernels)
-rocprofv3 --kernel-trace --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_READ_sum -d $P/k2_tcp -- python3 tools/k2_probe.py 12 > $P/k2_tcp.log 2>&1
-rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum -d $P/k2_tcc -- python3 tools/k2_probe.py 12 > $P/k2_tcc.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_INSTS_VALU SQ_INSTS_VMEM_RD -d $P/k2_sq -- python3 tools/k2_probe.py 12 > $P/k2_sq.log 2>&1
-rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum -d $P/k2_lat -- python3 tools/k2_probe.py 12 > $P/k2_lat.log 2>&1
-# ---- K1 per stage
+P=gpurun_out/r02
+mkdir -p $P
+# ---- (a) the headline command under the kernel tracer
+python3 bench.py > $P/bench_r02_n1.json 2> $P/bench_r02_n1.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $P/trace -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline > $P/trace_bench.json 2> $P/trace_bench.err
+T=$(ls $P/trace/*/*kernel_trace.csv | head -1)
+cp $(ls $P/trace/*/*kernel_stats.csv | head -1) $P/r02_bench_kernel_stats.csv
+python3 tools/analyze_trace.py $T --top 30 > $P/r02_forward_breakdown.txt
+python3 tools/timeline.py $T > $P/r02_timeline.txt
+# ---- (b) HBM traffic per kernel and clip: FETCH_SIZE and WRITE_SIZE in separate passes
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $P/pmc_fetch -- python3 bench.py --eager --steps 2 --warmup 1 --no-cpu-baseline > $P/pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $P/pmc_write -- python3 bench.py --eager --steps 2 --warmup 1 --no-cpu-baseline > $P/pmc_write.log 2>&1
+python3 tools/pmc_traffic.py $(ls $P/pmc_fetch/*/*counter_collection.csv | head -1) $(ls $P/pmc_write/*/*counter_collection.csv | head -1) > $P/r02_hbm_traffic_pmc.json
+# ---- (c) K1 per stage: matrix-pipe / VALU / LDS counters
 for st in 0 1 2 3; do
   rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY -d $P/k1s${st}_sq -- python3 tools/run_kernel.py k1s$st 12 > $P/k1s${st}_sq.log 2>&1
   rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_COEXEC_CYCLES GRBM_GUI_ACTIVE -d $P/k1s${st}_lds -- python3 tools/run_kernel.py k1s$st 12 > $P/k1s${st}_lds.log 2>&1
+  python3 tools/pmc_agg.py --kernels "k1_stage$st=win_attn3d_full_kernel" -- $P/k1s${st}_sq $P/k1s${st}_lds > $P/k1s${st}_counters.json
 done
-python3 tools/pmc_agg.py --kernels "k2_plain=msda_fwd_d32p4_kernel,true, false" "k2_encoder_form=msda_fwd_d32p4_kernel,true, true" -- $P/k2_tcp $P/k2_tcc $P/k2_sq $P/k2_lat > $P/k2_counters.json
-for st in 0 1 2 3; do python3 tools/pmc_agg.py --kernels "k1_stage$st=win_attn3d_full_kernel" -- $P/k1s${st}_sq $P/k1s${st}_lds > $P/k1s${st}_counters.json; done
-cat $P/k2_counters.json $P/k1s0_counters.json
-find $P -name "*_kernel_trace.csv" -size +2M -delete; du -sh $P
+# ---- (d) K2 (plain fused launch): where the gather is served from
+rocprofv3 --kernel-trace --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_READ_sum -d $P/k2_tcp -- python3 tools/k2_probe.py 12 plain > $P/k2_tcp.log 2>&1
+rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum -d $P/k2_tcc -- python3 tools/k2_probe.py 12 plain > $P/k2_tcc.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE -d $P/k2_sq -- python3 tools/k2_probe.py 12 plain > $P/k2_sq.log 2>&1
+python3 tools/pmc_agg.py --kernels "k2_fused=msda_fwd_d32p4_kernel" -- $P/k2_tcp $P/k2_tcc $P/k2_sq > $P/k2_counters.json
+python3 tools/k1_probe.py > $P/k1_probe_time.txt 2>&1
+python3 tools/k1_probe.py --stamps 0 2 > $P/k1_probe_stamps.txt 2>&1
+python3 tools/k2_probe.py 50 plain > $P/k2_probe_time.txt 2>&1
+# keep the merge small
+find $P -name "*kernel_trace.csv" -size +8M -delete
+find $P -name "*.db" -delete
+du -sh $P
