@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SOC_HIP_ABI_VERSION 2
+#define SOC_HIP_ABI_VERSION 3
 
 #define SOC_OK 0
 #define SOC_EINVAL (-1)       /* null pointer / non-positive dimension */
@@ -289,6 +289,20 @@ int soc_linear_small_multi_f32(const float* x, const float* x_add, int add_div, 
  */
 int soc_box_refine_f32(const float* delta, const float* ref, int ref_dim, const float* valid_ratios,
                        float* new_ref, float* ref_in, int N, int Q, int L, void* stream);
+
+/*
+ * K13 -- weight-stationary linear layer for the tall, short-K GEMMs of the Video-Swin blocks, with the LayerNorm
+ * in front and the residual add behind folded in (reference models/video_swin_transformer.py:219 norm1, :144-147
+ * qkv, :163-164 proj, :254-259 residual, :262-267 norm2 -> mlp.fc1 -> GELU -> mlp.fc2 -> residual; Mlp :24-37):
+ *   out[M, N] = act( LN(x)[M, K] . w[N, K]^T + bias ) + residual[M, N]
+ * ln_gamma / ln_beta NULL: no LayerNorm (ln_eps ignored); bias / residual may be NULL; act 0 none, 1 ReLU,
+ * 2 exact (erf) GELU as nn.GELU().  The weights are staged once per workgroup in LDS and the rows of x stream
+ * through in MFMA operand layout.  K in {96, 128, 192, 256, 384, 512} (LayerNorm: K <= 256), N % 16 == 0, 16-byte
+ * aligned pointers; otherwise SOC_EUNSUPPORTED (use the library GEMM).  out may alias residual.
+ */
+int soc_ws_linear_f32(const float* x, const float* ln_gamma, const float* ln_beta, float ln_eps, const float* w,
+                      const float* bias, const float* residual, float* out, long M, int N, int K, int act,
+                      void* stream);
 
 #ifdef __cplusplus
 }

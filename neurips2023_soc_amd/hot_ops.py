@@ -553,3 +553,44 @@ def linear_act_multi(x: Tensor, layers: Sequence[Tuple[Tensor, Optional[Tensor]]
                                             M, K, {"none": 0, "relu": 1, "gelu": 2}[act], _stream())
     _lib.check(code, "soc_linear_act_multi_f32")
     return outs
+
+
+WS_LINEAR_K = (96, 128, 192, 256, 384, 512)
+
+
+def ws_linear_supported(x: Tensor, weight: Tensor, has_ln: bool) -> bool:
+    """True when K13 takes linear(x, weight): CUDA fp32, K one of its widths (LayerNorm: K <= 256), N % 16 == 0."""
+    N, K = weight.shape
+    return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and K in WS_LINEAR_K
+            and N % 16 == 0 and (not has_ln or K <= 256) and x.shape[-1] == K)
+
+
+def ws_linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, ln: Optional[Tuple[Tensor, Tensor, float]] = None,
+              residual: Optional[Tensor] = None, act: str = "none") -> Tensor:
+    """K13: act(LN(x) @ weight.T + bias) + residual, every part optional; ln = (gamma, beta, eps).
+    x [..., K] -> [..., N]; residual has the output's shape."""
+    _need_gpu(x, weight, bias, residual, *(ln[:2] if ln else ()))
+    lib = _lib.load()
+    x, weight = _f32c(x), _f32c(weight)
+    N, K = weight.shape
+    M = x.numel() // K
+    out = torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=x.device)
+    if residual is not None:
+        residual = _f32c(residual)
+        if residual.shape != out.shape:
+            raise _lib.SocHipError(f"ws_linear: residual shape {tuple(residual.shape)} != output {tuple(out.shape)}")
+    g = be = None
+    eps = 0.0
+    if ln is not None:
+        g, be, eps = _f32c(ln[0]), _f32c(ln[1]), float(ln[2])
+    b = _f32c(bias) if bias is not None else None
+    code = {"none": 0, "relu": 1, "gelu": 2}[act]
+    work = 2.0 * M * N * K
+    with _timed("ws_linear", work):
+        rc = lib.soc_ws_linear_f32(x.data_ptr(), g.data_ptr() if g is not None else None,
+                                   be.data_ptr() if be is not None else None, eps, weight.data_ptr(),
+                                   b.data_ptr() if b is not None else None,
+                                   residual.data_ptr() if residual is not None else None, out.data_ptr(), M, N, K, code,
+                                   _stream())
+    _lib.check(rc, "soc_ws_linear_f32")
+    return out

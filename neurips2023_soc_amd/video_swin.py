@@ -99,9 +99,26 @@ class BasicLayer(nn.Module):
         self.downsample = None
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:  # [B,D,H,W,C] token-major throughout
-        """Every residual add is fused with the LayerNorm that consumes its result (K5):
-        x += attn -> norm2, x += mlp -> next block's norm1; same values as block-by-block."""
+        """Tall stages with a short channel width (stages 0-1 of every Video-Swin variant) run each block as four
+        K13 launches around K1 -- norm1 + qkv | K1 | proj + residual | norm2 + fc1 + GELU | fc2 + residual -- so no
+        LayerNorm-ed or GELU-ed copy of the token map is ever a separate pass.  Elsewhere every residual add is fused
+        with the LayerNorm that consumes its result (K5): x += attn -> norm2, x += mlp -> next block's norm1.  Same
+        values as block-by-block."""
         blocks = self.blocks
+        if self._weight_stationary(x):
+            for blk in blocks:
+                a = blk.attn
+                qkv = hot_ops.ws_linear(x, a.qkv.weight, a.qkv.bias, ln=(blk.norm1.weight, blk.norm1.bias, blk.norm1.eps))
+                o = hot_ops.window_attention3d(qkv, a.qkv.bias, a.relative_position_bias_table, a.num_heads,
+                                               a.window_size, blk.shift_size)
+                x = hot_ops.ws_linear(o, a.proj.weight, a.proj.bias, residual=x)
+                h = hot_ops.ws_linear(x, blk.mlp.fc1.weight, blk.mlp.fc1.bias,
+                                      ln=(blk.norm2.weight, blk.norm2.bias, blk.norm2.eps), act="gelu")
+                if hot_ops.ws_linear_supported(h, blk.mlp.fc2.weight, False):
+                    x = hot_ops.ws_linear(h, blk.mlp.fc2.weight, blk.mlp.fc2.bias, residual=x)
+                else:
+                    x = x + blk.mlp.fc2(h)
+            return x
         _, h = hot_ops.add_layernorm(x, None, blocks[0].norm1.weight, blocks[0].norm1.bias, blocks[0].norm1.eps)
         for i, blk in enumerate(blocks):
             a = blk.attn(h, blk.shift_size)
@@ -113,6 +130,14 @@ class BasicLayer(nn.Module):
             else:
                 x = x + m
         return x
+
+    def _weight_stationary(self, x: torch.Tensor) -> bool:
+        """K13 pays where the token map is tall and the weights of a layer fit a CU's LDS in a few column ranges."""
+        blk = self.blocks[0]
+        return (x.is_cuda and x.numel() // x.shape[-1] >= 16384
+                and hot_ops.ws_linear_supported(x, blk.attn.qkv.weight, True)
+                and hot_ops.ws_linear_supported(x, blk.attn.proj.weight, False)
+                and hot_ops.ws_linear_supported(x, blk.mlp.fc1.weight, True))
 
 
 class PatchMerging(nn.Module):

@@ -588,3 +588,48 @@ def test_linear_act_multi_with_add(ops):
     from neurips2023_soc_amd import fused
     a0, a1 = fused.linear_multi(dev(x), [(dev(w0), dev(b0), True), (dev(w1), None, True)], dev(pos))
     assert torch.equal(a0, o0) and torch.equal(a1, o1)
+
+
+# ------------------------------------------------------------------ K13 weight-stationary linear
+@pytest.mark.parametrize("M,K,N,ln,res,act,bias", [
+    (115200, 96, 288, True, False, "none", True),     # stage 0: norm1 + qkv
+    (115200, 96, 96, False, True, "none", True),      # proj + residual
+    (20000, 96, 384, True, False, "gelu", True),      # norm2 + fc1 + GELU
+    (20000, 384, 96, False, True, "none", True),      # fc2 + residual
+    (28800, 192, 576, True, False, "none", True),     # stage 1: W split over 3 column ranges
+    (5000, 192, 768, True, False, "gelu", True),
+    (3001, 128, 384, True, True, "relu", False),      # Swin-B width, ragged M, no bias, LN + residual together
+    (7, 256, 16, True, False, "none", True),          # fewer rows than one tile, single column tile
+    (1000, 512, 128, False, False, "gelu", True),
+    (0, 96, 96, False, False, "none", True),
+])
+def test_ws_linear_vs_torch(ops, M, K, N, ln, res, act, bias):
+    """K13 against the torch ops it replaces: layer_norm -> linear -> (GELU erf | ReLU) -> + residual.  The GELU uses
+    a 1.5e-7-accurate erf; everything else is plain fp32 with a different summation order."""
+    g = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=g) * 1.5 + 0.2
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g) if bias else None
+    gam, bet = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.1
+    r = torch.randn(M, N, generator=g) if res else None
+    got = ops.ws_linear(dev(x), dev(w), dev(b) if bias else None, (dev(gam), dev(bet), 1e-5) if ln else None,
+                        dev(r) if res else None, act)
+    assert got.shape == (M, N)
+    if M == 0:
+        return
+    h = torch.nn.functional.layer_norm(x.double(), (K,), gam.double(), bet.double(), 1e-5) if ln else x.double()
+    y = torch.nn.functional.linear(h, w.double(), b.double() if bias else None)
+    y = torch.nn.functional.gelu(y) if act == "gelu" else (y.relu() if act == "relu" else y)
+    if res:
+        y = y + r.double()
+    assert maxdiff(got, y) < 2e-5 * max(1.0, float(y.abs().max()))
+
+
+def test_ws_linear_rejects_unsupported(ops):
+    x = torch.zeros(32, 100).cuda()
+    assert not ops.ws_linear_supported(x, torch.zeros(96, 100).cuda(), False)          # K not a supported width
+    assert not ops.ws_linear_supported(torch.zeros(32, 384).cuda(), torch.zeros(96, 384).cuda(), True)   # LN needs K <= 256
+    with pytest.raises(RuntimeError):
+        ops.ws_linear(x, torch.zeros(96, 100).cuda())
+    with pytest.raises(RuntimeError):
+        ops.ws_linear(torch.zeros(32, 96), torch.zeros(96, 96))                        # CPU tensors: no fallback
