@@ -11,7 +11,7 @@ import sys
 GROUPS = collections.OrderedDict([
     ("win_attn3d", ("win_attn3d",)), ("msda_fwd", ("msda_fwd",)), ("xattn", ("xattn_",)), ("dyn_mask", ("dyn_mask",)),
     ("add_layernorm", ("add_layernorm",)), ("linear_small", ("linear_small",)), ("linear_act", ("gemm_nt_kernel",)),
-    ("groupnorm_tokens", ("gn_stats", "gn_apply")), ("patch_merge_layernorm", ("patch_merge",)),
+    ("groupnorm_tokens", ("gn_stats", "gn_apply")), ("patch_merge_layernorm", ("patch_merge",)), ("ws_linear", ("ws_linear_kernel",)),
     ("box_refine", ("box_refine",)),
 ])
 
