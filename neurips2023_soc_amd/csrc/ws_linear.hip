@@ -82,9 +82,15 @@ __global__ __launch_bounds__(THREADS, 2) void ws_linear_kernel(
             b4[j] = *reinterpret_cast<const float4*>(beta + 16 * j + 4 * kq);
         }
     }
+    // Work = (row tile, group of CT column tiles) units, dealt to the waves of this column range as CONTIGUOUS, equal
+    // shares (+-1 unit): whole tiles would leave 7200 tiles on 2048 waves at 4 rounds for 3.5 rounds of work.  A tile
+    // cut by a share boundary is loaded (and LayerNorm-ed) by both neighbours, each doing its part of the columns.
     const long ntiles = (M + 15) >> 4;
-    const long stride = (long)wg_per_split * (THREADS / 64);
-    long t = (long)wgi * (THREADS / 64) + wave;
+    const int gpt = nct / CT;                                   // groups per tile (the host picks CT | nct)
+    const long units = ntiles * gpt, nwaves = (long)wg_per_split * (THREADS / 64);
+    const long wv = (long)wgi * (THREADS / 64) + wave;
+    const long g0 = wv * units / nwaves, g1 = (wv + 1) * units / nwaves;
+    long t = g0 / gpt;
     float4 xn[PREFETCH ? KG : 1];
     auto load_rows = [&](long tile, float4 (&dst)[KG]) {
         const long m = min(tile * 16 + r, M - 1);
@@ -92,14 +98,16 @@ __global__ __launch_bounds__(THREADS, 2) void ws_linear_kernel(
 #pragma unroll
         for (int j = 0; j < KG; ++j) dst[j] = xp[4 * j];
     };
-    if (PREFETCH && t < ntiles) load_rows(t, reinterpret_cast<float4(&)[KG]>(xn));   // in flight behind the weight staging
+    if (PREFETCH && g0 < g1) load_rows(t, reinterpret_cast<float4(&)[KG]>(xn));   // in flight behind the weight staging
     __syncthreads();
-    for (; t < ntiles; t += stride) {
+    for (; t * gpt < g1; ++t) {
+        const int ct_lo = t * gpt < g0 ? (int)(g0 - t * gpt) * CT : 0;
+        const int ct_hi = (t + 1) * gpt > g1 ? (int)(g1 - t * gpt) * CT : nct;
         float4 xf[KG];
         if (PREFETCH) {
 #pragma unroll
             for (int j = 0; j < KG; ++j) xf[j] = xn[j];
-            if (t + stride < ntiles) load_rows(t + stride, reinterpret_cast<float4(&)[KG]>(xn));
+            if ((t + 1) * gpt < g1) load_rows(t + 1, reinterpret_cast<float4(&)[KG]>(xn));
         } else {
             load_rows(t, xf);
         }
@@ -142,7 +150,7 @@ __global__ __launch_bounds__(THREADS, 2) void ws_linear_kernel(
         };
         // CT column tiles at a time (the host picks a CT that divides the tile count): their MFMAs alternate
         // accumulators (no dependent-issue stalls); the accumulators start from the bias
-        for (int ct = 0; ct < nct; ct += CT) {
+        for (int ct = ct_lo; ct < ct_hi; ct += CT) {
             f32x4 acc[CT];
             const float4* wp = wimg + (ct * KG) * 64 + lane;
 #pragma unroll
@@ -223,6 +231,9 @@ int launch_one(const float* x, const float* gamma, const float* beta, float eps,
     const int nc = split_columns(N, K);
     if (nc == 0) return SOC_EUNSUPPORTED;
     const int nct = nc / 16;
+#ifdef WS_CT4
+    if (nct % 4 == 0) return launch_ct<K, ACT, HAS_LN, HAS_RES, 4>(x, gamma, beta, eps, w, bias, res, out, M, N, st);
+#endif
     if (nct % 3 == 0) return launch_ct<K, ACT, HAS_LN, HAS_RES, 3>(x, gamma, beta, eps, w, bias, res, out, M, N, st);
     if (nct % 2 == 0) return launch_ct<K, ACT, HAS_LN, HAS_RES, 2>(x, gamma, beta, eps, w, bias, res, out, M, N, st);
     return launch_ct<K, ACT, HAS_LN, HAS_RES, 1>(x, gamma, beta, eps, w, bias, res, out, M, N, st);
