@@ -39,11 +39,22 @@ def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libsoc_hip.so (no CPU fallback exists)")
-    cmd = [hipcc, *FLAGS, "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-o", LIB + ".tmp", *sources()]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True)
-    os.replace(LIB + ".tmp", LIB)
+    # one builder at a time (the ranks of a multi-GPU job all load the library): the others wait on the lock and
+    # then find the library fresh
+    import fcntl
+    with open(LIB + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not stale():
+                return LIB
+            tmp = f"{LIB}.{os.getpid()}.tmp"
+            cmd = [hipcc, *FLAGS, "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-o", tmp, *sources()]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True)
+            os.replace(tmp, LIB)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB
 
 

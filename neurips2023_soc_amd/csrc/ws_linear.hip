@@ -231,9 +231,6 @@ int launch_one(const float* x, const float* gamma, const float* beta, float eps,
     const int nc = split_columns(N, K);
     if (nc == 0) return SOC_EUNSUPPORTED;
     const int nct = nc / 16;
-#ifdef WS_CT4
-    if (nct % 4 == 0) return launch_ct<K, ACT, HAS_LN, HAS_RES, 4>(x, gamma, beta, eps, w, bias, res, out, M, N, st);
-#endif
     if (nct % 3 == 0) return launch_ct<K, ACT, HAS_LN, HAS_RES, 3>(x, gamma, beta, eps, w, bias, res, out, M, N, st);
     if (nct % 2 == 0) return launch_ct<K, ACT, HAS_LN, HAS_RES, 2>(x, gamma, beta, eps, w, bias, res, out, M, N, st);
     return launch_ct<K, ACT, HAS_LN, HAS_RES, 1>(x, gamma, beta, eps, w, bias, res, out, M, N, st);
