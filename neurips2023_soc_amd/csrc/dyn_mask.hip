@@ -43,6 +43,8 @@ __global__ __launch_bounds__(256) void dyn_mask_kernel(
     // blockIdx.z picks a slice of the frame's instances: with all Q per thread the launch has < 2 waves per
     // SIMD at the BASELINE config and the scalar parameter loads are fully exposed
     const int q_lo = blockIdx.z * q_per_block, q_hi = min(Q, q_lo + q_per_block);
+    // pix is even: a float2 store is aligned whenever inst*hw is, i.e. always for an even map (wave-uniform test)
+    const bool pair_store = (hw & 1) == 0;
     for (int q = q_lo; q < q_hi; ++q) {
         const int inst = t * Q + q;
         const float* __restrict__ P = params + (long)inst * NPARAM;  // wave-uniform
@@ -75,8 +77,8 @@ __global__ __launch_bounds__(256) void dyn_mask_kernel(
 #pragma unroll
         for (int c = 0; c < CH; ++c) r += W2[c] * h1[c];
         float* op = out + (long)inst * hw + pix;
-        if (live1 && ((((long)inst * hw + pix) & 1) == 0)) {
-            *reinterpret_cast<float2*>(op) = make_float2(r[0], r[1]);
+        if (pair_store) {
+            if (live1) *reinterpret_cast<float2*>(op) = make_float2(r[0], r[1]);
         } else {
             if (live0) op[0] = r[0];
             if (live1) op[1] = r[1];

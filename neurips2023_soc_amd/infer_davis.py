@@ -69,6 +69,32 @@ def run(model, tokenize: Tokenize, root: str, out_dir: str, rank: int = 0, world
     stats = {"videos": 0, "expressions": 0, "frames": 0, "seconds_input": 0.0, "seconds_model": 0.0}
     pending = []
     t0 = time.perf_counter()
+    # With graphs the clips stream through the software-pipelined replay (ClipInferencer.submit): a result arrives one
+    # submit late, so an annotator's label maps are merged once all its (object, chunk) results are in -- while the next
+    # annotator's clips already run.  Chunks are walked outermost so that clips of one length follow each other (a length
+    # change drains the pipeline); per (object, chunk) the forward is the same as in the object-major order of the
+    # reference (:199-246).
+    streaming = engine.use_graphs
+    waiting = []                # annotator jobs whose results are still arriving, oldest first
+
+    def place(res):
+        job, obj, ci = res["tag"]
+        job["got"][obj][ci] = res["mask_logits"].clone()        # a view of the graph's record: copy before the next submit
+        job["left"] -= 1
+
+    def merge_ready(writers, everything=False):
+        while waiting and (waiting[0]["left"] == 0):
+            job = waiting.pop(0)
+            t2 = time.perf_counter()
+            per_obj = torch.stack([torch.cat(chunks, 0) for chunks in job["got"]])
+            labels = hot_ops.upsample_merge_labels(per_obj, job["orig"]).cpu().numpy()   # [T,H0,W0]
+            stats["seconds_model"] += time.perf_counter() - t2    # waits for this annotator's forwards
+            os.makedirs(job["save_dir"], exist_ok=True)
+            for f in range(labels.shape[0]):
+                pending.append(writers.submit(save_label_map, labels[f], os.path.join(job["save_dir"], f"{f:05d}.png"),
+                                              palette))
+        assert not (everything and waiting), "results missing after the pipeline was drained"
+
     with ThreadPoolExecutor(max_workers=writer_workers) as writers:
         for vi, video in enumerate(todo):
             frames = data[video]["frames"]
@@ -78,30 +104,32 @@ def run(model, tokenize: Tokenize, root: str, out_dir: str, rank: int = 0, world
                 cache.prefetch(clip_io.frame_paths(img_folder, nxt, data[nxt]["frames"][:CLIP_LEN]))
             exp_ids = list(exps.keys())
             num_obj = len(exp_ids) // annotators
+            starts = list(range(0, len(frames), CLIP_LEN))
             for anno in range(annotators):
-                per_obj = []
-                orig = None
-                for obj in range(num_obj):
-                    text = exps[exp_ids[obj * annotators + anno]]["exp"]
-                    ids = tokenize(text).to(device)
-                    chunks = []
-                    for c0 in range(0, len(frames), CLIP_LEN):
-                        t1 = time.perf_counter()
-                        clip, orig = cache.get(clip_io.frame_paths(img_folder, video, frames[c0:c0 + CLIP_LEN]))
-                        stats["seconds_input"] += time.perf_counter() - t1
-                        chunks.append(engine(clip, ids)["mask_logits"].clone())   # [t,h,w]
-                    per_obj.append(torch.cat(chunks, 0))
-                    stats["expressions"] += 1
-                    stats["frames"] += len(frames)
-                t2 = time.perf_counter()
-                labels = hot_ops.upsample_merge_labels(torch.stack(per_obj), orig).cpu().numpy()   # [T,H0,W0]
-                stats["seconds_model"] += time.perf_counter() - t2    # waits for this annotator's forwards
-                save_dir = os.path.join(out_dir, f"anno_{anno}", video)
-                os.makedirs(save_dir, exist_ok=True)
-                for f in range(labels.shape[0]):
-                    pending.append(writers.submit(save_label_map, labels[f], os.path.join(save_dir, f"{f:05d}.png"),
-                                                  palette))
+                ids = [tokenize(exps[exp_ids[obj * annotators + anno]]["exp"]).to(device) for obj in range(num_obj)]
+                job = {"got": [[None] * len(starts) for _ in range(num_obj)], "left": num_obj * len(starts), "orig": None,
+                       "save_dir": os.path.join(out_dir, f"anno_{anno}", video)}
+                waiting.append(job)
+                for ci, c0 in enumerate(starts):
+                    t1 = time.perf_counter()
+                    clip, job["orig"] = cache.get(clip_io.frame_paths(img_folder, video, frames[c0:c0 + CLIP_LEN]))
+                    stats["seconds_input"] += time.perf_counter() - t1
+                    for obj in range(num_obj):
+                        if streaming:
+                            res = engine.submit(clip, ids[obj], (job, obj, ci))     # the PREVIOUS clip's result, or None
+                            if res is not None:
+                                place(res)
+                        else:
+                            job["got"][obj][ci] = engine(clip, ids[obj])["mask_logits"].clone()   # [t,h,w]
+                            job["left"] -= 1
+                    merge_ready(writers)
+                stats["expressions"] += num_obj
+                stats["frames"] += num_obj * len(frames)
             stats["videos"] += 1
+        if streaming:
+            for res in engine.drain():
+                place(res)
+        merge_ready(writers, everything=True)
         t_tail = time.perf_counter()
         for f in pending:
             f.result()

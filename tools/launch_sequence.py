@@ -1,0 +1,22 @@
+"""Ordered kernel launches of the last forward in a rocprofv3 --kernel-trace CSV (one line per launch).
+usage: python tools/launch_sequence.py <kernel_trace.csv>"""
+import csv
+import re
+import sys
+
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if "spin_kernel" not in r["Kernel_Name"]]
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+idx = [i for i, r in enumerate(rows) if "dyn_mask" in r["Kernel_Name"]]
+seg = rows[idx[-2] + 1: idx[-1] + 1]
+t0 = int(seg[0]["Start_Timestamp"])
+prev_end = t0
+for i, r in enumerate(seg):
+    n = r["Kernel_Name"]
+    n = re.sub(r"\(anonymous namespace\)::", "", n)
+    n = re.sub(r"^void ", "", n)
+    n = re.sub(r"at::native::", "", n)
+    m = re.match(r"(Cijk_\w+?_MT\d+x\d+x\d+)", n)
+    n = m.group(1) if m else n.split("(")[0][:70]
+    s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+    print(f"{i:4d} {(s - t0) / 1e3:9.1f} us  gap {(s - prev_end) / 1e3:6.1f}  dur {(e - s) / 1e3:7.1f}  grid {r['Grid_Size_X']:>8s}  {n}")
+    prev_end = max(prev_end, e)
