@@ -211,7 +211,20 @@ class VideoSwinTransformerBackbone(nn.Module):
         return out
 
 
-def resize_pad_mask(mask: torch.Tensor, size) -> torch.Tensor:
+_NO_PAD: Dict = {}
+
+
+def resize_pad_mask(mask: torch.Tensor, size, unpadded: bool = False) -> torch.Tensor:
+    """Padding mask [N,H,W] at a feature level's size (nearest, reference :716-722).  ``unpadded``: the caller vouches
+    that the mask is all-False, so the result depends on the geometry alone and is a cached constant (three launches
+    per level otherwise, on the critical path between the backbone and the fusion)."""
+    if unpadded:
+        key = (mask.shape[0], tuple(size), str(mask.device))
+        if key not in _NO_PAD:
+            if len(_NO_PAD) > 64:
+                _NO_PAD.clear()
+            _NO_PAD[key] = torch.zeros(mask.shape[0], *size, dtype=torch.bool, device=mask.device)
+        return _NO_PAD[key]
     return F.interpolate(mask[None].float(), size=size).to(torch.bool)[0]
 
 
@@ -226,7 +239,8 @@ class Backbone(nn.Module):
 
     def forward(self, tensor_list: NestedTensor, num_frames: int) -> Dict[str, NestedTensor]:
         xs = self.body(tensor_list.tensors, num_frames)
-        return {k: NestedTensor(x, resize_pad_mask(tensor_list.mask, x.shape[-2:])) for k, x in xs.items()}
+        unpadded = bool(getattr(tensor_list, "unpadded", False))
+        return {k: NestedTensor(x, resize_pad_mask(tensor_list.mask, x.shape[-2:], unpadded)) for k, x in xs.items()}
 
 
 class Joiner(nn.Sequential):
