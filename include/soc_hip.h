@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SOC_HIP_ABI_VERSION 3
+#define SOC_HIP_ABI_VERSION 4
 
 #define SOC_OK 0
 #define SOC_EINVAL (-1)       /* null pointer / non-positive dimension */
@@ -303,6 +303,30 @@ int soc_box_refine_f32(const float* delta, const float* ref, int ref_dim, const 
 int soc_ws_linear_f32(const float* x, const float* ln_gamma, const float* ln_beta, float ln_eps, const float* w,
                       const float* bias, const float* residual, float* out, long M, int N, int K, int act,
                       void* stream);
+
+/*
+ * K15 -- the cross-attention block of a deformable-decoder layer in one launch (reference
+ * models/deformable_transformer.py:335-341: tgt2 = cross_attn(with_pos_embed(tgt, query_pos), reference_points, src,
+ * ...); tgt = norm1(tgt + tgt2); MSDeformAttn.forward models/ops/modules/ms_deform_attn.py:79-117):
+ *   out = LayerNorm(tgt + output_proj(MSDeformAttn(tgt + query_pos, ref_points, value_proj(memory))))
+ * The 256-wide memory rows are sampled first and value_proj is applied to the sampled sums (value_proj is linear; the
+ * bias is weighted by the sum of the in-range tap coefficients), so the whole-memory value projection of the reference
+ * is never computed.  For few queries (one workgroup per (frame, query) row reads the four weight matrices).
+ *   tgt [N, Lq, 256]; query_pos [N, Lq, 256] (query_pos_per_frame != 0) or [Lq, 256] shared by the frames
+ *   ref_points [N, Lq, 4, ref_dim] (ref_dim 2 or 4, as soc_msda_fused_fwd_f32); memory [N, S, 256] (un-masked)
+ *   memory_pad_mask [N, S] uint8 + any_pad int32[1]: both NULL or both set (padded positions sample as 0)
+ *   w_off [256,256] b_off [256] sampling_offsets; w_att [128,256] b_att [128] attention_weights;
+ *   w_val / b_val value_proj; w_out / b_out output_proj; ln_gamma / ln_beta / ln_eps norm1;  out [N, Lq, 256]
+ * Built for d_model 256, 8 heads, 4 levels, 4 points (every shipped config); otherwise SOC_EUNSUPPORTED.
+ */
+int soc_decoder_cross_attn_f32(const float* tgt, const float* query_pos, int query_pos_per_frame,
+                               const float* ref_points, int ref_dim, const float* memory,
+                               const uint8_t* memory_pad_mask, const int32_t* any_pad, const int64_t* spatial_shapes,
+                               const int64_t* level_start_index, const float* w_off, const float* b_off,
+                               const float* w_att, const float* b_att, const float* w_val, const float* b_val,
+                               const float* w_out, const float* b_out, const float* ln_gamma, const float* ln_beta,
+                               float ln_eps, float* out, int N, int Lq, int S, int d_model, int n_heads, int n_levels,
+                               int n_points, void* stream);
 
 #ifdef __cplusplus
 }

@@ -83,10 +83,17 @@ class DeformableTransformerDecoderLayer(nn.Module):
                 pad_flag=None, value=None):
         tgt = _add_norm(tgt, self.self_attn(tgt, tgt, tgt, query_add=query_pos, key_add=query_pos,
                                             batch_first=True), self.norm2)
-        c, loc, w = self.cross_attn(tgt, reference_points, src, spatial_shapes, level_start_index,
-                                    src_padding_mask, pad_flag=pad_flag, return_sampling=False,
-                                    query_pos=query_pos, value=value)
-        tgt = _add_norm(tgt, c, self.norm1)
+        if (value is None and (src_padding_mask is None or pad_flag is not None)
+                and hot_ops.decoder_cross_attn_supported(tgt, self.cross_attn, src, reference_points)):
+            # K15: the whole block in one launch, value_proj applied to the sampled rows instead of the whole memory
+            tgt = hot_ops.decoder_cross_attn(tgt, query_pos, reference_points, src, spatial_shapes, level_start_index,
+                                             self.cross_attn, self.norm1, src_padding_mask, pad_flag)
+            loc = w = None
+        else:
+            c, loc, w = self.cross_attn(tgt, reference_points, src, spatial_shapes, level_start_index,
+                                        src_padding_mask, pad_flag=pad_flag, return_sampling=False,
+                                        query_pos=query_pos, value=value)
+            tgt = _add_norm(tgt, c, self.norm1)
         tgt = _add_norm(tgt, fused.apply(self.linear2, linear_relu(tgt, self.linear1)), self.norm3)
         return tgt, loc, w
 

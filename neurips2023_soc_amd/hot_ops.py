@@ -193,6 +193,55 @@ def msda_fused_forward(value: Tensor, spatial_shapes: Tensor, level_start_index:
     return out
 
 
+DECODER_XATTN_MAX_ROWS = 2048     # one workgroup per (frame, query) row re-reads 896 KB of weights: few rows only
+
+
+def decoder_cross_attn_supported(tgt: Tensor, cross_attn, memory: Tensor, reference_points: Tensor) -> bool:
+    """True when K15 covers this call (cross_attn: an MSDeformAttn module)."""
+    return (tgt.is_cuda and tgt.dtype == torch.float32 and memory.dtype == torch.float32
+            and cross_attn.d_model == 256 and cross_attn.n_heads == 8 and cross_attn.n_levels == 4
+            and cross_attn.n_points == 4 and reference_points.shape[-1] in (2, 4)
+            and tgt.shape[0] * tgt.shape[1] <= DECODER_XATTN_MAX_ROWS and memory.shape[1] * 256 < (1 << 31))
+
+
+def decoder_cross_attn(tgt: Tensor, query_pos: Tensor, reference_points: Tensor, memory: Tensor,
+                       spatial_shapes: Tensor, level_start_index: Tensor, cross_attn, norm,
+                       pad_mask: Optional[Tensor] = None, any_pad: Optional[Tensor] = None) -> Tensor:
+    """K15.  norm(tgt + cross_attn(tgt + query_pos, reference_points, memory)) for a deformable-decoder layer in one
+    launch: tgt [N,Lq,256], query_pos [N,Lq,256] or [Lq,256], reference_points [N,Lq,4,2|4], memory [N,S,256];
+    cross_attn: MSDeformAttn (sampling_offsets, attention_weights, value_proj, output_proj), norm: nn.LayerNorm."""
+    _need_gpu(tgt, query_pos, reference_points, memory, spatial_shapes, level_start_index, pad_mask, any_pad)
+    lib = _lib.load()
+    tgt, reference_points, memory = _f32c(tgt), _f32c(reference_points), _f32c(memory)
+    N, Lq, C = tgt.shape
+    if query_pos.dim() == 3 and query_pos.stride(0) == 0:
+        query_pos = query_pos[0]                      # an expanded [Lq,256] embedding
+    query_pos = _f32c(query_pos)
+    per_frame = 1 if query_pos.dim() == 3 else 0
+    if query_pos.shape[-2:] != (Lq, C) or (per_frame and query_pos.shape[0] != N):
+        raise _lib.SocHipError(f"decoder_cross_attn: query_pos {tuple(query_pos.shape)} does not match tgt {tuple(tgt.shape)}")
+    S = memory.shape[1]
+    pm_ptr = ap_ptr = None
+    if pad_mask is not None:
+        pm = _as_u8(pad_mask)
+        if any_pad is None or any_pad.dtype != torch.int32:
+            raise _lib.SocHipError("decoder_cross_attn: pad_mask needs an int32 any_pad flag tensor")
+        pm_ptr, ap_ptr = pm.data_ptr(), any_pad.data_ptr()
+    ca = cross_attn
+    ws = [_f32c(t) for t in (ca.sampling_offsets.weight, ca.sampling_offsets.bias, ca.attention_weights.weight,
+                             ca.attention_weights.bias, ca.value_proj.weight, ca.value_proj.bias,
+                             ca.output_proj.weight, ca.output_proj.bias, norm.weight, norm.bias)]
+    out = torch.empty_like(tgt)
+    with _timed("decoder_cross_attn", (tgt.numel() * 2 + sum(w.numel() for w in ws) * N * Lq) * 4):
+        code = lib.soc_decoder_cross_attn_f32(
+            tgt.data_ptr(), query_pos.data_ptr(), per_frame, reference_points.data_ptr(), reference_points.shape[-1],
+            memory.data_ptr(), pm_ptr, ap_ptr, spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+            *[w.data_ptr() for w in ws], float(norm.eps), out.data_ptr(), N, Lq, S, C, ca.n_heads, ca.n_levels,
+            ca.n_points, _stream())
+    _lib.check(code, "soc_decoder_cross_attn_f32")
+    return out
+
+
 def clamp_window(size: Sequence[int], window: Sequence[int], shift: Sequence[int]):
     """get_window_size of the reference (models/video_swin_transformer.py:71-84)."""
     w, s = list(window), list(shift)

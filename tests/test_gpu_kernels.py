@@ -310,6 +310,79 @@ def test_msda_fused_vs_oracle(ops, N, Lq, rd, padding):
         assert maxdiff(got0, O.msda_fused_core(value, shapes, lsi, ref, off, logits, None)) < 3e-5
 
 
+# ------------------------------------------------------------------ K15 decoder cross-attention block
+@pytest.mark.parametrize("N,Lq,rd,padding,shared_pos", [(8, 20, 4, False, True), (8, 20, 2, False, True),
+                                                        (3, 7, 4, True, False), (2, 33, 2, True, True)])
+def test_decoder_cross_attn_vs_oracle(ops, N, Lq, rd, padding, shared_pos):
+    """norm1(tgt + output_proj(MSDA(tgt + pos, ref, value_proj(memory)))) (reference deformable_transformer.py:335-341)
+    in f64 on the CPU, projecting the whole memory like the reference, against the sample-then-project launch."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(N * 1000 + Lq * 10 + rd)
+    big = Lq == 20
+    shapes = torch.tensor([[45, 80], [23, 40], [12, 20], [6, 10]]) if big else torch.tensor([[9, 7], [5, 4], [3, 2], [1, 1]])
+    lsi = torch.cat((shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]))
+    S, M, C = int(shapes.prod(1).sum()), 8, 256
+
+    def rnd(*shape, scale=1.0):
+        return torch.randn(*shape, generator=g) * scale
+
+    tgt, memory = rnd(N, Lq, C), rnd(N, S, C)
+    qpos = rnd(Lq, C) if shared_pos else rnd(N, Lq, C)
+    ref = torch.rand(N, Lq, 4, rd, generator=g)
+    if rd == 4:
+        ref[..., 2:] *= 0.5
+    w_off, b_off = rnd(256, C, scale=0.05), rnd(256, scale=2.0)
+    w_att, b_att = rnd(128, C, scale=0.06), rnd(128)
+    w_val, b_val = rnd(C, C, scale=0.06), rnd(C, scale=0.5)
+    w_out, b_out = rnd(C, C, scale=0.06), rnd(C, scale=0.5)
+    gamma, beta = 1 + rnd(C, scale=0.1), rnd(C, scale=0.1)
+    pad = (torch.rand(N, S, generator=g) < 0.3) if padding else None
+
+    d = torch.float64
+    qv = (tgt + qpos).to(d)
+    off = F.linear(qv, w_off.to(d), b_off.to(d)).view(N, Lq, M, 4, 4, 2)
+    logits = F.linear(qv, w_att.to(d), b_att.to(d)).view(N, Lq, M, 16)
+    value = F.linear(memory.to(d), w_val.to(d), b_val.to(d)).view(N, S, M, 32)
+    sampled = O.msda_fused_core(value, shapes, lsi, ref.to(d), off, logits, pad)
+    want = F.layer_norm(tgt.to(d) + F.linear(sampled, w_out.to(d), b_out.to(d)), (C,), gamma.to(d), beta.to(d), 1e-5)
+
+    class Lin:
+        def __init__(self, w, b):
+            self.weight, self.bias = dev(w), dev(b)
+
+    class CA:
+        d_model, n_heads, n_levels, n_points = 256, 8, 4, 4
+        sampling_offsets, attention_weights = Lin(w_off, b_off), Lin(w_att, b_att)
+        value_proj, output_proj = Lin(w_val, b_val), Lin(w_out, b_out)
+
+    class Norm:
+        weight, bias, eps = dev(gamma), dev(beta), 1e-5
+
+    flag = dev(pad.any().to(torch.int32).reshape(1)) if padding else None
+    assert ops.decoder_cross_attn_supported(dev(tgt), CA, dev(memory), dev(ref))
+    got = ops.decoder_cross_attn(dev(tgt), dev(qpos), dev(ref), dev(memory), dev(shapes), dev(lsi), CA, Norm,
+                                 dev(pad) if padding else None, flag)
+    assert got.shape == (N, Lq, C)
+    assert maxdiff(got, want.float()) < 5e-5
+    # an expanded [Lq,C] embedding (what the decoder passes) is the shared form
+    if shared_pos:
+        got2 = ops.decoder_cross_attn(dev(tgt), dev(qpos).unsqueeze(0).expand(N, -1, -1), dev(ref), dev(memory),
+                                      dev(shapes), dev(lsi), CA, Norm, dev(pad) if padding else None, flag)
+        assert torch.equal(got2, got)
+
+
+def test_decoder_cross_attn_rejects_unsupported(ops):
+    lib = __import__("neurips2023_soc_amd._lib", fromlist=["load"]).load()
+    z = torch.zeros(4096, device="cuda")
+    i64 = torch.zeros(8, dtype=torch.long, device="cuda")
+    args = [z.data_ptr(), z.data_ptr(), 0, z.data_ptr(), 2, z.data_ptr(), None, None, i64.data_ptr(), i64.data_ptr()] + \
+           [z.data_ptr()] * 10 + [1e-5, z.data_ptr()]
+    assert lib.soc_decoder_cross_attn_f32(*args, 1, 1, 4, 128, 8, 4, 4, None) == -2      # d_model
+    assert lib.soc_decoder_cross_attn_f32(*args, 1, 1, 4, 256, 8, 4, 8, None) == -2      # points
+    assert lib.soc_decoder_cross_attn_f32(*args, 0, 5, 4, 256, 8, 4, 4, None) == 0       # empty
+    assert lib.soc_decoder_cross_attn_f32(*args, -1, 5, 4, 256, 8, 4, 4, None) == -1
+
+
 # ------------------------------------------------------------------ K6 fused upsample + threshold
 @pytest.mark.parametrize("T,h,w,H0,W0", [(8, 90, 160, 720, 1280), (3, 63, 75, 250, 300), (1, 5, 7, 33, 50),
                                          (2, 90, 160, 360, 640), (1, 9, 9, 9, 9), (0, 4, 4, 8, 8)])

@@ -1,0 +1,72 @@
+"""hipGraph replay time of the pieces of one clip forward at the BASELINE config (forks as in the product path):
+backbone (text || Video-Swin), fusion + deformable encoder, the encoder alone, the tail -- and of the whole head.
+usage: python tools/head_probe.py [reps]"""
+import sys
+
+import torch
+
+sys.path.insert(0, ".")
+import neurips2023_soc_amd as S  # noqa: E402
+from neurips2023_soc_amd import weights as W  # noqa: E402
+from neurips2023_soc_amd.nested_tensor import NestedTensor  # noqa: E402
+
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+T, H, Wd, L = 8, 360, 640, 10
+model, _, _ = S.build_model(S.default_args(text_encoder_random_init=True))
+W.load_synthetic(model, 2023)
+model = model.cuda().eval()
+clip = W.synthetic_clip(1, T, H, Wd).cuda().view(T, 1, 3, H, Wd)
+pad = torch.zeros(T, 1, H, Wd, dtype=torch.bool, device="cuda")
+ids = W.synthetic_token_ids(1, L).cuda().view(1, L)
+attn = torch.ones_like(ids)
+targets = [[{"size": (H, Wd)}] for _ in range(T)]
+
+
+def backbone():
+    return model.forward_backbone(NestedTensor(clip.clone(), pad.clone(), unpadded=True), None,
+                                  {"input_ids": ids, "attention_mask": attn})
+
+
+def capture(fn):
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            out = fn()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = fn()
+    return g, out
+
+
+def time_ms(g):
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        g.replay()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps
+
+
+with torch.no_grad():
+    g_b, sa = capture(backbone)
+    print(f"backbone (text || Video-Swin)      {time_ms(g_b):7.3f} ms")
+    g_f, sb = capture(lambda: model.forward_fuse_encode(sa))
+    print(f"fusion + deformable encoder        {time_ms(g_f):7.3f} ms")
+    g_h, _ = capture(lambda: model.forward_fuse_encode(backbone()))
+    print(f"head = backbone + fusion + encoder {time_ms(g_h):7.3f} ms")
+    g_t, _ = capture(lambda: model.forward_tail(sb, targets))
+    print(f"tail (FPN || decoder, VOC, heads)  {time_ms(g_t):7.3f} ms")
+    g_t2, _ = capture(lambda: model.forward_tail(sb, targets, fork=False))
+    print(f"tail on one stream                 {time_ms(g_t2):7.3f} ms")
+    tr = model.transformer
+    ctx = sb["ctx"]
+    memory, spatial_shapes, level_start, ratios, mask, pad_flag, shapes = ctx
+    const = tr._unpadded_constants(tuple(shapes), memory.shape[0], sa["pos"][-3:] + [None], memory.device) \
+        if False else None
