@@ -328,6 +328,21 @@ int soc_decoder_cross_attn_f32(const float* tgt, const float* query_pos, int que
                                float ln_eps, float* out, int N, int Lq, int S, int d_model, int n_heads, int n_levels,
                                int n_points, void* stream);
 
+/*
+ * K16 -- up to three 256-wide linear layers on few rows, optionally closed by residual add + LayerNorm, in one launch:
+ *   h = x (+ x_add, rows broadcast as (m / add_div) % add_mod);  h = relu(h w[i]^T + bias[i]) for i < n_layers - 1;
+ *   y = h w[last]^T + bias[last]   ([n_out, 256], n_out <= 256);
+ *   out = y (+ residual)                          when ln_gamma == NULL
+ *   out = LayerNorm(residual + y; gamma, beta)    otherwise (n_out == 256; residual may be NULL)
+ * Replaces MLP.forward of bbox_embed / controller (reference models/soc.py:552-564, 3 Linear + ReLU) and the
+ * out_proj -> residual -> LayerNorm tails of the decoder's self-attention (models/deformable_transformer.py:330-334)
+ * and of VOC's attention layers (models/voc.py:44-48,84-94).  K (input and hidden width) must be 256, n_layers <= 3;
+ * otherwise SOC_EUNSUPPORTED.  One workgroup per row: meant for M <= a few hundred rows.
+ */
+int soc_row_mlp_f32(const float* x, const float* x_add, int add_div, int add_mod, int n_layers, const float* const* w,
+                    const float* const* bias, int n_out, const float* residual, const float* ln_gamma,
+                    const float* ln_beta, float ln_eps, float* out, int M, int K, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

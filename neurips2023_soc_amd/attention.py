@@ -31,11 +31,13 @@ class HipMultiheadAttention(nn.Module):
     def forward(self, query: torch.Tensor, key: torch.Tensor, value: torch.Tensor,
                 key_padding_mask: Optional[torch.Tensor] = None, query_add: Optional[torch.Tensor] = None,
                 key_add: Optional[torch.Tensor] = None, batch_first: bool = False,
-                attn_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+                attn_mask: Optional[torch.Tensor] = None, post_norm: Optional[nn.LayerNorm] = None) -> torch.Tensor:
         """attention(query + query_add, key + key_add, value): the *_add terms are the positional
         embeddings the reference adds before calling nn.MultiheadAttention (with_pos_embed).
         batch_first: tensors are [B,L,E] instead of nn.MultiheadAttention's [L,B,E].
-        attn_mask: additive float mask as in nn.MultiheadAttention ([Lq,Lk], [B,Lq,Lk] or [B*heads,Lq,Lk])."""
+        attn_mask: additive float mask as in nn.MultiheadAttention ([Lq,Lk], [B,Lq,Lk] or [B*heads,Lq,Lk]).
+        post_norm: return post_norm(query + attention(...)) -- the post-norm residual every caller on the query chain
+        applies next -- with out_proj, the add and the LayerNorm in one launch (K16) when the rows are few."""
         if self.training:
             raise RuntimeError("HipMultiheadAttention is inference-only (no backward kernel)")
         E = self.embed_dim
@@ -65,4 +67,10 @@ class HipMultiheadAttention(nn.Module):
         else:
             o = hot_ops.mha_core(q, k, v, self.num_heads, key_padding_mask, batch_first=batch_first,
                                  attn_mask=attn_mask)
-        return fused.apply(self.out_proj, o)
+        if post_norm is None:
+            return fused.apply(self.out_proj, o)
+        if o.shape == query.shape and hot_ops.row_mlp_supported(o, [self.out_proj.weight], has_ln=True):
+            return hot_ops.row_mlp(o, [(self.out_proj.weight, self.out_proj.bias)], residual=query,
+                                   ln=(post_norm.weight, post_norm.bias, post_norm.eps))
+        return hot_ops.add_layernorm(query, fused.apply(self.out_proj, o), post_norm.weight, post_norm.bias,
+                                     post_norm.eps, return_sum=False)[1]

@@ -21,15 +21,17 @@
 // A dot-product phase gives each wave 16 output rows: 16 coalesced 1-KB weight-row loads in flight per wave, the 16 x 64
 // partial products reduced by a transposing butterfly (17 cross-lane moves instead of 96).
 #include "soc_common.h"
+#include "row_ops.h"
 
 namespace {
 
-constexpr int DM = 256;       // d_model
+constexpr int DM = ROW_DM;    // d_model
 constexpr int NH = 8;         // heads
 constexpr int NLV = 4;        // levels
 constexpr int NPT = 4;        // points
-constexpr int THREADS = 1024;
-constexpr int NWAVES = THREADS / 64;
+// 16 waves x 16 weight rows in flight.  A 4-wave / 8-row build with <= 80 registers per lane (workgroups that fit beside
+// another clip's chip-filling kernels) measured the same inside the software pipeline (8.76 vs 8.78 ms per clip over
+// 3 x 150 clips, tools/experiments/README.md) and is not built.
 
 struct DecXArgs {
     const float* tgt;        // [N, Lq, 256]
@@ -52,54 +54,9 @@ struct DecXArgs {
     int N, Lq, S;
 };
 
-// v[i] (i < 16) of every lane -> sum over the 64 lanes of v[idx], idx = bits (5,4,3,2) of the lane id read as a 4-bit
-// number (bit 5 the most significant); every lane of a quad ends up with the same value.
-__device__ __forceinline__ float reduce16(float (&v)[16], const int lane) {
-    const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8, b2 = lane & 4;
-    float a[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const float send = b5 ? v[i] : v[i + 8];
-        const float keep = b5 ? v[i + 8] : v[i];
-        a[i] = keep + __shfl_xor(send, 32);
-    }
-    float b[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float send = b4 ? a[i] : a[i + 4];
-        const float keep = b4 ? a[i + 4] : a[i];
-        b[i] = keep + __shfl_xor(send, 16);
-    }
-    float c[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const float send = b3 ? b[i] : b[i + 2];
-        const float keep = b3 ? b[i + 2] : b[i];
-        c[i] = keep + __shfl_xor(send, 8);
-    }
-    float d = (b2 ? c[1] : c[0]) + __shfl_xor(b2 ? c[0] : c[1], 4);
-    d += __shfl_xor(d, 2);
-    d += __shfl_xor(d, 1);
-    return d;
-}
-
-// dst[j0 + i] = dot(W[j0 + i, 0:256], x) + bias[j0 + i] * bscale for i < 16; x4 = x[4*lane .. 4*lane+3]
-__device__ __forceinline__ void matvec16(const float* __restrict__ W, const float* __restrict__ bias, const float bscale,
-                                         const int j0, const float4 x4, float* dst, const int lane) {
-    float4 w[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) w[i] = reinterpret_cast<const float4*>(W + (long)(j0 + i) * DM)[lane];
-    float v[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) v[i] = (w[i].x * x4.x + w[i].y * x4.y) + (w[i].z * x4.z + w[i].w * x4.w);
-    const float r = reduce16(v, lane);
-    if ((lane & 3) == 0) {
-        const int idx = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
-        dst[j0 + idx] = r + bias[j0 + idx] * bscale;
-    }
-}
-
+template <int THREADS, int R>
 __global__ __launch_bounds__(THREADS) void dec_cross_attn_kernel(const DecXArgs a) {
+    constexpr int NWAVES = THREADS / 64;
     __shared__ __attribute__((aligned(16))) float qv[DM];            // tgt + pos
     __shared__ __attribute__((aligned(16))) float offlog[DM + 128];  // 256 raw offsets, then 128 raw logits
     __shared__ float tcoef[NH][64];
@@ -121,9 +78,9 @@ __global__ __launch_bounds__(THREADS) void dec_cross_attn_kernel(const DecXArgs 
     // ---- A: 384 outputs = 24 groups of 16 rows over 16 waves
     {
         const float4 x4 = reinterpret_cast<const float4*>(qv)[lane];
-        for (int g = wave; g < 24; g += NWAVES) {
-            if (g < 16) matvec16(a.w_off, a.b_off, 1.f, g * 16, x4, offlog, lane);
-            else matvec16(a.w_att, a.b_att, 1.f, (g - 16) * 16, x4, offlog + DM, lane);
+        for (int g = wave; g < 384 / R; g += NWAVES) {
+            if (g < 256 / R) matvec_rows<R>(a.w_off, a.b_off, 1.f, g * R, 256, x4, offlog, lane, 0);
+            else matvec_rows<R>(a.w_att, a.b_att, 1.f, g * R - 256, 128, x4, offlog + DM, lane, 0);
         }
     }
     __syncthreads();
@@ -188,12 +145,12 @@ __global__ __launch_bounds__(THREADS) void dec_cross_attn_kernel(const DecXArgs 
     }
     __syncthreads();
 
-    // ---- C: wave (m, half): 32 taps of 1-KB memory rows, one float4 per lane
-    {
-        const int m = wave >> 1, half = wave & 1;
+    // ---- C: unit (m, half): 32 taps of 1-KB memory rows, one float4 per lane; 16 units over the waves
+    for (int u = wave; u < 16; u += NWAVES) {
+        const int m = u >> 1, half = u & 1;
         const float4* mem = reinterpret_cast<const float4*>(a.memory + (long)n * a.S * DM) + lane;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 16
+#pragma unroll R
         for (int t = 0; t < 32; ++t) {
             const float c = tcoef[m][half * 32 + t];
             const float4 r = mem[(long)trow[m][half * 32 + t] * (DM / 4)];
@@ -203,20 +160,20 @@ __global__ __launch_bounds__(THREADS) void dec_cross_attn_kernel(const DecXArgs 
     }
     __syncthreads();
 
-    // ---- D: wave w -> head w >> 1, output rows 16 w .. 16 w + 15 of value_proj
-    {
-        const int m = wave >> 1;
+    // ---- D: value_proj rows j0 .. j0 + R - 1 belong to head j0 / 32
+    for (int g = wave; g < 256 / R; g += NWAVES) {
+        const int m = (g * R) >> 5;
         const float4 s0 = reinterpret_cast<const float4*>(part[0][m])[lane];
         const float4 s1 = reinterpret_cast<const float4*>(part[1][m])[lane];
         const float4 x4 = make_float4(s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w);
-        matvec16(a.w_val, a.b_val, csum[m], wave * 16, x4, vproj, lane);
+        matvec_rows<R>(a.w_val, a.b_val, csum[m], g * R, 256, x4, vproj, lane, 0);
     }
     __syncthreads();
 
     // ---- E: output_proj, residual, LayerNorm
     {
         const float4 x4 = reinterpret_cast<const float4*>(vproj)[lane];
-        matvec16(a.w_out, a.b_out, 1.f, wave * 16, x4, oproj, lane);
+        for (int g = wave; g < 256 / R; g += NWAVES) matvec_rows<R>(a.w_out, a.b_out, 1.f, g * R, 256, x4, oproj, lane, 0);
     }
     __syncthreads();
     float mean = 0.f, x = 0.f;
@@ -271,6 +228,6 @@ extern "C" int soc_decoder_cross_attn_f32(const float* tgt, const float* query_p
     a.w_off = w_off; a.b_off = b_off; a.w_att = w_att; a.b_att = b_att; a.w_val = w_val; a.b_val = b_val;
     a.w_out = w_out; a.b_out = b_out; a.gamma = ln_gamma; a.beta = ln_beta; a.eps = ln_eps; a.out = out;
     a.N = N; a.Lq = Lq; a.S = S;
-    hipLaunchKernelGGL(dec_cross_attn_kernel, dim3(N * Lq), dim3(THREADS), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL((dec_cross_attn_kernel<1024, 16>), dim3(N * Lq), dim3(1024), 0, (hipStream_t)stream, a);
     return soc_check_launch();
 }

@@ -81,8 +81,8 @@ class DeformableTransformerDecoderLayer(nn.Module):
 
     def forward(self, tgt, query_pos, reference_points, src, spatial_shapes, level_start_index, src_padding_mask=None,
                 pad_flag=None, value=None):
-        tgt = _add_norm(tgt, self.self_attn(tgt, tgt, tgt, query_add=query_pos, key_add=query_pos,
-                                            batch_first=True), self.norm2)
+        tgt = self.self_attn(tgt, tgt, tgt, query_add=query_pos, key_add=query_pos, batch_first=True,
+                             post_norm=self.norm2)
         if (value is None and (src_padding_mask is None or pad_flag is not None)
                 and hot_ops.decoder_cross_attn_supported(tgt, self.cross_attn, src, reference_points)):
             # K15: the whole block in one launch, value_proj applied to the sampled rows instead of the whole memory

@@ -133,7 +133,13 @@ class PipelinedClipGraph:
         return self.model.forward_fuse_encode(sa, fork=fork)
 
     def _tail(self, sb, fork: bool):
-        out = self.model.forward_tail(sb, self.targets, fork=fork)
+        # the tail runs beside another clip's head, which pays for the tail's CU time and not for its launch count: the
+        # query chain keeps K7's small workgroups here (hot_ops.row_chain_fusion)
+        prev, hot_ops.row_chain_fusion = hot_ops.row_chain_fusion, False
+        try:
+            out = self.model.forward_tail(sb, self.targets, fork=fork)
+        finally:
+            hot_ops.row_chain_fusion = prev
         idx, masks = P.select_trajectory(out)
         CP.pack_record(self.record, idx, out["pred_cls"][:, 0, :, 0], masks)
 

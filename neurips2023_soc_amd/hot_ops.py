@@ -193,6 +193,12 @@ def msda_fused_forward(value: Tensor, spatial_shapes: Tensor, level_start_index:
     return out
 
 
+# K16 fuses 2-3 dependent launches of the query chain into one 16-wave workgroup per row: fewer launches and less
+# latency for a chain that owns the GPU, but more CU time than K7's small workgroups.  A chain that runs beside another
+# clip's chip-filling kernels (graph_runner.PipelinedClipGraph's tail) is charged for CU time, not for launches, and
+# switches it off (measured 8.70 vs 8.76 ms per clip).
+row_chain_fusion = True
+
 DECODER_XATTN_MAX_ROWS = 2048     # one workgroup per (frame, query) row re-reads 896 KB of weights: few rows only
 
 
@@ -239,6 +245,62 @@ def decoder_cross_attn(tgt: Tensor, query_pos: Tensor, reference_points: Tensor,
             *[w.data_ptr() for w in ws], float(norm.eps), out.data_ptr(), N, Lq, S, C, ca.n_heads, ca.n_levels,
             ca.n_points, _stream())
     _lib.check(code, "soc_decoder_cross_attn_f32")
+    return out
+
+
+ROW_MLP_MAX_ROWS = 2048     # one workgroup per row re-reads the layers' weights: few rows only
+
+
+def row_mlp_supported(x: Tensor, weights: Sequence[Tensor], has_ln: bool = False) -> bool:
+    """True when K16 covers `x -> Linear(+ReLU) ... -> Linear` over these weight matrices."""
+    if not row_chain_fusion:
+        return False
+    if not (x.is_cuda and x.dtype == torch.float32 and 1 <= len(weights) <= 3 and x.shape[-1] == 256
+            and 0 < x.numel() // 256 <= ROW_MLP_MAX_ROWS):
+        return False
+    if any(w.shape[1] != 256 or w.dtype != torch.float32 for w in weights) or any(w.shape[0] != 256 for w in weights[:-1]):
+        return False
+    n_out = weights[-1].shape[0]
+    return n_out == 256 if has_ln else n_out <= 256
+
+
+def row_mlp(x: Tensor, layers: Sequence[Tuple[Tensor, Optional[Tensor]]], add: Optional[Tensor] = None,
+            residual: Optional[Tensor] = None, ln: Optional[Tuple[Tensor, Tensor, float]] = None) -> Tensor:
+    """K16.  layers = [(weight [N,256], bias | None), ...] (ReLU between layers, none after the last);
+    out = y (+ residual), or LayerNorm(residual + y) with ln = (gamma, beta, eps).  x [..., 256]; `add` (a positional
+    embedding added to x) must have x's shape or be [rows_mod, 256] broadcast over the leading rows."""
+    _need_gpu(x, add, residual, *[t for wb in layers for t in wb])
+    lib = _lib.load()
+    x = _f32c(x)
+    M = x.numel() // 256
+    ws = [_f32c(w) for w, _ in layers]
+    bs = [None if b is None else _f32c(b) for _, b in layers]
+    n_out = ws[-1].shape[0]
+    add_ptr, add_div, add_mod = None, 1, 1
+    if add is not None:
+        add = _f32c(add)
+        add_ptr, add_mod = add.data_ptr(), add.numel() // 256
+        if add_mod != M and x.shape[-2] != add_mod:
+            raise _lib.SocHipError(f"row_mlp: add {tuple(add.shape)} does not broadcast over x {tuple(x.shape)}")
+    res_ptr = None
+    if residual is not None:
+        residual = _f32c(residual)
+        if residual.numel() != M * n_out:
+            raise _lib.SocHipError("row_mlp: residual shape does not match the output")
+        res_ptr = residual.data_ptr()
+    g_ptr = b_ptr = None
+    eps = 0.0
+    if ln is not None:
+        gamma, beta, eps = _f32c(ln[0]), _f32c(ln[1]), float(ln[2])
+        g_ptr, b_ptr = gamma.data_ptr(), beta.data_ptr()
+    out = torch.empty(x.shape[:-1] + (n_out,), dtype=torch.float32, device=x.device)
+    wp = (C.c_void_p * 3)(*[w.data_ptr() for w in ws], *([None] * (3 - len(ws))))
+    has_bias = any(b is not None for b in bs)
+    bp = (C.c_void_p * 3)(*[None if b is None else b.data_ptr() for b in bs], *([None] * (3 - len(bs)))) if has_bias else None
+    with _timed("row_mlp", (x.numel() + out.numel() + M * sum(w.numel() for w in ws)) * 4):
+        code = lib.soc_row_mlp_f32(x.data_ptr(), add_ptr, add_div, add_mod, len(ws), wp, bp, n_out, res_ptr, g_ptr, b_ptr,
+                                   eps, out.data_ptr(), M, 256, _stream())
+    _lib.check(code, "soc_row_mlp_f32")
     return out
 
 

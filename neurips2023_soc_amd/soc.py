@@ -38,6 +38,9 @@ class MLP(nn.Module):
         self.layers = nn.ModuleList(nn.Linear(a, b) for a, b in zip(dims[:-1], dims[1:]))
 
     def forward(self, x):
+        ws = [layer.weight for layer in self.layers]
+        if hot_ops.row_mlp_supported(x, ws):          # K16: the whole MLP of a few query rows in one launch
+            return hot_ops.row_mlp(x, [(layer.weight, layer.bias) for layer in self.layers])
         for i, layer in enumerate(self.layers):
             x = fused.linear(x, layer.weight, layer.bias, relu=i + 1 < self.num_layers)
         return x

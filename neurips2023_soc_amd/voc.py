@@ -42,8 +42,8 @@ class SelfAttentionLayer(nn.Module):
         self.norm = nn.LayerNorm(d_model)
 
     def forward(self, tgt, tgt_key_padding_mask=None, query_pos=None, tgt_mask=None):
-        return _add_norm(tgt, self.self_attn(tgt, tgt, tgt, tgt_key_padding_mask, query_add=query_pos,
-                                             key_add=query_pos, attn_mask=tgt_mask), self.norm)
+        return self.self_attn(tgt, tgt, tgt, tgt_key_padding_mask, query_add=query_pos, key_add=query_pos,
+                              attn_mask=tgt_mask, post_norm=self.norm)
 
 
 class CrossAttentionLayer(nn.Module):
@@ -53,8 +53,8 @@ class CrossAttentionLayer(nn.Module):
         self.norm = nn.LayerNorm(d_model)
 
     def forward(self, tgt, memory, memory_key_padding_mask=None, pos=None, query_pos=None):
-        return _add_norm(tgt, self.multihead_attn(tgt, memory, memory, memory_key_padding_mask,
-                                                  query_add=query_pos, key_add=pos), self.norm)
+        return self.multihead_attn(tgt, memory, memory, memory_key_padding_mask, query_add=query_pos, key_add=pos,
+                                   post_norm=self.norm)
 
 
 class VOC(nn.Module):

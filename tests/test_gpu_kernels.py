@@ -383,6 +383,57 @@ def test_decoder_cross_attn_rejects_unsupported(ops):
     assert lib.soc_decoder_cross_attn_f32(*args, -1, 5, 4, 256, 8, 4, 4, None) == -1
 
 
+# ------------------------------------------------------------------ K16 row MLP / out_proj + residual + LayerNorm
+@pytest.mark.parametrize("M,n_layers,n_out,ln,add", [(160, 3, 4, False, None), (160, 3, 169, False, None),
+                                                     (160, 1, 256, True, "full"), (20, 1, 256, True, "rows"),
+                                                     (7, 2, 33, False, "rows"), (1, 1, 256, False, None)])
+def test_row_mlp_vs_torch(ops, M, n_layers, n_out, ln, add):
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(M * 10 + n_layers + n_out)
+    lead = (M // 4, 4) if M % 4 == 0 else (M,)
+    x = torch.randn(*lead, 256, generator=g)
+    dims = [256] * n_layers + [n_out]
+    layers = [(torch.randn(dims[i + 1], 256, generator=g) * 0.08, torch.randn(dims[i + 1], generator=g) * 0.3)
+              for i in range(n_layers)]
+    a = None
+    if add == "full":
+        a = torch.randn(*lead, 256, generator=g)
+    elif add == "rows":
+        a = torch.randn(lead[-1], 256, generator=g)
+    residual = torch.randn(*lead, n_out, generator=g) if (ln or n_out == 33) else None
+    gamma, beta = 1 + torch.randn(256, generator=g) * 0.1, torch.randn(256, generator=g) * 0.1
+    d = torch.float64
+    h = (x if a is None else x + a).to(d)
+    for i, (w, b) in enumerate(layers):
+        h = F.linear(h, w.to(d), b.to(d))
+        if i + 1 < n_layers:
+            h = h.relu()
+    if residual is not None:
+        h = h + residual.to(d)
+    want = F.layer_norm(h, (256,), gamma.to(d), beta.to(d), 1e-5) if ln else h
+    assert ops.row_mlp_supported(dev(x), [w for w, _ in layers], has_ln=ln)
+    got = ops.row_mlp(dev(x), [(dev(w), dev(b)) for w, b in layers], add=None if a is None else dev(a),
+                      residual=None if residual is None else dev(residual),
+                      ln=(dev(gamma), dev(beta), 1e-5) if ln else None)
+    assert got.shape == want.shape
+    assert maxdiff(got, want.float()) < 3e-5
+
+
+def test_row_mlp_rejects_unsupported(ops):
+    ops.row_chain_fusion = False       # what PipelinedClipGraph sets for its tail
+    try:
+        assert not ops.row_mlp_supported(torch.zeros(4, 256).cuda(), [torch.zeros(256, 256).cuda()])
+    finally:
+        ops.row_chain_fusion = True
+    x = torch.zeros(4, 128).cuda()
+    assert not ops.row_mlp_supported(x, [torch.zeros(128, 128).cuda()])
+    assert not ops.row_mlp_supported(torch.zeros(4, 256).cuda(), [torch.zeros(300, 256).cuda()])
+    assert not ops.row_mlp_supported(torch.zeros(4, 256).cuda(), [torch.zeros(64, 256).cuda()], has_ln=True)
+    assert not ops.row_mlp_supported(torch.zeros(5000, 256).cuda(), [torch.zeros(256, 256).cuda()])
+    with pytest.raises(RuntimeError):
+        ops.row_mlp(torch.zeros(4, 256).cuda(), [(torch.zeros(300, 256).cuda(), None)])
+
+
 # ------------------------------------------------------------------ K6 fused upsample + threshold
 @pytest.mark.parametrize("T,h,w,H0,W0", [(8, 90, 160, 720, 1280), (3, 63, 75, 250, 300), (1, 5, 7, 33, 50),
                                          (2, 90, 160, 360, 640), (1, 9, 9, 9, 9), (0, 4, 4, 8, 8)])
