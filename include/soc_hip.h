@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SOC_HIP_ABI_VERSION 4
+#define SOC_HIP_ABI_VERSION 5
 
 #define SOC_OK 0
 #define SOC_EINVAL (-1)       /* null pointer / non-positive dimension */
@@ -342,6 +342,26 @@ int soc_decoder_cross_attn_f32(const float* tgt, const float* query_pos, int que
 int soc_row_mlp_f32(const float* x, const float* x_add, int add_div, int add_mod, int n_layers, const float* const* w,
                     const float* const* bias, int n_out, const float* residual, const float* ln_gamma,
                     const float* ln_beta, float ln_eps, float* out, int M, int K, void* stream);
+
+/*
+ * K17 -- GroupNorm (+ the preceding convolution's bias, + ReLU) on an NCHW map in one launch: the
+ * `F.relu(gn(lay(x)))` steps of the FPN spatial decoder (reference models/segmentation.py:57-72) without the
+ * convolution itself:   y = act(GroupNorm(x + bias[c]; groups, gamma, beta, eps)),  act = ReLU when relu != 0.
+ * x, y [N, C, HW] contiguous (y may alias x); bias [C] or NULL; biased variance as torch.  HW % 4 == 0 and at most 32 768
+ * values per (sample, group); otherwise SOC_EUNSUPPORTED.
+ */
+int soc_groupnorm_nchw_f32(const float* x, const float* bias, const float* gamma, const float* beta, float* y, int N,
+                           int C, int HW, int groups, float eps, int relu, void* stream);
+
+/*
+ * K18 -- lateral connection of the FPN spatial decoder (reference models/segmentation.py:62-72:
+ * `cur_fpn + F.interpolate(x, size=cur_fpn.shape[-2:], mode="nearest")`):
+ *   y[n,c,h,w] = lateral[n,c,h,w] + bias[c] + prev[n, c, min(floor(h * Hp / H), Hp-1), min(floor(w * Wp / W), Wp-1)]
+ * (the float index rule of F.interpolate(mode="nearest")).  lateral, y [N,C,H,W]; prev [N,C,Hp,Wp]; bias [C] or NULL
+ * (the adapter convolution's bias when that was run without one).
+ */
+int soc_upsample_add_nchw_f32(const float* lateral, const float* bias, const float* prev, float* y, int N, int C, int H,
+                              int W, int Hp, int Wp, void* stream);
 
 #ifdef __cplusplus
 }

@@ -18,8 +18,8 @@ EXPORTS = ("soc_hip_abi_version", "soc_hip_error_string", "soc_msda_fwd_f32", "s
            "soc_msda_bwd_f32", "soc_msda_bwd_f64", "soc_groupnorm_tokens_workspace_bytes",
            "soc_groupnorm_tokens_f32", "soc_patch_merge_layernorm_f32", "soc_linear_act_f32",
            "soc_linear_act_multi_f32", "soc_ws_linear_f32", "soc_decoder_cross_attn_f32",
-           "soc_row_mlp_f32")
-ABI_VERSION = 4
+           "soc_row_mlp_f32", "soc_groupnorm_nchw_f32", "soc_upsample_add_nchw_f32")
+ABI_VERSION = 5
 SOC_EUNSUPPORTED = -2      # include/soc_hip.h: shape outside what the kernel is built for
 
 _lib = None
@@ -76,6 +76,10 @@ def load() -> C.CDLL:
     lib.soc_decoder_cross_attn_f32.argtypes = [p, p, i, p, i, p, p, p, p, p] + [p] * 10 + [f, p] + [i] * 7 + [p]
     lib.soc_row_mlp_f32.restype = i
     lib.soc_row_mlp_f32.argtypes = [p, p, i, i, i, p, p, i, p, p, p, f, p, i, i, p]
+    lib.soc_groupnorm_nchw_f32.restype = i
+    lib.soc_groupnorm_nchw_f32.argtypes = [p, p, p, p, p, i, i, i, i, f, i, p]
+    lib.soc_upsample_add_nchw_f32.restype = i
+    lib.soc_upsample_add_nchw_f32.argtypes = [p, p, p, p, i, i, i, i, i, i, p]
     lib.soc_upsample_threshold_u8.restype = i
     lib.soc_upsample_threshold_u8.argtypes = [p, p, i, i, i, i, i, f, p]
     lib.soc_add_layernorm_f32.restype = i

@@ -304,6 +304,46 @@ def row_mlp(x: Tensor, layers: Sequence[Tuple[Tensor, Optional[Tensor]]], add: O
     return out
 
 
+def groupnorm_nchw_supported(x: Tensor, groups: int) -> bool:
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()):
+        return False
+    N, Cc, H, W = x.shape
+    return Cc % groups == 0 and (H * W) % 4 == 0 and (Cc // groups) * H * W <= 32768
+
+
+def groupnorm_nchw(x: Tensor, conv_bias: Optional[Tensor], weight: Tensor, bias: Tensor, groups: int, eps: float,
+                   relu: bool = True) -> Tensor:
+    """K17.  relu(GroupNorm(x + conv_bias[c])) on an NCHW map (x is overwritten when it owns its memory: it is the
+    bias-free convolution output)."""
+    _need_gpu(x, conv_bias, weight, bias)
+    lib = _lib.load()
+    x = _f32c(x)
+    N, Cc, H, W = x.shape
+    with _timed("fpn_elementwise", x.numel() * 8):
+        code = lib.soc_groupnorm_nchw_f32(x.data_ptr(), None if conv_bias is None else _f32c(conv_bias).data_ptr(),
+                                          _f32c(weight).data_ptr(), _f32c(bias).data_ptr(), x.data_ptr(), N, Cc, H * W,
+                                          groups, float(eps), int(relu), _stream())
+    _lib.check(code, "soc_groupnorm_nchw_f32")
+    return x
+
+
+def upsample_add_nchw(lateral: Tensor, conv_bias: Optional[Tensor], prev: Tensor) -> Tensor:
+    """K18.  lateral + conv_bias[c] + F.interpolate(prev, size=lateral.shape[-2:], mode="nearest") (lateral is
+    overwritten: it is the bias-free adapter output)."""
+    _need_gpu(lateral, conv_bias, prev)
+    lib = _lib.load()
+    lateral, prev = _f32c(lateral), _f32c(prev)
+    N, Cc, H, W = lateral.shape
+    if prev.shape[:2] != (N, Cc):
+        raise _lib.SocHipError(f"upsample_add_nchw: {tuple(prev.shape)} vs {tuple(lateral.shape)}")
+    with _timed("fpn_elementwise", lateral.numel() * 8 + prev.numel() * 4):
+        code = lib.soc_upsample_add_nchw_f32(lateral.data_ptr(), None if conv_bias is None else _f32c(conv_bias).data_ptr(),
+                                             prev.data_ptr(), lateral.data_ptr(), N, Cc, H, W, prev.shape[2],
+                                             prev.shape[3], _stream())
+    _lib.check(code, "soc_upsample_add_nchw_f32")
+    return lateral
+
+
 def clamp_window(size: Sequence[int], window: Sequence[int], shift: Sequence[int]):
     """get_window_size of the reference (models/video_swin_transformer.py:71-84)."""
     w, s = list(window), list(shift)

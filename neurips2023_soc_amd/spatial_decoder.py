@@ -1,11 +1,15 @@
 """FPN spatial decoder feeding the dynamic mask head (reference models/segmentation.py:11-74).
-conv3x3 + GroupNorm(8) + ReLU ladder with nearest up-sampling; library convolutions (MIOpen)."""
+conv3x3 + GroupNorm(8) + ReLU ladder with nearest up-sampling; library convolutions (MIOpen).  On the GPU the
+convolutions run without their bias and everything between two convolutions is one launch: K17 (bias + GroupNorm +
+ReLU) and K18 (adapter bias + nearest up-sampling + add)."""
 from __future__ import annotations
 
 from typing import List
 
 import torch.nn.functional as F
 from torch import Tensor, nn
+
+from . import hot_ops
 
 
 class FPNSpatialDecoder(nn.Module):
@@ -31,14 +35,29 @@ class FPNSpatialDecoder(nn.Module):
                 nn.init.kaiming_uniform_(m.weight, a=1)
                 nn.init.zeros_(m.bias)
 
+    @staticmethod
+    def _conv_gn_relu(x: Tensor, lay: nn.Conv2d, gn: nn.GroupNorm) -> Tensor:
+        y = F.conv2d(x, lay.weight, None, lay.stride, lay.padding)
+        if hot_ops.groupnorm_nchw_supported(y, gn.num_groups):
+            return hot_ops.groupnorm_nchw(y, lay.bias, gn.weight, gn.bias, gn.num_groups, gn.eps, relu=True)
+        return F.relu(gn(y + lay.bias.view(1, -1, 1, 1)))
+
     def forward(self, x: Tensor, layer_features: List[Tensor]) -> Tensor:
-        x = F.relu(self.gn1(self.lay1(x)))
-        x = F.relu(self.gn2(self.lay2(x)))
         stages = [(self.adapter1, self.lay3, self.gn3), (self.adapter2, self.lay4, self.gn4)]
         if self.add_extra_layer:
             stages.append((self.adapter3, self.lay5, self.gn5))
+        if not x.is_cuda:
+            x = F.relu(self.gn1(self.lay1(x)))
+            x = F.relu(self.gn2(self.lay2(x)))
+            for feat, (adapter, lay, gn) in zip(layer_features, stages):
+                lateral = adapter(feat)
+                x = lateral + F.interpolate(x, size=lateral.shape[-2:], mode="nearest")
+                x = F.relu(gn(lay(x)))
+            return self.out_lay(x)
+        x = self._conv_gn_relu(x, self.lay1, self.gn1)
+        x = self._conv_gn_relu(x, self.lay2, self.gn2)
         for feat, (adapter, lay, gn) in zip(layer_features, stages):
-            lateral = adapter(feat)
-            x = lateral + F.interpolate(x, size=lateral.shape[-2:], mode="nearest")
-            x = F.relu(gn(lay(x)))
+            lateral = F.conv2d(feat, adapter.weight, None)
+            x = hot_ops.upsample_add_nchw(lateral, adapter.bias, x)
+            x = self._conv_gn_relu(x, lay, gn)
         return self.out_lay(x)

@@ -434,6 +434,44 @@ def test_row_mlp_rejects_unsupported(ops):
         ops.row_mlp(torch.zeros(4, 256).cuda(), [(torch.zeros(300, 256).cuda(), None)])
 
 
+# ------------------------------------------------------------------ K17 / K18 FPN elementwise passes
+@pytest.mark.parametrize("N,C,H,W,G,relu,with_bias", [(8, 256, 12, 20, 8, True, True), (8, 16, 90, 160, 8, True, True),
+                                                     (2, 32, 45, 80, 8, False, False), (1, 8, 2, 2, 8, True, True)])
+def test_groupnorm_nchw_vs_torch(ops, N, C, H, W, G, relu, with_bias):
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(C + H)
+    x = torch.randn(N, C, H, W, generator=g) * 2 + 0.5
+    cb = torch.randn(C, generator=g) if with_bias else None
+    gamma, beta = 1 + torch.randn(C, generator=g) * 0.2, torch.randn(C, generator=g) * 0.2
+    d = torch.float64
+    want = F.group_norm((x if cb is None else x + cb.view(1, -1, 1, 1)).to(d), G, gamma.to(d), beta.to(d), 1e-5)
+    if relu:
+        want = want.relu()
+    assert ops.groupnorm_nchw_supported(dev(x), G)
+    got = ops.groupnorm_nchw(dev(x), None if cb is None else dev(cb), dev(gamma), dev(beta), G, 1e-5, relu=relu)
+    assert maxdiff(got, want.float()) < 2e-5
+
+
+def test_groupnorm_nchw_rejects_unsupported(ops):
+    assert not ops.groupnorm_nchw_supported(torch.zeros(1, 8, 3, 3).cuda(), 8)          # HW % 4
+    assert not ops.groupnorm_nchw_supported(torch.zeros(1, 64, 90, 160).cuda(), 8)      # 115 200 values per group
+    assert not ops.groupnorm_nchw_supported(torch.zeros(1, 8, 4, 4).cuda().permute(0, 1, 3, 2), 8)
+
+
+@pytest.mark.parametrize("N,C,H,W,Hp,Wp", [(8, 128, 23, 40, 12, 20), (8, 64, 45, 80, 23, 40), (8, 32, 90, 160, 45, 80),
+                                           (1, 3, 7, 5, 3, 4), (2, 4, 9, 9, 9, 9)])
+def test_upsample_add_nchw_vs_torch(ops, N, C, H, W, Hp, Wp):
+    """bit-exact: one add chain per element and the index rule of F.interpolate(mode='nearest')"""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(H * 100 + Wp)
+    lat, prev, b = torch.randn(N, C, H, W, generator=g), torch.randn(N, C, Hp, Wp, generator=g), torch.randn(C, generator=g)
+    want = (dev(lat) + F.interpolate(dev(prev), size=(H, W), mode="nearest")) + dev(b).view(1, -1, 1, 1)
+    got = ops.upsample_add_nchw(dev(lat), dev(b), dev(prev))
+    assert maxdiff(got, want.cpu()) < 1e-6
+    idx_only = ops.upsample_add_nchw(torch.zeros(N, C, H, W).cuda(), None, dev(prev))
+    assert torch.equal(idx_only, F.interpolate(dev(prev), size=(H, W), mode="nearest"))
+
+
 # ------------------------------------------------------------------ K6 fused upsample + threshold
 @pytest.mark.parametrize("T,h,w,H0,W0", [(8, 90, 160, 720, 1280), (3, 63, 75, 250, 300), (1, 5, 7, 33, 50),
                                          (2, 90, 160, 360, 640), (1, 9, 9, 9, 9), (0, 4, 4, 8, 8)])
