@@ -13,7 +13,8 @@ t0, t1 = int(seg[0]["Start_Timestamp"]), int(seg[-1]["End_Timestamp"])
 
 def cat(n):
     if any(k in n for k in ("win_attn", "msda", "xattn", "dyn_mask", "add_layernorm", "linear_small", "box_refine",
-                            "upsample_", "resize_", "gemm_nt_kernel", "gn_stats", "gn_apply", "patch_merge", "ws_linear")):
+                            "upsample_threshold", "upsample_merge", "upsample_add_nchw", "resize_", "gemm_nt_kernel", "gn_stats", "gn_apply",
+                            "patch_merge", "ws_linear", "dec_cross_attn", "row_mlp", "groupnorm_nchw")):
         return "soc_hip kernels"
     if n.startswith("Cijk"):
         return "GEMM (hipBLASLt/rocBLAS)"

@@ -12,7 +12,8 @@ GROUPS = collections.OrderedDict([
     ("win_attn3d", ("win_attn3d",)), ("msda_fwd", ("msda_fwd",)), ("xattn", ("xattn_",)), ("dyn_mask", ("dyn_mask",)),
     ("add_layernorm", ("add_layernorm",)), ("linear_small", ("linear_small",)), ("linear_act", ("gemm_nt_kernel",)),
     ("groupnorm_tokens", ("gn_stats", "gn_apply")), ("patch_merge_layernorm", ("patch_merge",)), ("ws_linear", ("ws_linear_kernel",)),
-    ("box_refine", ("box_refine",)),
+    ("box_refine", ("box_refine",)), ("decoder_cross_attn", ("dec_cross_attn_kernel",)), ("row_mlp", ("row_mlp_kernel",)),
+    ("fpn_elementwise", ("groupnorm_nchw_kernel", "upsample_add_nchw_kernel")),
 ])
 
 
