@@ -1,4 +1,9 @@
-"""Does replaying the pipelined graph from a high-priority HIP stream change the per-clip time?  (experiment)"""
+"""Do HIP stream priorities reach the branches of the pipelined graph?  (experiment, result in README.md: no)
+
+The capture-priority rows need this two-line patch of graph_runner.PipelinedClipGraph.__init__ (not in the tree):
+    self._pc = torch.cuda.Stream(device=dev, priority=self.TAIL_PRIORITY)
+    cap = torch.cuda.Stream(device=dev, priority=self.HEAD_PRIORITY);  with torch.cuda.graph(g, stream=cap): ...
+Without it only the last row (launching the replays from a high-priority stream) measures anything."""
 import sys
 import time
 
