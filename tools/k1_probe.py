@@ -1,8 +1,9 @@
 """K1 diagnostics on an MI355X: (A) HIP-event time per Video-Swin stage geometry through the shipped library,
 (B) a -DSOC_K1_STAMPS build (never shipped) whose workgroups stamp s_memtime at phase boundaries and
 s_memrealtime at start / end: in-kernel clock under load, per-phase cycles, workgroup rounds per CU.
-(C) --sweep: forced schedules.
-usage: python tools/k1_probe.py [--stamps|--sweep] [--flags=-DX,-DY] [stages...]"""
+(C) --sweep: forced schedules.  (D) --insitu: forced schedules timed inside the 12-launch sequence of a forward (every
+launch on its own qkv tensor, 634 MB in all, so that K/V staging sees the cache state it has inside the model).
+usage: python tools/k1_probe.py [--stamps|--sweep|--insitu] [--flags=-DX,-DY] [stages...]"""
 import ctypes as C
 import os
 import subprocess
@@ -168,6 +169,54 @@ def sweep(stages, flags):
             print(f"   n_main {nm:5d} qsplit {q}: {us:7.1f} us  blocks {nm + (pairs - nm) * q}")
 
 
+def insitu(stages, flags, reps=12):
+    lib = build(["-DSOC_K1_TUNE", *flags], "tune")
+    seq = [0, 0, 1, 1, 2, 2, 2, 2, 2, 2, 3, 3]                      # stage of the 12 K1 launches of a Swin-T forward
+    tens = [inputs(st) for st in seq]
+    shifts = [(0, 0, 0), (4, 3, 3)] * 6
+
+    def run(target, plan):
+        """mean time (us) of one launch of stage `target` under `plan` = (n_main, qsplit) or None (planner)"""
+        tot, n = 0.0, 0
+        for rep in range(reps + 2):
+            evs = []
+            for i, st in enumerate(seq):
+                forced = plan is not None and st == target
+                lib.soc_debug_force_k1_plan(*(plan if forced else (0, 0)))
+                if st == target:
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record()
+                    call(lib, tens[i], st, shifts[i])
+                    b.record()
+                    evs.append((a, b))
+                else:
+                    call(lib, tens[i], st, shifts[i])
+            torch.cuda.synchronize()
+            if rep >= 2:
+                tot += sum(a.elapsed_time(b) for a, b in evs) * 1e3
+                n += len(evs)
+        lib.soc_debug_force_k1_plan(0, 0)
+        return tot / n
+
+    for st in stages:
+        H, W, nH = GEO[st]
+        pairs = nH * (-(-H // 7)) * (-(-W // 7))
+        base = pairs - pairs % 256
+        cands = {(pairs, 1)}
+        for q in (2, 3, 4, 5, 6, 7, 8):
+            for nm in (0, base - 256, base - 192, base - 128, base - 96, base - 64, base - 32, base, base + 32, base + 64):
+                if 0 <= nm < pairs and (pairs - nm) * q <= 4096:
+                    cands.add((nm // 8 * 8, q))
+        run(st, None)                                            # warm-up: clocks, caches
+        own = run(st, None)
+        rows = sorted((run(st, c), c) for c in sorted(cands))
+        own2 = run(st, None)
+        print(f"stage {st}: {pairs} pairs; planner's own choice {own:.1f} / {own2:.1f} us before / after the sweep "
+              f"(event pairs, in sequence)")
+        for us, (nm, q) in rows[:8]:
+            print(f"   n_main {nm:5d} qsplit {q}: {us:7.1f} us  blocks {nm + (pairs - nm) * q}")
+
+
 if __name__ == "__main__":
     av = sys.argv[1:]
     flags = []
@@ -177,7 +226,9 @@ if __name__ == "__main__":
             av.remove(a)
     do_stamps = "--stamps" in av
     stages = [int(a) for a in av if a.isdigit()] or [0, 1, 2, 3]
-    if "--sweep" in av:
+    if "--insitu" in av:
+        insitu(stages, flags)
+    elif "--sweep" in av:
         sweep(stages, flags)
     elif do_stamps:
         stamps(stages, flags)
