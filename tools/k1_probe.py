@@ -169,8 +169,8 @@ def sweep(stages, flags):
             print(f"   n_main {nm:5d} qsplit {q}: {us:7.1f} us  blocks {nm + (pairs - nm) * q}")
 
 
-def insitu(stages, flags, reps=12):
-    lib = build(["-DSOC_K1_TUNE", *flags], "tune")
+def insitu(stages, flags, reps=12, own_only=False):
+    lib = build(["-DSOC_K1_TUNE", *flags], "tune" + "".join(f.replace("-D", "_") for f in flags))
     seq = [0, 0, 1, 1, 2, 2, 2, 2, 2, 2, 3, 3]                      # stage of the 12 K1 launches of a Swin-T forward
     tens = [inputs(st) for st in seq]
     shifts = [(0, 0, 0), (4, 3, 3)] * 6
@@ -209,6 +209,9 @@ def insitu(stages, flags, reps=12):
                     cands.add((nm // 8 * 8, q))
         run(st, None)                                            # warm-up: clocks, caches
         own = run(st, None)
+        if own_only:
+            print(f"stage {st}: planner's own choice {own:.1f} / {run(st, None):.1f} us  flags {flags}")
+            continue
         rows = sorted((run(st, c), c) for c in sorted(cands))
         own2 = run(st, None)
         print(f"stage {st}: {pairs} pairs; planner's own choice {own:.1f} / {own2:.1f} us before / after the sweep "
@@ -227,7 +230,7 @@ if __name__ == "__main__":
     do_stamps = "--stamps" in av
     stages = [int(a) for a in av if a.isdigit()] or [0, 1, 2, 3]
     if "--insitu" in av:
-        insitu(stages, flags)
+        insitu(stages, flags, own_only="--own" in av)
     elif "--sweep" in av:
         sweep(stages, flags)
     elif do_stamps:
