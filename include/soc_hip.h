@@ -261,7 +261,7 @@ int soc_linear_act_multi_f32(const float* x, const float* x_add, int nseg, const
  * in front of them (with_pos_embed, deformable_transformer.py:318-320; voc.py:84-90,141-149).
  *   x      [M, K] contiguous         w [N, K] (nn.Linear.weight layout)    bias [N] or NULL
  *   x_add  [add_mod, K] or NULL: row m of the input is x[m] + x_add[(m / add_div) % add_mod]
- *   out    [M, N];  relu != 0 applies max(., 0)
+ *   out    [M, N];  relu: 0 none, 1 max(., 0), 2 exact (erf) GELU (the text encoder's intermediate activation)
  * K % 16 == 0, M <= 4096, 16-byte aligned x / x_add / w; otherwise SOC_EUNSUPPORTED (use the
  * library GEMM).  fp32 MFMA accumulation, K split 4-ways per output tile.
  */

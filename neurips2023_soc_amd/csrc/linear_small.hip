@@ -107,7 +107,8 @@ __global__ __launch_bounds__(256) void linear_small_kernel(
     if (row < M && col < N) {
         float v = (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
         if (bias) v += bias[col];
-        if (relu) v = fmaxf(v, 0.f);
+        if (relu == 1) v = fmaxf(v, 0.f);
+        else if (relu == 2) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));   // exact GELU, as nn.GELU()
         out[(long)row * N + col] = v;
     }
 }

@@ -550,7 +550,7 @@ def linear_small_multi(x: Tensor, layers: Sequence[Tuple[Tensor, Optional[Tensor
     u_arr = (C.c_int * n)(*(int(bool(u)) for _, _, u in layers))
     with _timed("linear_small", (M * K + sum(w.numel() + M * w.shape[0] for w in ws)) * 4):
         code = lib.soc_linear_small_multi_f32(x.data_ptr(), add_ptr, div, mod, n, w_arr, b_arr, o_arr, n_arr, u_arr,
-                                              M, K, int(bool(relu)), _stream())
+                                              M, K, 2 if relu == "gelu" else int(bool(relu)), _stream())
     _lib.check(code, "soc_linear_small_multi_f32")
     return outs
 

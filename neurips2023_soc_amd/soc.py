@@ -25,6 +25,7 @@ from .nested_tensor import NestedTensor
 from .position_encoding import PositionEmbeddingSine1D
 from .postprocessing import build_postprocessors
 from .spatial_decoder import FPNSpatialDecoder
+from .text_fast import accelerate_text_encoder
 from .video_swin import build_video_swin_backbone, resize_pad_mask
 from .vla import MMF
 from .voc import VOC
@@ -126,6 +127,7 @@ class SOC(nn.Module):
         self.transformer.decoder.bbox_embed = self.bbox_embed  # shared modules, aliased state_dict keys
 
         self.text_encoder, self.tokenizer = _load_text_stack(config)
+        accelerate_text_encoder(self.text_encoder)     # GPU form of the encoder layers (text_fast.py); no-op on CPU
         self.freeze_text_encoder = config.freeze_text_encoder
         self.text_pos = PositionEmbeddingSine1D(d_model, normalize=True)
         self.query_embed = nn.Embedding(self.num_queries, d_model)

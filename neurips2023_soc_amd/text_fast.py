@@ -1,0 +1,97 @@
+"""The text side of SOC.forward_text on the GPU: HuggingFace RobertaModel with its encoder layers re-expressed on this
+package's small-row kernels.
+
+The reference runs `RobertaModel` per forward (models/soc.py:167-181); north_star keeps RoBERTa in PyTorch.  On ~10 word
+rows the stock module is ~170 short launches per clip (72 library GEMMs of 10-17 us on a few workgroups each, separate
+bias-free adds, LayerNorms, GELU) that run on the side branch beside Video-Swin and cost it 0.27 ms per clip
+(tools/experiments/text_ablation.py).  Here a layer is 7 launches:
+
+    K7 (q | k | v as three segments of one launch)  ->  F.scaled_dot_product_attention (what HF's "sdpa" path calls)
+    ->  K7 (attention.output.dense)  ->  K5 (residual + LayerNorm)
+    ->  K7 (intermediate.dense with the exact-erf GELU in its epilogue)  ->  K7 (output.dense)  ->  K5
+
+Parameters, state_dict keys and the module tree are HuggingFace's; only `forward` of the layer instances is bound, and it
+falls back to the original for anything it does not cover (CPU, training, decoder / cross-attention, caches, attention
+probabilities requested, another activation).  Embeddings, mask construction and the pooler stay HuggingFace code.
+"""
+from __future__ import annotations
+
+import types
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import fused, hot_ops
+
+
+def _small_row_linear(self, x):
+    """nn.Linear.forward routed through fused.linear (K7 for few rows, the library GEMM otherwise)."""
+    if x.is_cuda and x.dtype == torch.float32:
+        return fused.linear(x, self.weight, self.bias)
+    return F.linear(x, self.weight, self.bias)
+
+
+def _covered(layer, hidden_states, args, kwargs) -> bool:
+    if args or layer.training or not hidden_states.is_cuda or hidden_states.dtype != torch.float32:
+        return False
+    if getattr(layer, "is_decoder", False) or getattr(layer, "add_cross_attention", False):
+        return False
+    if kwargs.get("output_attentions") or kwargs.get("head_mask") is not None:
+        return False
+    if any(kwargs.get(k) is not None for k in ("encoder_hidden_states", "encoder_attention_mask", "past_key_values",
+                                               "past_key_value")):
+        return False
+    return hidden_states.dim() == 3 and fused.is_small(hidden_states)
+
+
+def _layer_forward(self, hidden_states, attention_mask=None, *args, **kwargs):
+    if not _covered(self, hidden_states, args, kwargs):
+        return self._soc_orig_forward(hidden_states, attention_mask, *args, **kwargs)
+    att, att_out, inter, out = self.attention.self, self.attention.output, self.intermediate, self.output
+    B, L, E = hidden_states.shape
+    nh = att.num_attention_heads
+    q, k, v = fused.linear_multi(hidden_states, [(att.query.weight, att.query.bias, False),
+                                                 (att.key.weight, att.key.bias, False),
+                                                 (att.value.weight, att.value.bias, False)])
+    q, k, v = (t.view(B, L, nh, E // nh).transpose(1, 2) for t in (q, k, v))
+    ctx = F.scaled_dot_product_attention(q, k, v, attn_mask=attention_mask, scale=getattr(att, "scaling", None))
+    ctx = ctx.transpose(1, 2).reshape(B, L, E)
+    h = hot_ops.add_layernorm(hidden_states, fused.linear(ctx, att_out.dense.weight, att_out.dense.bias),
+                              att_out.LayerNorm.weight, att_out.LayerNorm.bias, att_out.LayerNorm.eps, return_sum=False)[1]
+    mid = hot_ops.linear_small(h, inter.dense.weight, inter.dense.bias, None, "gelu")
+    y = hot_ops.add_layernorm(h, fused.linear(mid, out.dense.weight, out.dense.bias), out.LayerNorm.weight,
+                              out.LayerNorm.bias, out.LayerNorm.eps, return_sum=False)[1]
+    return y if self._soc_returns_tensor else (y,)
+
+
+def accelerate_text_encoder(text_encoder: nn.Module) -> int:
+    """Bind the fast forward to every RobertaLayer-shaped module of `text_encoder` and route its remaining nn.Linear
+    layers (pooler) through K7.  Returns the number of encoder layers bound (0: unknown module layout, nothing changed
+    except the Linear routing)."""
+    import transformers
+    returns_tensor = int(transformers.__version__.split(".")[0]) >= 5      # 4.x layers return a tuple
+    n = 0
+    for m in text_encoder.modules():
+        if type(m) is nn.Linear and m.in_features % 16 == 0:
+            m.forward = types.MethodType(_small_row_linear, m)
+    for m in text_encoder.modules():
+        try:
+            att, inter, out = m.attention.self, m.intermediate, m.output
+            shaped = (all(type(x) is nn.Linear for x in (att.query, att.key, att.value, m.attention.output.dense,
+                                                          inter.dense, out.dense))
+                      and type(m.attention.output.LayerNorm) is nn.LayerNorm and type(out.LayerNorm) is nn.LayerNorm)
+        except AttributeError:
+            continue
+        act = getattr(inter, "intermediate_act_fn", None)
+        exact_gelu = type(act).__name__ == "GELUActivation" or act is F.gelu or isinstance(act, nn.GELU)
+        if isinstance(act, nn.GELU) and getattr(act, "approximate", "none") != "none":
+            exact_gelu = False
+        if not (shaped and exact_gelu) or getattr(att, "position_embedding_type", "absolute") != "absolute":
+            continue
+        if not hasattr(m, "_soc_orig_forward"):
+            m._soc_orig_forward = m.forward
+            m._soc_returns_tensor = returns_tensor
+            m.forward = types.MethodType(_layer_forward, m)
+        n += 1
+    return n

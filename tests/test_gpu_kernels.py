@@ -310,6 +310,49 @@ def test_msda_fused_vs_oracle(ops, N, Lq, rd, padding):
         assert maxdiff(got0, O.msda_fused_core(value, shapes, lsi, ref, off, logits, None)) < 3e-5
 
 
+# ------------------------------------------------------------------ K7 GELU epilogue, text encoder layers on K7 / K5
+def test_linear_small_gelu_epilogue(ops):
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(7)
+    x, w, b = torch.randn(10, 768, generator=g), torch.randn(3072, 768, generator=g) * 0.05, torch.randn(3072, generator=g)
+    want = F.gelu(F.linear(x.double(), w.double(), b.double()))
+    got = ops.linear_small(dev(x), dev(w), dev(b), None, "gelu")
+    assert maxdiff(got, want.float()) < 2e-5
+
+
+@pytest.mark.parametrize("L,pad", [(10, 0), (32, 22), (5, 0)])
+def test_text_encoder_fast_layers_match_huggingface(L, pad):
+    """RobertaModel with its layers bound to text_fast._layer_forward against the same module's original forward
+    (reference models/soc.py:167-181 calls it as is), padded expressions included."""
+    import neurips2023_soc_amd as S
+    from neurips2023_soc_amd import weights as W
+    from neurips2023_soc_amd.text_fast import accelerate_text_encoder
+    model, _, _ = S.build_model(S.default_args(text_encoder_random_init=True))
+    W.load_synthetic(model, 2023)
+    enc = model.text_encoder.cuda().eval()
+    assert accelerate_text_encoder(enc) == 12                      # idempotent: already bound by SOC.__init__
+    g = torch.Generator().manual_seed(L)
+    ids = torch.randint(3, 50000, (2, L), generator=g)
+    ids[:, 0] = 0
+    attn = torch.ones_like(ids)
+    if pad:
+        ids[1, L - pad:], attn[1, L - pad:] = 1, 0
+    with torch.no_grad():
+        fast = enc(input_ids=ids.cuda(), attention_mask=attn.cuda())
+        for m in enc.modules():
+            if hasattr(m, "_soc_orig_forward"):
+                m._soc_fast, m.forward = m.forward, m._soc_orig_forward
+        try:
+            ref = enc(input_ids=ids.cuda(), attention_mask=attn.cuda())
+        finally:
+            for m in enc.modules():
+                if hasattr(m, "_soc_fast"):
+                    m.forward = m._soc_fast
+    keep = attn.bool().cuda()
+    assert maxdiff(fast.last_hidden_state[keep], ref.last_hidden_state[keep].cpu()) < 2e-4
+    assert maxdiff(fast.pooler_output, ref.pooler_output.cpu()) < 2e-4
+
+
 # ------------------------------------------------------------------ K15 decoder cross-attention block
 @pytest.mark.parametrize("N,Lq,rd,padding,shared_pos", [(8, 20, 4, False, True), (8, 20, 2, False, True),
                                                         (3, 7, 4, True, False), (2, 33, 2, True, True)])
