@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SOC_HIP_ABI_VERSION 5
+#define SOC_HIP_ABI_VERSION 6
 
 #define SOC_OK 0
 #define SOC_EINVAL (-1)       /* null pointer / non-positive dimension */
@@ -213,12 +213,13 @@ int soc_resize_normalize_u8_f32(const uint8_t* frames, float* out, uint8_t* out_
  * front becomes a GEMM over tokens.
  *   x, out [N, S, C]  (N = frames, S = h*w);  gamma, beta [C];  G groups of C/G consecutive channels;
  *   statistics per (frame, group) over S * C/G elements, biased variance, as torch.nn.GroupNorm.
- * C <= 256, C % 4 == 0, (C/G) a multiple of 4 with (C/G)/4 a power of two, G <= 64.
+ * C <= 256 with C/4 a power of two; C/G a multiple of 4 with (C/G)/4 a power of two, or C/G == 2; G <= 64.
+ * relu != 0 applies max(., 0) to the result (the FPN spatial decoder's GroupNorm + ReLU, models/segmentation.py:57-72).
  * workspace: soc_groupnorm_tokens_workspace_bytes() bytes of device memory (per-chunk partial sums).
  */
 size_t soc_groupnorm_tokens_workspace_bytes(int N, int S, int C, int G);
 int soc_groupnorm_tokens_f32(const float* x, const float* gamma, const float* beta, float* out, int N, int S,
-                             int C, int G, float eps, void* workspace, size_t workspace_bytes, void* stream);
+                             int C, int G, float eps, int relu, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * K11 -- Video-Swin patch merging: 2x2 spatial gather + LayerNorm(4C) in one pass.  Replaces
@@ -362,6 +363,28 @@ int soc_groupnorm_nchw_f32(const float* x, const float* bias, const float* gamma
  */
 int soc_upsample_add_nchw_f32(const float* lateral, const float* bias, const float* prev, float* y, int N, int C, int H,
                               int W, int Hp, int Wp, void* stream);
+
+/*
+ * K18 (token-major form) -- the same lateral connection on channels-last maps:
+ *   y[n, h, w, c] = lateral[n, h, w, c] + bias[c] + prev[n, min(floor(h * Hp / H), Hp-1), min(floor(w * Wp / W), Wp-1), c]
+ * lateral, y [N, H*W, C] contiguous (y may alias lateral); prev [N, Hp*Wp, C] contiguous; C % 4 == 0.
+ */
+int soc_upsample_add_tokens_f32(const float* lateral, const float* bias, const float* prev, float* y, int N, int C, int H,
+                                int W, int Hp, int Wp, void* stream);
+
+/*
+ * K19 -- 3x3 / stride 1 / zero-pad 1 convolution on a token-major (channels-last) map as an implicit GEMM on f32 MFMA:
+ * the convolutions of the FPN spatial decoder (reference models/segmentation.py:24-33,57-74: lay1..lay5, out_lay).
+ *   out[(n, y, x), co] = act(bias[co] + sum_{ky,kx,ci} in[n, y+ky-1, x+kx-1, ci] * w[co, ci, ky, kx])
+ *   in      [N][H*W][Cin], frame n at in + n * in_frame_stride (elements; >= H*W*Cin: a level of the encoder memory is
+ *           read in place)
+ *   w_taps  [Cout][9 * Cin] = the Conv2d weight [Cout, Cin, 3, 3] permuted to [Cout, ky, kx, Cin]
+ *   bias    [Cout] or NULL;  relu != 0: max(., 0)
+ *   out     token-major [N*H*W][Cout] (out_nchw == 0) or NCHW [N][Cout][H][W] (out_nchw != 0)
+ * Cin % 16 == 0 and 16-byte aligned in / w_taps; otherwise SOC_EUNSUPPORTED.
+ */
+int soc_conv3x3_tokens_f32(const float* in, long in_frame_stride, const float* w_taps, const float* bias, float* out,
+                           int N, int H, int W, int Cin, int Cout, int out_nchw, int relu, void* stream);
 
 #ifdef __cplusplus
 }

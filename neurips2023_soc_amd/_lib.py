@@ -18,8 +18,9 @@ EXPORTS = ("soc_hip_abi_version", "soc_hip_error_string", "soc_msda_fwd_f32", "s
            "soc_msda_bwd_f32", "soc_msda_bwd_f64", "soc_groupnorm_tokens_workspace_bytes",
            "soc_groupnorm_tokens_f32", "soc_patch_merge_layernorm_f32", "soc_linear_act_f32",
            "soc_linear_act_multi_f32", "soc_ws_linear_f32", "soc_decoder_cross_attn_f32",
-           "soc_row_mlp_f32", "soc_groupnorm_nchw_f32", "soc_upsample_add_nchw_f32")
-ABI_VERSION = 5
+           "soc_row_mlp_f32", "soc_groupnorm_nchw_f32", "soc_upsample_add_nchw_f32",
+           "soc_upsample_add_tokens_f32", "soc_conv3x3_tokens_f32")
+ABI_VERSION = 6
 SOC_EUNSUPPORTED = -2      # include/soc_hip.h: shape outside what the kernel is built for
 
 _lib = None
@@ -80,6 +81,10 @@ def load() -> C.CDLL:
     lib.soc_groupnorm_nchw_f32.argtypes = [p, p, p, p, p, i, i, i, i, f, i, p]
     lib.soc_upsample_add_nchw_f32.restype = i
     lib.soc_upsample_add_nchw_f32.argtypes = [p, p, p, p, i, i, i, i, i, i, p]
+    lib.soc_upsample_add_tokens_f32.restype = i
+    lib.soc_upsample_add_tokens_f32.argtypes = [p, p, p, p, i, i, i, i, i, i, p]
+    lib.soc_conv3x3_tokens_f32.restype = i
+    lib.soc_conv3x3_tokens_f32.argtypes = [p, C.c_long, p, p, p, i, i, i, i, i, i, i, p]
     lib.soc_upsample_threshold_u8.restype = i
     lib.soc_upsample_threshold_u8.argtypes = [p, p, i, i, i, i, i, f, p]
     lib.soc_add_layernorm_f32.restype = i
@@ -99,7 +104,7 @@ def load() -> C.CDLL:
     lib.soc_groupnorm_tokens_workspace_bytes.restype = C.c_size_t
     lib.soc_groupnorm_tokens_workspace_bytes.argtypes = [i] * 4
     lib.soc_groupnorm_tokens_f32.restype = i
-    lib.soc_groupnorm_tokens_f32.argtypes = [p, p, p, p, i, i, i, i, f, p, C.c_size_t, p]
+    lib.soc_groupnorm_tokens_f32.argtypes = [p, p, p, p, i, i, i, i, f, i, p, C.c_size_t, p]
     lib.soc_patch_merge_layernorm_f32.restype = i
     lib.soc_patch_merge_layernorm_f32.argtypes = [p, p, p, p, i, i, i, i, f, p]
     lib.soc_linear_act_f32.restype = i

@@ -91,7 +91,42 @@ __global__ __launch_bounds__(256) void upsample_add_nchw_kernel(
     y[i] = v;
 }
 
+__global__ __launch_bounds__(256) void upsample_add_tokens_kernel(
+    const float* __restrict__ lat, const float* __restrict__ bias, const float* __restrict__ prev,
+    float* __restrict__ y, int C4, int H, int W, int Hp, int Wp, float sh, float sw, long total4) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;       // float4 index into [N, H, W, C]
+    if (i >= total4) return;
+    const int c4 = (int)(i % C4);
+    const long pix = i / C4;
+    const int xo = (int)(pix % W);
+    const long r = pix / W;
+    const int yo = (int)(r % H);
+    const long n = r / H;
+    const int ys = min((int)floorf(yo * sh), Hp - 1), xs = min((int)floorf(xo * sw), Wp - 1);
+    const float4 a = reinterpret_cast<const float4*>(lat)[i];
+    const float4 p = reinterpret_cast<const float4*>(prev)[((n * Hp + ys) * Wp + xs) * C4 + c4];
+    float4 o = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
+    if (bias) {
+        const float4 b = reinterpret_cast<const float4*>(bias)[c4];
+        o.x += b.x; o.y += b.y; o.z += b.z; o.w += b.w;
+    }
+    reinterpret_cast<float4*>(y)[i] = o;
+}
+
 }  // namespace
+
+extern "C" int soc_upsample_add_tokens_f32(const float* lateral, const float* bias, const float* prev, float* y, int N,
+                                           int C, int H, int W, int Hp, int Wp, void* stream) {
+    if (N < 0 || C <= 0 || H <= 0 || W <= 0 || Hp <= 0 || Wp <= 0) return SOC_EINVAL;
+    if (N == 0) return SOC_OK;
+    if (!lateral || !prev || !y) return SOC_EINVAL;
+    if (C % 4 || (((uintptr_t)lateral | (uintptr_t)prev | (uintptr_t)y | (uintptr_t)bias) & 15)) return SOC_EUNSUPPORTED;
+    const long total4 = (long)N * H * W * (C / 4);
+    hipLaunchKernelGGL(upsample_add_tokens_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, lateral, bias, prev, y, C / 4, H, W, Hp, Wp, (float)Hp / (float)H,
+                       (float)Wp / (float)W, total4);
+    return soc_check_launch();
+}
 
 extern "C" int soc_groupnorm_nchw_f32(const float* x, const float* bias, const float* gamma, const float* beta, float* y,
                                       int N, int C, int HW, int groups, float eps, int relu, void* stream) {

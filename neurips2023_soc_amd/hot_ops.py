@@ -344,6 +344,48 @@ def upsample_add_nchw(lateral: Tensor, conv_bias: Optional[Tensor], prev: Tensor
     return lateral
 
 
+def conv3x3_tokens(x: Tensor, hw: Tuple[int, int], w_taps: Tensor, bias: Optional[Tensor], out_nchw: bool = False,
+                   relu: bool = False) -> Tensor:
+    """K19.  3x3 / pad 1 convolution of a token-major map.  x [N, H*W, Cin] whose frames may be strided (a level slice of
+    the encoder memory: x.stride() == (frame_stride, Cin, 1)); w_taps [Cout, 9*Cin] = conv.weight.permute(0, 2, 3, 1);
+    -> [N, H*W, Cout] (token-major) or [N, Cout, H, W]."""
+    _need_gpu(x, w_taps, bias)
+    lib = _lib.load()
+    N, S, Cin = x.shape
+    H, W = hw
+    if x.dtype != torch.float32 or S != H * W or x.stride(2) != 1 or x.stride(1) != Cin or (N > 1 and x.stride(0) < S * Cin):
+        raise _lib.SocHipError(f"conv3x3_tokens: unsupported input layout {tuple(x.shape)} / {x.stride()}")
+    w_taps = _f32c(w_taps)
+    Cout = w_taps.shape[0]
+    if w_taps.shape[1] != 9 * Cin:
+        raise _lib.SocHipError("conv3x3_tokens: w_taps must be [Cout, 9*Cin]")
+    out = torch.empty((N, Cout, H, W) if out_nchw else (N, S, Cout), dtype=torch.float32, device=x.device)
+    with _timed("conv3x3_tokens", (x.numel() + w_taps.numel() + out.numel()) * 4):
+        code = lib.soc_conv3x3_tokens_f32(x.data_ptr(), x.stride(0) if N > 1 else S * Cin, w_taps.data_ptr(),
+                                          None if bias is None else _f32c(bias).data_ptr(), out.data_ptr(), N, H, W, Cin,
+                                          Cout, int(out_nchw), int(relu), _stream())
+    _lib.check(code, "soc_conv3x3_tokens_f32")
+    return out
+
+
+def upsample_add_tokens(lateral: Tensor, bias: Optional[Tensor], prev: Tensor, hw: Tuple[int, int],
+                        hw_prev: Tuple[int, int]) -> Tensor:
+    """K18, token-major form.  lateral [N, H*W, C] + bias + nearest-up-sampled prev [N, Hp*Wp, C] (lateral is overwritten
+    when it owns its memory)."""
+    _need_gpu(lateral, bias, prev)
+    lib = _lib.load()
+    lateral, prev = _f32c(lateral), _f32c(prev)
+    N, S, Cc = lateral.shape
+    (H, W), (Hp, Wp) = hw, hw_prev
+    if S != H * W or prev.shape != (N, Hp * Wp, Cc):
+        raise _lib.SocHipError(f"upsample_add_tokens: {tuple(lateral.shape)} / {tuple(prev.shape)} vs {hw} / {hw_prev}")
+    with _timed("fpn_elementwise", lateral.numel() * 8 + prev.numel() * 4):
+        code = lib.soc_upsample_add_tokens_f32(lateral.data_ptr(), None if bias is None else _f32c(bias).data_ptr(),
+                                               prev.data_ptr(), lateral.data_ptr(), N, Cc, H, W, Hp, Wp, _stream())
+    _lib.check(code, "soc_upsample_add_tokens_f32")
+    return lateral
+
+
 def clamp_window(size: Sequence[int], window: Sequence[int], shift: Sequence[int]):
     """get_window_size of the reference (models/video_swin_transformer.py:71-84)."""
     w, s = list(window), list(shift)
@@ -631,8 +673,16 @@ def resize_normalize(frames: Tensor, size: Sequence[int], tables_x, tables_y, me
     return (out, out_u8) if return_u8 else out
 
 
-def groupnorm_tokens(x: Tensor, weight: Tensor, bias: Tensor, groups: int, eps: float = 1e-5) -> Tensor:
-    """K10.  GroupNorm of token-major activations: x [N,S,C] -> [N,S,C], statistics per (n, group) over
+def groupnorm_tokens_supported(C_: int, groups: int) -> bool:
+    cpg, nvec = C_ // max(groups, 1), C_ // 4
+    whole = cpg % 4 == 0 and ((cpg // 4) & (cpg // 4 - 1)) == 0
+    return (groups > 0 and C_ % groups == 0 and C_ <= 256 and C_ % 4 == 0 and (nvec & (nvec - 1)) == 0
+            and (whole or cpg == 2) and groups <= 64)
+
+
+def groupnorm_tokens(x: Tensor, weight: Tensor, bias: Tensor, groups: int, eps: float = 1e-5,
+                     relu: bool = False) -> Tensor:
+    """K10.  GroupNorm (+ ReLU) of token-major activations: x [N,S,C] -> [N,S,C], statistics per (n, group) over
     S * C/groups elements (what nn.GroupNorm computes on the '(n) c h w' view of the same data)."""
     _need_gpu(x, weight, bias)
     lib = _lib.load()
@@ -643,8 +693,8 @@ def groupnorm_tokens(x: Tensor, weight: Tensor, bias: Tensor, groups: int, eps: 
     ws = torch.empty(max(need, 1), dtype=torch.uint8, device=x.device)
     with _timed("groupnorm_tokens", 3 * x.numel() * 4):
         code = lib.soc_groupnorm_tokens_f32(x.data_ptr(), _f32c(weight).data_ptr(), _f32c(bias).data_ptr(),
-                                            out.data_ptr(), N, S, C_, int(groups), float(eps), ws.data_ptr(), need,
-                                            _stream())
+                                            out.data_ptr(), N, S, C_, int(groups), float(eps), int(relu), ws.data_ptr(),
+                                            need, _stream())
     _lib.check(code, "soc_groupnorm_tokens_f32")
     return out
 

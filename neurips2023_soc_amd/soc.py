@@ -324,7 +324,13 @@ class SOC(nn.Module):
         device = feats0.device
         Q = self.num_queries
         tgt = lang_last.new_zeros(B, T, Q, lang_last.shape[-1])
-        memory = self.transformer.memory_maps(ctx)
+        use_tokens = self.spatial_decoder.tokens_supported(ctx[0])     # GPU: the FPN runs token-major, no NCHW maps
+
+        def run_fpn():
+            if use_tokens:
+                return self.spatial_decoder.forward_tokens(ctx[0], ctx[6][:self.num_feature_levels - 1], feats0)
+            memory = self.transformer.memory_maps(ctx)
+            return self.spatial_decoder(memory[-1], [memory[1], memory[0], feats0])  # '(b t) 8 h/4 w/4'
 
         # The FPN spatial decoder (convs over the memory maps) only meets the query branch (decoder -> VOC ->
         # heads -> controller, ~150 small latency-bound launches) at the dynamic mask head, so it runs on the
@@ -334,9 +340,9 @@ class SOC(nn.Module):
             main = torch.cuda.current_stream(device)
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                fpn = self.spatial_decoder(memory[-1], [memory[1], memory[0], feats0])  # '(b t) 8 h/4 w/4'
+                fpn = run_fpn()
         else:
-            fpn = self.spatial_decoder(memory[-1], [memory[1], memory[0], feats0])
+            fpn = run_fpn()
 
         hs, init_ref, inter_refs = self.transformer.decode(ctx, tgt, self.query_embed.weight)
 

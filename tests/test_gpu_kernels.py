@@ -515,6 +515,84 @@ def test_upsample_add_nchw_vs_torch(ops, N, C, H, W, Hp, Wp):
     assert torch.equal(idx_only, F.interpolate(dev(prev), size=(H, W), mode="nearest"))
 
 
+# ------------------------------------------------------------------ K19 conv3x3 on tokens, K18 token form, token FPN
+@pytest.mark.parametrize("N,H,W,Cin,Cout,nchw,relu", [(8, 12, 20, 256, 256, False, False), (8, 12, 20, 256, 128, False, True),
+                                                      (8, 23, 40, 128, 64, False, False), (2, 45, 80, 64, 32, False, False),
+                                                      (2, 90, 160, 32, 16, False, False), (2, 90, 160, 16, 8, True, False),
+                                                      (1, 5, 7, 16, 3, True, True), (1, 1, 1, 32, 40, False, False)])
+def test_conv3x3_tokens_vs_torch(ops, N, H, W, Cin, Cout, nchw, relu):
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(H * W + Cin + Cout)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w, b = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5, torch.randn(Cout, generator=g)
+    want = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    if relu:
+        want = want.relu()
+    tok = dev(x).permute(0, 2, 3, 1).reshape(N, H * W, Cin).contiguous()
+    taps = dev(w).permute(0, 2, 3, 1).reshape(Cout, -1).contiguous()
+    got = ops.conv3x3_tokens(tok, (H, W), taps, dev(b), out_nchw=nchw, relu=relu)
+    if not nchw:
+        got = got.view(N, H, W, Cout).permute(0, 3, 1, 2)
+    assert got.shape == want.shape
+    assert maxdiff(got, want.float()) < 3e-5
+    # frames read in place out of a wider buffer (a level slice of the encoder memory)
+    wide = torch.zeros(N, H * W + 13, Cin, device="cuda")
+    wide[:, 5:5 + H * W] = tok
+    got2 = ops.conv3x3_tokens(wide[:, 5:5 + H * W], (H, W), taps, dev(b), out_nchw=nchw, relu=relu)
+    if not nchw:
+        got2 = got2.view(N, H, W, Cout).permute(0, 3, 1, 2)
+    assert torch.equal(got2, got)
+
+
+def test_conv3x3_tokens_rejects_unsupported(ops):
+    with pytest.raises(RuntimeError):                     # Cin % 16
+        ops.conv3x3_tokens(torch.zeros(1, 4, 8).cuda(), (2, 2), torch.zeros(4, 72).cuda(), None)
+    with pytest.raises(RuntimeError):                     # channels not innermost
+        ops.conv3x3_tokens(torch.zeros(1, 16, 4).cuda().transpose(1, 2), (2, 2), torch.zeros(4, 144).cuda(), None)
+
+
+@pytest.mark.parametrize("N,C,H,W,Hp,Wp", [(8, 128, 23, 40, 12, 20), (8, 32, 90, 160, 45, 80), (1, 4, 7, 5, 3, 4)])
+def test_upsample_add_tokens_vs_torch(ops, N, C, H, W, Hp, Wp):
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(H * 100 + Wp + 1)
+    lat, prev, b = torch.randn(N, C, H, W, generator=g), torch.randn(N, C, Hp, Wp, generator=g), torch.randn(C, generator=g)
+    want = (dev(lat) + F.interpolate(dev(prev), size=(H, W), mode="nearest")) + dev(b).view(1, -1, 1, 1)
+
+    def tok(t):
+        return dev(t).permute(0, 2, 3, 1).reshape(t.shape[0], -1, t.shape[1]).contiguous()
+
+    got = ops.upsample_add_tokens(tok(lat), dev(b), tok(prev), (H, W), (Hp, Wp))
+    assert maxdiff(got.view(N, H, W, C).permute(0, 3, 1, 2), want.cpu()) < 1e-6
+
+
+def test_fpn_tokens_matches_nchw_ladder():
+    """FPNSpatialDecoder.forward_tokens (K19 / K10 / K18 token form) against the module's CPU forward in f64 (the
+    reference ladder, models/segmentation.py:41-74) at the BASELINE geometry."""
+    import copy
+    import neurips2023_soc_amd as S
+    from neurips2023_soc_amd import weights as W
+    model, _, _ = S.build_model(S.default_args(text_encoder_random_init=True))
+    W.load_synthetic(model, 2023)
+    fpn = model.spatial_decoder.eval()
+    g = torch.Generator().manual_seed(11)
+    shapes = [(45, 80), (23, 40), (12, 20)]
+    n, Ssum = 8, sum(h * w for h, w in shapes) + 60          # + the 4th level's rows, unused by the FPN
+    memory = torch.randn(n, Ssum, 256, generator=g)
+    feats0 = torch.randn(n, 90, 160, 96, generator=g).permute(0, 3, 1, 2)      # channels-last in memory
+    maps, at = [], 0
+    for h, w in shapes:
+        maps.append(memory[:, at:at + h * w].reshape(n, h, w, 256).permute(0, 3, 1, 2))
+        at += h * w
+    ref = copy.deepcopy(fpn).double()
+    with torch.no_grad():
+        want = ref(maps[-1].double(), [maps[1].double(), maps[0].double(), feats0.double()])
+        fg = fpn.cuda()
+        assert fg.tokens_supported(dev(memory))
+        got = fg.forward_tokens(dev(memory), shapes, dev(feats0.contiguous(memory_format=torch.channels_last)))
+    assert got.shape == want.shape
+    assert maxdiff(got, want.float()) < 1e-4 * max(1.0, float(want.abs().max()))
+
+
 # ------------------------------------------------------------------ K6 fused upsample + threshold
 @pytest.mark.parametrize("T,h,w,H0,W0", [(8, 90, 160, 720, 1280), (3, 63, 75, 250, 300), (1, 5, 7, 33, 50),
                                          (2, 90, 160, 360, 640), (1, 9, 9, 9, 9), (0, 4, 4, 8, 8)])
@@ -724,7 +802,9 @@ def test_windowed_voc_module_matches_reference(ops, golden, ref_shapes, tag):
 
 # ------------------------------------------------------------------ K10 GroupNorm over tokens
 @pytest.mark.parametrize("N,S,C,G,shift", [(8, 3600, 256, 32, 0.0), (8, 920, 256, 32, 50.0), (3, 77, 256, 32, 0.0),
-                                           (1, 1, 256, 32, 0.0), (2, 130, 128, 8, -7.0), (0, 5, 256, 32, 0.0)])
+                                           (1, 1, 256, 32, 0.0), (2, 130, 128, 8, -7.0), (0, 5, 256, 32, 0.0),
+                                           (8, 14400, 16, 8, 3.0), (8, 3600, 32, 8, 0.0), (2, 333, 64, 8, 1.0),
+                                           (3, 5, 16, 8, 0.0), (2, 240, 256, 8, 0.0)])
 def test_groupnorm_tokens_vs_torch(ops, N, S, C, G, shift):
     g = torch.Generator().manual_seed(S + C)
     x = torch.randn(N, S, C, generator=g) * 2 + shift          # shift: |mean| >> std must not lose the variance
@@ -735,6 +815,7 @@ def test_groupnorm_tokens_vs_torch(ops, N, S, C, G, shift):
         want = O.groupnorm_tokens_core(x.double(), w.double(), b.double(), G, 1e-5).float()
         assert maxdiff(got, want) < 3e-5 * max(1.0, float(want.abs().max()))
         assert torch.equal(got, ops.groupnorm_tokens(dev(x), dev(w), dev(b), G, 1e-5))   # no atomics: repeatable
+        assert torch.equal(ops.groupnorm_tokens(dev(x), dev(w), dev(b), G, 1e-5, relu=True), got.clamp_min(0))
 
 
 def test_groupnorm_tokens_rejects_unsupported(ops):

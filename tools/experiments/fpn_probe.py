@@ -42,6 +42,12 @@ def timed(fn, reps=50):
 
 t, ref = timed(lambda: fpn(x, feats))
 print(f"default pick, NCHW          {t:.3f} ms", flush=True)
+# the token-major ladder (K19 / K10 / K18): memory levels in place, feats0 channels-last
+shapes = [(45, 80), (23, 40), (12, 20)]
+memory = torch.randn(8, sum(h * w for h, w in shapes) + 60, 256, device="cuda", generator=g)
+f0 = feats[2].contiguous(memory_format=torch.channels_last)
+t, o = timed(lambda: fpn.forward_tokens(memory, shapes, f0))
+print(f"token-major ladder          {t:.3f} ms", flush=True)
 xc, fc = x.contiguous(memory_format=torch.channels_last), [f.contiguous(memory_format=torch.channels_last) for f in feats]
 t, o = timed(lambda: fpn(xc, fc))
 print(f"default pick, channels_last {t:.3f} ms   max|d| {(o - ref).abs().max().item():.2e}", flush=True)
