@@ -173,6 +173,138 @@ __global__ __launch_bounds__(256, 4) void msda_fwd_d32p4_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// fused path with the sampling-point tiles staged in LDS (round 2).  In the kernel above the 8 lanes that share a
+// (query, head) row each repeat the whole per-point arithmetic -- softmax, location, floor, four bilinear weights, four
+// clamped addresses: ~40 vector instructions x 16 points per lane -- and the counters (profiles/r02_k2_counters.json)
+// show the launch vector-issue-bound: 54.9 M vector instructions, 93 us of VALU time in a 131-us kernel.  Here every lane
+// works out TWO of its group's 16 points once (phase 1: lane c of the group takes points 2c, 2c+1, the softmax runs over
+// the 8 lanes with DPP shuffles) and writes (4 byte offsets, 4 weights) per point to LDS; phase 2 reads them back as two
+// broadcast ds_read_b128 per point (the 8 groups of a wave sit 136 dwords apart: conflict-free) and is the plain gather:
+// 4 buffer loads + 16 FMAs per point.  A group's producers and consumers are the same 8 lanes of one wave, so no
+// workgroup barrier is needed.  Same per-point formulas as above; the softmax sums in another order.
+// ---------------------------------------------------------------------------------------------
+constexpr int TILE_GROUP_STRIDE = 16 * 8 + 8;     // dwords per (query, head) group: 16 points x (4 offsets + 4 weights) + pad
+
+__global__ __launch_bounds__(256, 4) void msda_fused_tiles_kernel(
+    const float* __restrict__ value, const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
+    const float* __restrict__ offs, const float* __restrict__ logits, float* __restrict__ out, int N, int S, int M,
+    int Lq, int groups_per_frame, const float* __restrict__ ref, int ref_dim, const uint8_t* __restrict__ pad,
+    const int* __restrict__ any_pad) {
+    __shared__ __attribute__((aligned(16))) unsigned tile[32 * TILE_GROUP_STRIDE];
+    const int n = blockIdx.x % N;        // XCD-friendly: blocks b, b+8, ... share an XCD
+    const int chunk = blockIdx.x / N;
+    const int sub = threadIdx.x >> 3;    // 32 (query, head) groups per block
+    const int c4 = threadIdx.x & 7;      // phase 1: points 2*c4, 2*c4+1; phase 2: which float4 of the 32 channels
+    const int g = min(chunk * 32 + sub, groups_per_frame - 1);      // groups past the end recompute the last one
+    const bool live = chunk * 32 + sub < groups_per_frame;
+    const int m = g % M;
+    const long gi = (long)n * groups_per_frame + g;          // (n, q, m) flat
+    const unsigned rstride = (unsigned)M * 32u * 4u;         // bytes between consecutive spatial positions
+
+    // ---- phase 1: two points of the group per lane
+    {
+        const float2 lg = reinterpret_cast<const float2*>(logits + gi * 16)[c4];
+        float mx = fmaxf(lg.x, lg.y);
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        const float e0 = __expf(lg.x - mx), e1 = __expf(lg.y - mx);
+        float sum = e0 + e1;
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) sum += __shfl_xor(sum, o);
+        const float inv = __builtin_amdgcn_rcpf(sum);      // 1 ulp: the weights are a convex combination either way
+        const float wsm[2] = {e0 * inv, e1 * inv};
+        const float4 of = reinterpret_cast<const float4*>(offs + gi * 32)[c4];      // (x, y) of the two points
+        const int l = c4 >> 1;
+        const int Hl = (int)shapes[2 * l], Wl = (int)shapes[2 * l + 1];
+        const int lstart = (int)lsi[l];
+        const float* rp = ref + (((long)n * Lq + g / M) * 4 + l) * ref_dim;
+        float xs[2] = {of.x, of.z}, ys[2] = {of.y, of.w};
+        if (ref_dim == 2) {
+            const float rW = 1.0f / (float)Wl, rH = 1.0f / (float)Hl;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { xs[j] = rp[0] + xs[j] * rW; ys[j] = rp[1] + ys[j] * rH; }
+        } else {
+            const float rw = rp[2], rh = rp[3];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {      // / 4 is exact (power of two)
+                xs[j] = rp[0] + xs[j] * 0.25f * rw * 0.5f;
+                ys[j] = rp[1] + ys[j] * 0.25f * rh * 0.5f;
+            }
+        }
+        const bool use_pad = pad != nullptr && any_pad != nullptr && *any_pad != 0;
+        const uint8_t* padn = pad + (long)n * S;
+        unsigned* dst = tile + sub * TILE_GROUP_STRIDE + (2 * c4) * 8;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float him = ys[j] * Hl - 0.5f;
+            const float wim = xs[j] * Wl - 0.5f;
+            const bool ok = him > -1.f && wim > -1.f && him < Hl && wim < Wl;
+            const float hf = floorf(him), wf = floorf(wim);
+            const float lh = him - hf, lw = wim - wf;
+            const float hh = 1.f - lh, hw = 1.f - lw;
+            const int h0 = (int)fminf(fmaxf(hf, -1.f), (float)Hl);
+            const int w0 = (int)fminf(fmaxf(wf, -1.f), (float)Wl);
+            const bool h0ok = ok && h0 >= 0, h1ok = ok && h0 + 1 <= Hl - 1;
+            const bool w0ok = w0 >= 0, w1ok = w0 + 1 <= Wl - 1;
+            const int h0c = min(max(h0, 0), Hl - 1), h1c = min(max(h0 + 1, 0), Hl - 1);
+            const int w0c = min(max(w0, 0), Wl - 1), w1c = min(max(w0 + 1, 0), Wl - 1);
+            const float wgt = wsm[j];
+            float tw[4] = {(h0ok && w0ok) ? hh * hw * wgt : 0.f, (h0ok && w1ok) ? hh * lw * wgt : 0.f,
+                           (h1ok && w0ok) ? lh * hw * wgt : 0.f, (h1ok && w1ok) ? lh * lw * wgt : 0.f};
+            const int pos[4] = {lstart + h0c * Wl + w0c, lstart + h0c * Wl + w1c, lstart + h1c * Wl + w0c,
+                                lstart + h1c * Wl + w1c};
+            if (use_pad) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (padn[pos[k]]) tw[k] = 0.f;
+            }
+            const unsigned head_off = (unsigned)m * 128u;
+            *reinterpret_cast<u32x4*>(dst + j * 8) = (u32x4){__umul24(pos[0], rstride) + head_off, __umul24(pos[1], rstride) + head_off,
+                                                            __umul24(pos[2], rstride) + head_off, __umul24(pos[3], rstride) + head_off};
+            *reinterpret_cast<float4*>(dst + j * 8 + 4) = make_float4(tw[0], tw[1], tw[2], tw[3]);
+        }
+    }
+    // producers and consumers of a group's tile are the same 8 lanes of one wave: order the LDS traffic, no s_barrier
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // ---- phase 2: the gather.  Taps are buffer loads: <frame descriptor> + <32-bit per-lane byte offset>
+    const __amdgpu_buffer_rsrc_t vframe = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(value + (long)n * S * M * 32), 0, S * M * 32 * 4, 0x00020000);
+    const unsigned lane_off = (unsigned)c4 * 16u;
+    const unsigned* src = tile + sub * TILE_GROUP_STRIDE;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 1
+    for (int l = 0; l < 4; ++l) {
+        u32x4 po[4];
+        float4 tw[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            po[p] = *reinterpret_cast<const u32x4*>(src + (l * 4 + p) * 8);
+            tw[p] = *reinterpret_cast<const float4*>(src + (l * 4 + p) * 8 + 4);
+        }
+        float4 tv[4][4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(vframe, po[p][k] + lane_off, 0, 0);
+                tv[p][k] = make_float4(__uint_as_float(raw.x), __uint_as_float(raw.y), __uint_as_float(raw.z),
+                                       __uint_as_float(raw.w));
+            }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            fma4(acc, tw[p].x, tv[p][0]);
+            fma4(acc, tw[p].y, tv[p][1]);
+            fma4(acc, tw[p].z, tv[p][2]);
+            fma4(acc, tw[p].w, tv[p][3]);
+        }
+    }
+    if (live) *reinterpret_cast<float4*>(out + gi * 32 + c4 * 4) = acc;
+}
+
+// ---------------------------------------------------------------------------------------------
 // generic path: one thread per output scalar (any D, float or double)
 // ---------------------------------------------------------------------------------------------
 template <typename T>
@@ -285,8 +417,8 @@ extern "C" int soc_msda_fused_fwd_f32(const float* value, const uint8_t* value_p
     if ((value_pad_mask == nullptr) != (any_pad == nullptr)) return SOC_EINVAL;
     const int gpf = Lq * M;
     const int bpf = soc_ceil_div(gpf, 32);
-    hipLaunchKernelGGL(msda_fwd_d32p4_kernel<true>, dim3(bpf * N), dim3(256), 0, (hipStream_t)stream, value,
-                       spatial_shapes, level_start_index, offsets, attn_logits, out, N, S, M, L, Lq, gpf,
-                       ref_points, ref_dim, value_pad_mask, (const int*)any_pad);
+    hipLaunchKernelGGL(msda_fused_tiles_kernel, dim3(bpf * N), dim3(256), 0, (hipStream_t)stream, value, spatial_shapes,
+                       level_start_index, offsets, attn_logits, out, N, S, M, Lq, gpf, ref_points, ref_dim, value_pad_mask,
+                       (const int*)any_pad);
     return soc_check_launch();
 }
