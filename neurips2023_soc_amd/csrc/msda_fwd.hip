@@ -195,9 +195,12 @@ __global__ __launch_bounds__(256, 4) void msda_fused_tiles_kernel(
     const int chunk = blockIdx.x / N;
     const int sub = threadIdx.x >> 3;    // 32 (query, head) groups per block
     const int c4 = threadIdx.x & 7;      // phase 1: points 2*c4, 2*c4+1; phase 2: which float4 of the 32 channels
-    const int g = min(chunk * 32 + sub, groups_per_frame - 1);      // groups past the end recompute the last one
-    const bool live = chunk * 32 + sub < groups_per_frame;
-    const int m = g % M;
+    // a block = 32 consecutive queries of ONE head, so a wave = 8 raster-adjacent queries whose taps share L1 lines
+    // (98.5 vs 101.6 us for the 8-heads-of-one-query order of the kernel above)
+    const int m = chunk % M;
+    const int q_ = (chunk / M) * 32 + sub;
+    const bool live = q_ < Lq;                                // queries past the end recompute the last one
+    const int g = min(q_, Lq - 1) * M + m;
     const long gi = (long)n * groups_per_frame + g;          // (n, q, m) flat
     const unsigned rstride = (unsigned)M * 32u * 4u;         // bytes between consecutive spatial positions
 
@@ -416,7 +419,7 @@ extern "C" int soc_msda_fused_fwd_f32(const float* value, const uint8_t* value_p
         return SOC_EUNSUPPORTED;   // 32-bit tap offsets inside a frame, 24-bit multiplies
     if ((value_pad_mask == nullptr) != (any_pad == nullptr)) return SOC_EINVAL;
     const int gpf = Lq * M;
-    const int bpf = soc_ceil_div(gpf, 32);
+    const int bpf = soc_ceil_div(Lq, 32) * M;
     hipLaunchKernelGGL(msda_fused_tiles_kernel, dim3(bpf * N), dim3(256), 0, (hipStream_t)stream, value, spatial_shapes,
                        level_start_index, offsets, attn_logits, out, N, S, M, Lq, gpf, ref_points, ref_dim, value_pad_mask,
                        (const int*)any_pad);
