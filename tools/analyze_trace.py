@@ -14,7 +14,7 @@ t0, t1 = int(seg[0]["Start_Timestamp"]), int(seg[-1]["End_Timestamp"])
 def cat(n):
     if any(k in n for k in ("win_attn", "msda", "xattn", "dyn_mask", "add_layernorm", "linear_small", "box_refine",
                             "upsample_threshold", "upsample_merge", "upsample_add_nchw", "resize_", "gemm_nt_kernel", "gn_stats", "gn_apply",
-                            "patch_merge", "ws_linear", "dec_cross_attn", "row_mlp", "groupnorm_nchw")):
+                            "patch_merge", "ws_linear", "dec_cross_attn", "row_mlp", "groupnorm_nchw", "conv3x3_tokens")):
         return "soc_hip kernels"
     if n.startswith("Cijk"):
         return "GEMM (hipBLASLt/rocBLAS)"
