@@ -69,7 +69,7 @@ class ClipGraph:
 class PipelinedClipGraph:
     """Two clips in flight inside ONE stream of graph replays (software pipeline across clips).
 
-    Graph k runs the TAIL of the previous clip (FPN, query decoder, VOC, heads, mask head, selection -- ~150 short,
+    Graph k runs the TAIL of the previous clip (FPN, query decoder, VOC, heads, mask head, selection -- ~120 short,
     latency-bound launches that leave most of the GPU idle) on a side branch while the HEAD of the next clip
     (text ‖ Video-Swin, fusion, deformable encoder -- chip-filling kernels) runs on the main branch.  The head hands
     over through a double-buffered static state, so graphs 0 / 1 alternate and are never replayed concurrently

@@ -1,4 +1,4 @@
-"""Host-side entry points of the four HIP hot ops (torch tensors in, torch tensors out).
+"""Host-side entry points of the HIP kernels K1-K19 (torch tensors in, torch tensors out).
 
 Every function requires CUDA(=HIP) tensors and calls straight into libsoc_hip.so through the C
 ABI of include/soc_hip.h on torch's current stream.  There is deliberately no fallback: CPU
