@@ -10,13 +10,11 @@ bias-free adds, LayerNorms, GELU) that run on the side branch beside Video-Swin 
     ->  K7 (attention.output.dense)  ->  K5 (residual + LayerNorm)
     ->  K7 (intermediate.dense with the exact-erf GELU in its epilogue)  ->  K7 (output.dense)  ->  K5
 
-Parameters, state_dict keys and the module tree are HuggingFace's; only `forward` of the layer instances is bound, and it
-falls back to the original for anything it does not cover (CPU, training, decoder / cross-attention, caches, attention
+Parameters, state_dict keys and the module tree are HuggingFace's; the layer instances are re-classed to a subclass that
+overrides `forward`, which falls back to the original for anything it does not cover (CPU, training, decoder / cross-attention, caches, attention
 probabilities requested, another activation).  Embeddings, mask construction and the pooler stay HuggingFace code.
 """
 from __future__ import annotations
-
-import types
 
 import torch
 import torch.nn.functional as F
@@ -25,11 +23,15 @@ from torch import nn
 from . import fused, hot_ops
 
 
-def _small_row_linear(self, x):
-    """nn.Linear.forward routed through fused.linear (K7 for few rows, the library GEMM otherwise)."""
-    if x.is_cuda and x.dtype == torch.float32:
-        return fused.linear(x, self.weight, self.bias)
-    return F.linear(x, self.weight, self.bias)
+class RoutedLinear(nn.Linear):
+    """nn.Linear whose forward goes through fused.linear (K7 for few rows, the library GEMM otherwise).  Instances are
+    made by re-classing existing nn.Linear modules, so parameters and state_dict keys are untouched and copies / pickles of
+    the model keep working (a method bound to an instance would keep pointing at the original module's weights)."""
+
+    def forward(self, x):
+        if x.is_cuda and x.dtype == torch.float32:
+            return fused.linear(x, self.weight, self.bias)
+        return F.linear(x, self.weight, self.bias)
 
 
 def _covered(layer, hidden_states, args, kwargs) -> bool:
@@ -47,7 +49,7 @@ def _covered(layer, hidden_states, args, kwargs) -> bool:
 
 def _layer_forward(self, hidden_states, attention_mask=None, *args, **kwargs):
     if not _covered(self, hidden_states, args, kwargs):
-        return self._soc_orig_forward(hidden_states, attention_mask, *args, **kwargs)
+        return self._soc_orig_forward(hidden_states, attention_mask, *args, **kwargs)       # the parent class's forward
     att, att_out, inter, out = self.attention.self, self.attention.output, self.intermediate, self.output
     B, L, E = hidden_states.shape
     nh = att.num_attention_heads
@@ -65,21 +67,39 @@ def _layer_forward(self, hidden_states, attention_mask=None, *args, **kwargs):
     return y if self._soc_returns_tensor else (y,)
 
 
+_FAST_CLASSES = {}
+
+
+def _fast_layer_class(cls):
+    """Subclass of a HuggingFace encoder-layer class whose forward is _layer_forward (the original stays reachable as
+    _soc_orig_forward).  One per original class, registered in this module so that pickling by reference works."""
+    if cls not in _FAST_CLASSES:
+        import transformers
+        name = "Fast" + cls.__name__
+        sub = type(name, (cls,), {"forward": _layer_forward, "_soc_orig_forward": cls.forward,
+                                  "_soc_returns_tensor": int(transformers.__version__.split(".")[0]) >= 5,   # 4.x: tuple
+                                  "__module__": __name__})
+        globals()[name] = sub
+        _FAST_CLASSES[cls] = sub
+    return _FAST_CLASSES[cls]
+
+
 def accelerate_text_encoder(text_encoder: nn.Module) -> int:
-    """Bind the fast forward to every RobertaLayer-shaped module of `text_encoder` and route its remaining nn.Linear
-    layers (pooler) through K7.  Returns the number of encoder layers bound (0: unknown module layout, nothing changed
-    except the Linear routing)."""
-    import transformers
-    returns_tensor = int(transformers.__version__.split(".")[0]) >= 5      # 4.x layers return a tuple
+    """Re-class every RobertaLayer-shaped module of `text_encoder` to its fast subclass and its remaining nn.Linear layers
+    (pooler) to RoutedLinear.  Idempotent.  Returns the number of encoder layers on the fast forward (0: unknown module
+    layout, nothing changed except the Linear routing)."""
     n = 0
     for m in text_encoder.modules():
         if type(m) is nn.Linear and m.in_features % 16 == 0:
-            m.forward = types.MethodType(_small_row_linear, m)
+            m.__class__ = RoutedLinear
     for m in text_encoder.modules():
+        if type(m) in _FAST_CLASSES.values():
+            n += 1
+            continue
         try:
             att, inter, out = m.attention.self, m.intermediate, m.output
-            shaped = (all(type(x) is nn.Linear for x in (att.query, att.key, att.value, m.attention.output.dense,
-                                                          inter.dense, out.dense))
+            shaped = (all(isinstance(x, nn.Linear) for x in (att.query, att.key, att.value, m.attention.output.dense,
+                                                             inter.dense, out.dense))
                       and type(m.attention.output.LayerNorm) is nn.LayerNorm and type(out.LayerNorm) is nn.LayerNorm)
         except AttributeError:
             continue
@@ -89,9 +109,6 @@ def accelerate_text_encoder(text_encoder: nn.Module) -> int:
             exact_gelu = False
         if not (shaped and exact_gelu) or getattr(att, "position_embedding_type", "absolute") != "absolute":
             continue
-        if not hasattr(m, "_soc_orig_forward"):
-            m._soc_orig_forward = m.forward
-            m._soc_returns_tensor = returns_tensor
-            m.forward = types.MethodType(_layer_forward, m)
+        m.__class__ = _fast_layer_class(type(m))
         n += 1
     return n
