@@ -84,7 +84,10 @@ int soc_msda_bwd_f64(const double* value, const int64_t* spatial_shapes, const i
  *   offsets        [N, Lq, M, L, P, 2]  raw sampling_offsets Linear output
  *   attn_logits    [N, Lq, M, L*P]      raw attention_weights Linear output (softmax in-kernel)
  * Built for D = 32, L = 4, P = 4 (every shipped config); other shapes: SOC_EUNSUPPORTED, use
- * soc_msda_fwd_f32.
+ * soc_msda_fwd_f32.  Tap addresses are 32-bit byte offsets inside a frame formed with 24-bit multiplies:
+ * S * M * 128 < 2^31, S < 2^24 and M * 128 < 2^24 are required (a 720x1280 clip has S = 19 160; the limit is
+ * S ~ 2 million positions at 8 heads); beyond that SOC_EUNSUPPORTED -- soc_msda_fwd_f32 then takes its
+ * 64-bit generic path for the same sizes.
  */
 int soc_msda_fused_fwd_f32(const float* value, const uint8_t* value_pad_mask, const int32_t* any_pad,
                            const int64_t* spatial_shapes, const int64_t* level_start_index,

@@ -274,3 +274,107 @@ class VideoClipCache:
 
 def frame_paths(img_folder: str, video: str, frames: Sequence[str], ext: str = ".jpg") -> List[str]:
     return [os.path.join(img_folder, video, f + ext) for f in frames]
+
+
+class _NoStream:
+    """CPU stand-in for a HIP stream: everything is already ordered."""
+
+    def wait_event(self, ev):
+        pass
+
+
+class DoubleBufferedH2D:
+    """Host clips -> device through `depth` device slots, copies on their own stream ahead of the compute stream.
+
+    The reference copies every clip to the device inside its loop (`samples.to(device)`, infer_refytb.py:206-212), from
+    pageable memory, on the compute stream: the forward waits for 22 MB over PCIe per clip.  Here the host side hands over
+    PINNED tensors (PinnedPool, or any `pin_memory()`-ed tensor) and
+
+        feeder.submit(host[0])
+        for i in range(n):
+            if i + 1 < n: feeder.submit(host[i + 1])      # clip i+1 crosses PCIe while clip i computes
+            clip = feeder.acquire()                        # compute stream waits for clip i's copy only
+            ... launch the work that reads `clip` ...
+            feeder.release()                               # slot may be refilled once that work has run
+
+    Ordering rules (checked by tests/test_clip_io.py with recording stand-ins for streams and events): the copy into a
+    slot waits for the `free` event of the work that last read the slot; the compute stream waits for the slot's `ready`
+    event; at most `depth` clips are submitted and not yet released, a further submit() raises instead of overwriting.
+    `copy_stream` / `compute_stream` / `event_factory` exist for those tests (objects with `wait_event(ev)`; events with
+    `record(stream)`); by default they are a fresh HIP stream, the current stream, and `torch.cuda.Event`.
+    """
+
+    def __init__(self, shape: Sequence[int], dtype=torch.float32, device="cuda", depth: int = 2,
+                 copy_stream=None, compute_stream=None, event_factory=None):
+        self.device = torch.device(device)
+        self.depth = int(depth)
+        if self.depth < 2:
+            raise ValueError("one slot cannot be filled while it is being read")
+        cuda = self.device.type == "cuda"
+        self.slots = [torch.empty(tuple(shape), dtype=dtype, device=self.device) for _ in range(self.depth)]
+        if copy_stream is None:
+            copy_stream = torch.cuda.Stream(device=self.device) if cuda else _NoStream()
+        self._copy = copy_stream
+        self._compute = compute_stream                     # None: the current stream at the time of the call
+        self._event = event_factory if event_factory is not None else (torch.cuda.Event if cuda else (lambda: None))
+        self._ready = [None] * self.depth
+        self._free = [None] * self.depth
+        self._host = [None] * self.depth                   # keeps the pinned source alive until the slot is released
+        self._submitted = self._acquired = self._released = 0
+
+    def _cur(self):
+        if self._compute is not None:
+            return self._compute
+        return torch.cuda.current_stream(self.device) if self.device.type == "cuda" else _NoStream()
+
+    def _record(self, stream):
+        ev = self._event()
+        if ev is not None:
+            ev.record(stream)
+        return ev
+
+    def in_flight(self) -> int:
+        return self._submitted - self._released
+
+    def submit(self, host: torch.Tensor, on_copied=None) -> int:
+        """Enqueue the copy of `host` into the next slot; returns the slot index.  `on_copied(event)` is called with
+        the event that fires when the bytes have left `host` (PinnedEntry.release fits)."""
+        if self.in_flight() >= self.depth:
+            raise RuntimeError("DoubleBufferedH2D: every slot is still in use (submit without a matching release)")
+        k = self._submitted % self.depth
+        cs = self._copy
+        if self._free[k] is not None:
+            cs.wait_event(self._free[k])                   # the work that read this slot last has run
+        if isinstance(cs, torch.cuda.Stream):
+            with torch.cuda.stream(cs):
+                self.slots[k].copy_(host.view(self.slots[k].shape), non_blocking=True)
+        else:
+            self.slots[k].copy_(host.view(self.slots[k].shape))
+        ev = self._ready[k] = self._record(cs)
+        self._host[k] = host
+        self._submitted += 1
+        if on_copied is not None:
+            on_copied(ev)
+        return k
+
+    def acquire(self) -> torch.Tensor:
+        """Device tensor of the oldest submitted, not yet acquired clip; the compute stream waits for its copy."""
+        if self._acquired >= self._submitted:
+            raise RuntimeError("DoubleBufferedH2D: acquire() without a submitted clip")
+        if self._acquired > self._released:
+            raise RuntimeError("DoubleBufferedH2D: release() the previous clip first")
+        k = self._acquired % self.depth
+        if self._ready[k] is not None:
+            self._cur().wait_event(self._ready[k])
+        self._acquired += 1
+        return self.slots[k]
+
+    def release(self) -> None:
+        """The work reading the acquired slot has been enqueued on the compute stream: mark the point after which the
+        slot may be overwritten."""
+        if self._released >= self._acquired:
+            raise RuntimeError("DoubleBufferedH2D: release() without acquire()")
+        k = self._released % self.depth
+        self._free[k] = self._record(self._cur())
+        self._host[k] = None
+        self._released += 1

@@ -32,20 +32,13 @@ __device__ __forceinline__ void fma4(float4& a, float w, const float4& v) {
     a.x += w * v.x; a.y += w * v.y; a.z += w * v.z; a.w += w * v.w;
 }
 
-// FUSED = true additionally folds in what MSDeformAttn.forward does around the op (reference
-// models/ops/modules/ms_deform_attn.py:95-112): `loc` then holds the RAW sampling offsets and `attw`
-// the RAW attention logits; the kernel computes softmax over the L*P = 16 logits, the sampling
-// locations ref + off / (W_l, H_l)  (2-d refs) or ref_xy + off / P * ref_wh * 0.5  (4-d refs), and
-// applies the value padding mask per tap (only when the device-side flag says padding exists).
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-template <bool FUSED>
 __global__ __launch_bounds__(256, 4) void msda_fwd_d32p4_kernel(
     const float* __restrict__ value, const int64_t* __restrict__ shapes,
     const int64_t* __restrict__ lsi, const float* __restrict__ loc,
     const float* __restrict__ attw, float* __restrict__ out, int N, int S, int M, int L, int Lq,
-    int groups_per_frame /* = Lq*M */, const float* __restrict__ ref, int ref_dim,
-    const uint8_t* __restrict__ pad, const int* __restrict__ any_pad) {
+    int groups_per_frame /* = Lq*M */) {
     const int n = blockIdx.x % N;        // XCD-friendly: blocks b, b+8, ... share an XCD
     const int chunk = blockIdx.x / N;
     const int sub = threadIdx.x >> 3;    // 32 (query, head) groups per block
@@ -63,32 +56,6 @@ __global__ __launch_bounds__(256, 4) void msda_fwd_d32p4_kernel(
     const unsigned lane_off = (unsigned)(m * 32 + c4 * 4) * 4u;
     const unsigned rstride = (unsigned)M * 32u * 4u;  // bytes between consecutive spatial positions
 
-    // FUSED: softmax over the 16 logits of this (query, head) -- L == 4 is enforced by the host
-    float4 sm[4];
-    bool use_pad = false;
-    const float* rp = nullptr;
-    const uint8_t* padn = nullptr;
-    if (FUSED) {
-#pragma unroll
-        for (int l = 0; l < 4; ++l) sm[l] = wp[l];
-        float mx = -INFINITY;
-#pragma unroll
-        for (int l = 0; l < 4; ++l) mx = fmaxf(mx, fmaxf(fmaxf(sm[l].x, sm[l].y), fmaxf(sm[l].z, sm[l].w)));
-        float sum = 0.f;
-#pragma unroll
-        for (int l = 0; l < 4; ++l) {
-            sm[l].x = __expf(sm[l].x - mx); sm[l].y = __expf(sm[l].y - mx);
-            sm[l].z = __expf(sm[l].z - mx); sm[l].w = __expf(sm[l].w - mx);
-            sum += (sm[l].x + sm[l].y) + (sm[l].z + sm[l].w);
-        }
-        const float inv = 1.f / sum;
-#pragma unroll
-        for (int l = 0; l < 4; ++l) { sm[l].x *= inv; sm[l].y *= inv; sm[l].z *= inv; sm[l].w *= inv; }
-        rp = ref + ((long)n * Lq + g / M) * (long)(L * ref_dim);
-        use_pad = pad != nullptr && any_pad != nullptr && *any_pad != 0;  // wave-uniform
-        padn = pad + (long)n * S;
-    }
-
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 1
     for (int l = 0; l < L; ++l) {
@@ -96,27 +63,9 @@ __global__ __launch_bounds__(256, 4) void msda_fwd_d32p4_kernel(
         const int lstart = (int)lsi[l];
         const unsigned vl = (unsigned)lstart * rstride;       // wave-uniform byte offset of the level
         const float4 la = lp[2 * l], lb = lp[2 * l + 1];
-        const float4 wv = FUSED ? sm[l & 3] : wp[l];
+        const float4 wv = wp[l];
         float xs[4] = {la.x, la.z, lb.x, lb.z};
         float ys[4] = {la.y, la.w, lb.y, lb.w};
-        if (FUSED) {
-            const float rx = rp[l * ref_dim], ry = rp[l * ref_dim + 1];
-            if (ref_dim == 2) {
-                // off / (W_l, H_l) as a multiplication by the level's reciprocal (wave-uniform, one division per
-                // level instead of 8 per lane: the IEEE division sequence is ~10 VALU instructions); <= 1 ulp from
-                // the reference's true division, i.e. ~1e-7 of a pixel
-                const float rW = 1.0f / (float)Wl, rH = 1.0f / (float)Hl;
-#pragma unroll
-                for (int p = 0; p < 4; ++p) { xs[p] = rx + xs[p] * rW; ys[p] = ry + ys[p] * rH; }
-            } else {
-                const float rw = rp[l * ref_dim + 2], rh = rp[l * ref_dim + 3];
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {      // / 4 is exact (power of two)
-                    xs[p] = rx + xs[p] * 0.25f * rw * 0.5f;
-                    ys[p] = ry + ys[p] * 0.25f * rh * 0.5f;
-                }
-            }
-        }
         const float ws[4] = {wv.x, wv.y, wv.z, wv.w};
         float tw[4][4];
         unsigned ptr[4][4];
@@ -148,12 +97,6 @@ __global__ __launch_bounds__(256, 4) void msda_fwd_d32p4_kernel(
             ptr[p][1] = r0 + c1;
             ptr[p][2] = r1 + c0;
             ptr[p][3] = r1 + c1;
-            if (FUSED && use_pad) {  // value.masked_fill(padding_mask, 0): a padded position samples 0
-                if (padn[lstart + h0c * Wl + w0c]) tw[p][0] = 0.f;
-                if (padn[lstart + h0c * Wl + w1c]) tw[p][1] = 0.f;
-                if (padn[lstart + h1c * Wl + w0c]) tw[p][2] = 0.f;
-                if (padn[lstart + h1c * Wl + w1c]) tw[p][3] = 0.f;
-            }
         }
         float4 tv[4][4];
 #pragma unroll
@@ -196,9 +139,13 @@ __global__ __launch_bounds__(256, 4) void msda_fused_tiles_kernel(
     const int sub = threadIdx.x >> 3;    // 32 (query, head) groups per block
     const int c4 = threadIdx.x & 7;      // phase 1: points 2*c4, 2*c4+1; phase 2: which float4 of the 32 channels
     // a block = 32 consecutive queries of ONE head, so a wave = 8 raster-adjacent queries whose taps share L1 lines
-    // (98.5 vs 101.6 us for the 8-heads-of-one-query order of the kernel above)
-    const int m = chunk % M;
-    const int q_ = (chunk / M) * 32 + sub;
+    // (98.5 vs 101.6 us for the 8-heads-of-one-query order of the kernel above).  The head is the SLOW index inside a
+    // frame: the blocks an XCD has in flight (its frame's, in chunk order) then sample one or two heads' 617-KB value
+    // planes at a time, which its 4 MiB L2 holds -- with the head fastest they cycled through all 8 heads of the 4.9 MB
+    // map (PMC traffic 198 MB per encoder call against 138 MB algorithmic, L2 hit rate 0.90 in round 2)
+    const int nqb = (Lq + 31) >> 5;
+    const int m = chunk / nqb;
+    const int q_ = (chunk - m * nqb) * 32 + sub;
     const bool live = q_ < Lq;                                // queries past the end recompute the last one
     const int g = min(q_, Lq - 1) * M + m;
     const long gi = (long)n * groups_per_frame + g;          // (n, q, m) flat
@@ -382,10 +329,9 @@ extern "C" int soc_msda_fwd_f32(const float* value, const int64_t* spatial_shape
     if (D == 32 && P == 4 && (long)S * M * 128 < (1L << 31) && S < (1 << 24) && M * 128 < (1 << 24)) {   // 32-bit tap offsets
         const int gpf = Lq * M;
         const int bpf = soc_ceil_div(gpf, 32);
-        hipLaunchKernelGGL(msda_fwd_d32p4_kernel<false>, dim3(bpf * N), dim3(256), 0, st, value,
+        hipLaunchKernelGGL(msda_fwd_d32p4_kernel, dim3(bpf * N), dim3(256), 0, st, value,
                            spatial_shapes, level_start_index, sampling_loc, attn_weight, out, N,
-                           S, M, L, Lq, gpf, (const float*)nullptr, 0, (const uint8_t*)nullptr,
-                           (const int*)nullptr);
+                           S, M, L, Lq, gpf);
         return soc_check_launch();
     }
     return launch_generic<float>(value, spatial_shapes, level_start_index, sampling_loc,

@@ -190,7 +190,7 @@ def _run_dataset(a):
     print(json.dumps({"rank": rank, "world": world, **stats}))
 
 
-def main(argv=None):
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--clips", type=int, default=16)
     ap.add_argument("--backbone", default="video-swin-t")
@@ -208,9 +208,18 @@ def main(argv=None):
     ap.add_argument("--graphs", action="store_true", help="hipGraph replay per clip geometry in the dataset drivers")
     ap.add_argument("--words", type=int, default=0, help="--make-synthetic: fixed number of words per expression")
     ap.add_argument("--repeat", type=int, default=1, help="run the driver this many times, report the last (warm) pass")
-    ap.add_argument("--gpus", "-ng", type=int, default=1,
-                    help="GPUs of this node; >1 without an outer launcher starts one rank per GPU (reference -ng)")
+    ap.add_argument("--gpus", "-ng", type=int, default=None,
+                    help="GPUs of this node; >1 without an outer launcher starts one rank per GPU (reference -ng).  "
+                         "Default: WORLD_SIZE under an outer launcher, 1 otherwise; an explicit value must equal WORLD_SIZE")
     a = ap.parse_args(argv)
+    a.gpus_given = a.gpus is not None
+    if a.gpus is None:
+        a.gpus = int(os.environ["WORLD_SIZE"]) if CP.launched_as_rank() else 1
+    return a
+
+
+def main(argv=None):
+    a = parse_args(argv)
     if a.gpus > 1 and not CP.launched_as_rank():
         # one process per GPU, started before this process touches the GPU (reference infer_refytb.py:84-109)
         import sys
@@ -235,14 +244,23 @@ def main(argv=None):
     records = torch.zeros(n_local, CP.record_size(T, 20, hm, wm), device=dev)
     fg = torch.zeros(n_local, device=dev)
     # synthetic stream: clip i / expression i from seeds, like tests/golden (seed 1 == golden clip)
-    clips = [W.synthetic_clip(1 + i, T, H, Wd) for i in mine]
-    ids = [W.synthetic_token_ids(1 + i, L) for i in mine]
+    clips = [W.synthetic_clip(1 + i, T, H, Wd).pin_memory() for i in mine]
+    ids = [W.synthetic_token_ids(1 + i, L).to(dev) for i in mine]
+    from .clip_io import DoubleBufferedH2D
+    feeder = DoubleBufferedH2D((T, 3, H, Wd), torch.float32, dev, depth=2)
 
     def run_local(out):
-        for slot, (c, t) in enumerate(zip(clips, ids)):
-            res = run(c.to(dev, non_blocking=True), t.to(dev), a.orig)   # H2D inside the loop, like the reference
+        # H2D inside the loop, like the reference (infer_refytb.py:206-212), but from pinned memory on a copy stream,
+        # one clip ahead of the compute stream
+        if clips:
+            feeder.submit(clips[0])
+        for slot, t in enumerate(ids):
+            if slot + 1 < len(clips):
+                feeder.submit(clips[slot + 1])
+            res = run(feeder.acquire(), t, a.orig)
             out[slot].copy_(res["record"])
             fg[slot] = res["masks"].float().mean()
+            feeder.release()
 
     timed = CP.timed_sharded_run(run_local, records, dev)             # the one collective sits inside
     gathered, dt = CP.interleave(timed["gathered"], a.clips), timed["seconds"]

@@ -29,13 +29,26 @@ class RoutedLinear(nn.Linear):
     the model keep working (a method bound to an instance would keep pointing at the original module's weights)."""
 
     def forward(self, x):
-        if x.is_cuda and x.dtype == torch.float32:
+        # the K7 path has no autograd: anything that may need a gradient (fine-tuning with freeze_text_encoder=False)
+        # goes through F.linear
+        needs_grad = torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad)
+        if x.is_cuda and x.dtype == torch.float32 and not needs_grad:
             return fused.linear(x, self.weight, self.bias)
         return F.linear(x, self.weight, self.bias)
 
 
+FAST_LAYER_CALLS = 0     # encoder-layer forwards that took the 7-launch form (tests assert that it is not dead code)
+
+
 def _covered(layer, hidden_states, args, kwargs) -> bool:
-    if args or layer.training or not hidden_states.is_cuda or hidden_states.dtype != torch.float32:
+    # HuggingFace passes some of the optional arguments POSITIONALLY (transformers 5.x: RobertaEncoder.forward hands
+    # `encoder_hidden_states` over as the third positional argument; 4.x: head_mask, ..., output_attentions), in an order
+    # that differs between releases.  Whatever they are, a None / False there requests nothing.
+    if any(a is not None and a is not False for a in args):
+        return False
+    if layer.training or not hidden_states.is_cuda or hidden_states.dtype != torch.float32:
+        return False
+    if torch.is_grad_enabled() and any(p.requires_grad for p in layer.attention.self.query.parameters()):
         return False
     if getattr(layer, "is_decoder", False) or getattr(layer, "add_cross_attention", False):
         return False
@@ -50,6 +63,8 @@ def _covered(layer, hidden_states, args, kwargs) -> bool:
 def _layer_forward(self, hidden_states, attention_mask=None, *args, **kwargs):
     if not _covered(self, hidden_states, args, kwargs):
         return self._soc_orig_forward(hidden_states, attention_mask, *args, **kwargs)       # the parent class's forward
+    global FAST_LAYER_CALLS
+    FAST_LAYER_CALLS += 1
     att, att_out, inter, out = self.attention.self, self.attention.output, self.intermediate, self.output
     B, L, E = hidden_states.shape
     nh = att.num_attention_heads

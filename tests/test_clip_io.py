@@ -193,3 +193,67 @@ def test_pinned_pool_never_hands_out_a_buffer_twice():
     a, b = pool.take(shape), pool.take(shape)
     c = pool.take(shape)                      # both ring entries (or all three) busy -> distinct third / fourth
     assert len({id(a), id(b), id(c)}) == 3
+
+
+def test_double_buffered_h2d_ordering():
+    """The streamed form of the reference's per-clip `samples.to(device)` (infer_refytb.py:206-212; SURVEY 8e: pinned,
+    double-buffered H2D).  Streams and events are recording stand-ins, so the test sees the ORDER of operations the
+    feeder would enqueue: the copy into a slot waits for the release of the work that read it last, the compute stream
+    waits for exactly the copy of the clip it is about to read, and a third un-released submit raises."""
+    log = []
+
+    class Ev:
+        n = 0
+
+        def __init__(self):
+            Ev.n += 1
+            self.id, self.on = Ev.n, None
+
+        def record(self, stream):
+            self.on = stream.name
+            log.append(("record", stream.name, self.id))
+
+    class St:
+        def __init__(self, name):
+            self.name = name
+
+        def wait_event(self, ev):
+            log.append(("wait", self.name, ev.id, ev.on))
+
+    n = 7
+    hosts = [torch.full((2, 3), float(i)) for i in range(n)]
+    f = CI.DoubleBufferedH2D((2, 3), device="cpu", depth=2, copy_stream=St("copy"), compute_stream=St("compute"),
+                             event_factory=Ev)
+    seen, copied = [], []
+    f.submit(hosts[0], on_copied=copied.append)
+    for i in range(n):
+        if i + 1 < n:
+            f.submit(hosts[i + 1], on_copied=copied.append)
+            with pytest.raises(RuntimeError):
+                f.submit(hosts[0])               # both slots hold clips that have not been released
+        clip = f.acquire()
+        seen.append(float(clip[0, 0]))           # "launch the work that reads clip"
+        assert float(clip.min()) == float(clip.max()) == i
+        with pytest.raises(RuntimeError):
+            f.acquire()                          # one clip at a time on the compute stream
+        f.release()
+    assert seen == [float(i) for i in range(n)] and f.in_flight() == 0 and len(copied) == n
+    with pytest.raises(RuntimeError):
+        f.acquire()
+    with pytest.raises(RuntimeError):
+        f.release()
+    # per clip i >= 2 the copy stream waited, before recording the copy's `ready`, for the event the compute stream
+    # recorded when it released clip i-2 (same slot); the compute stream waited for clip i's own `ready`
+    ready = [e for e in log if e[0] == "record" and e[1] == "copy"]
+    free = [e for e in log if e[0] == "record" and e[1] == "compute"]
+    cwait = [e for e in log if e[0] == "wait" and e[1] == "copy"]
+    kwait = [e for e in log if e[0] == "wait" and e[1] == "compute"]
+    assert len(ready) == n and len(free) == n and len(cwait) == n - 2 and len(kwait) == n
+    for i in range(n):
+        assert kwait[i][2] == ready[i][2] and kwait[i][3] == "copy"
+        assert log.index(ready[i]) < log.index(kwait[i])
+    for i in range(2, n):
+        assert cwait[i - 2][2] == free[i - 2][2] and cwait[i - 2][3] == "compute"
+        assert log.index(free[i - 2]) < log.index(cwait[i - 2]) < log.index(ready[i])
+    with pytest.raises(ValueError):
+        CI.DoubleBufferedH2D((2, 3), device="cpu", depth=1)

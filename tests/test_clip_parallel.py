@@ -104,6 +104,22 @@ def test_world_size_must_match_requested_gpus(monkeypatch):
         CP.init_rank("cpu", expect_world=8)
 
 
+def test_infer_gpus_defaults_to_world_size(monkeypatch):
+    """`torch.distributed.run --nproc-per-node 8 -m neurips2023_soc_amd.infer` WITHOUT --gpus (the launch line of round 1)
+    must keep working: the default is WORLD_SIZE under an outer launcher and 1 otherwise; only an explicit value is
+    checked against WORLD_SIZE."""
+    from neurips2023_soc_amd import infer
+    monkeypatch.delenv("RANK", raising=False)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    assert infer.parse_args([]).gpus == 1
+    monkeypatch.setenv("RANK", "3")
+    monkeypatch.setenv("WORLD_SIZE", "8")
+    a = infer.parse_args([])
+    assert a.gpus == 8 and not a.gpus_given
+    a = infer.parse_args(["--gpus", "4"])
+    assert a.gpus == 4 and a.gpus_given          # init_rank(expect_world=4) then raises against WORLD_SIZE=8
+
+
 def test_bench_consumes_gpus_flag_without_a_gpu():
     """No GPU here: `bench.py --gpus 2` must start its two ranks (each then refuses to run without an MI355X)
     and exit non-zero -- it can no longer silently measure one rank."""

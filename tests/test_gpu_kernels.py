@@ -168,6 +168,16 @@ def test_window_attention_golden_block(ops, golden, synthetic_sd, blk, shift):
     assert maxdiff(y, g[blk + "_out"]) < 5e-5 * max(1.0, float(np.abs(g[blk + "_out"]).max()))
 
 
+@pytest.mark.parametrize("nH,shift", [(3, (0, 0, 0)), (3, (4, 3, 3)), (4, (4, 3, 3))])
+def test_window_attention_stage0_geometry_vs_oracle(ops, nH, shift):
+    """The full stage-0 geometry of the BASELINE configs (1x8x90x160; Swin-T 3 heads = 897 pairs, Swin-B 4 heads =
+    1 196 pairs), shifted and un-shifted, against the oracle (reference video_swin_transformer.py:215-249): the planner's
+    mixed schedule for these pair counts (n_main whole pairs + pairs split over query tiles) exists nowhere else.
+    The oracle materialises the [pairs,392,392] scores (551 / 735 MB) and takes a few seconds on the host."""
+    d, scale = _win_case(ops, 1, 8, 90, 160, nH, shift, seed=900 + nH)
+    assert d < 2e-5 * max(scale, 1.0), (d, scale)
+
+
 def test_window_attention_full_config_stage0(ops):
     """BASELINE config size (stage 0: 8x90x160, 3 heads, shifted): oracle on a few windows' worth
     is too slow for the whole map, so check the size-independent property instead: rows of the
@@ -337,26 +347,31 @@ def test_text_encoder_fast_layers_match_huggingface(L, pad):
     attn = torch.ones_like(ids)
     if pad:
         ids[1, L - pad:], attn[1, L - pad:] = 1, 0
+    import copy
+    from neurips2023_soc_amd import text_fast
     with torch.no_grad():
+        calls0 = text_fast.FAST_LAYER_CALLS
         fast = enc(input_ids=ids.cuda(), attention_mask=attn.cuda())
-        fast_classes = {}
-        for m in enc.modules():                      # back to HuggingFace's own layer class for the comparison
+        # the 7-launch form really ran in all 12 layers (round 2: transformers 5.x passes encoder_hidden_states=None
+        # positionally and every layer fell back to HuggingFace's forward -- the comparison below was fallback vs fallback)
+        assert text_fast.FAST_LAYER_CALLS - calls0 == 12
+        # reference: HuggingFace's own layer class and plain F.linear, on the CPU
+        cpu = copy.deepcopy(enc).cpu()
+        for m in cpu.modules():
             if hasattr(m, "_soc_orig_forward"):
-                fast_classes[m] = type(m)
                 m.__class__ = type(m).__mro__[1]
-        try:
-            ref = enc(input_ids=ids.cuda(), attention_mask=attn.cuda())
-        finally:
-            for m, c in fast_classes.items():
-                m.__class__ = c
-        import copy
+            elif type(m) is text_fast.RoutedLinear:
+                m.__class__ = torch.nn.Linear
+        calls1 = text_fast.FAST_LAYER_CALLS
+        ref = cpu(input_ids=ids, attention_mask=attn)
+        assert text_fast.FAST_LAYER_CALLS == calls1
         twin = copy.deepcopy(enc)                    # a copy runs on ITS OWN weights (not bound to the original's)
         for p in twin.parameters():
             p.zero_()
         assert float(twin(input_ids=ids.cuda(), attention_mask=attn.cuda()).last_hidden_state.abs().max()) < 1e-3
-    keep = attn.bool().cuda()
-    assert maxdiff(fast.last_hidden_state[keep], ref.last_hidden_state[keep].cpu()) < 2e-4
-    assert maxdiff(fast.pooler_output, ref.pooler_output.cpu()) < 2e-4
+    keep = attn.bool()
+    assert maxdiff(fast.last_hidden_state.cpu()[keep], ref.last_hidden_state[keep]) < 2e-4
+    assert maxdiff(fast.pooler_output, ref.pooler_output) < 2e-4
 
 
 # ------------------------------------------------------------------ K15 decoder cross-attention block
@@ -894,6 +909,8 @@ def test_linear_act_multi_with_add(ops):
     (7, 256, 16, True, False, "none", True),          # fewer rows than one tile, single column tile
     (1000, 512, 128, False, False, "gelu", True),
     (0, 96, 96, False, False, "none", True),
+    (115200, 96, 384, True, False, "gelu", True),     # stage-0 fc1 + GELU at the BASELINE token count (7 200 row tiles)
+    (115200, 384, 96, False, True, "none", True),     # stage-0 fc2 + residual at the BASELINE token count
 ])
 def test_ws_linear_vs_torch(ops, M, K, N, ln, res, act, bias):
     """K13 against the torch ops it replaces: layer_norm -> linear -> (GELU erf | ReLU) -> + residual.  The GELU uses

@@ -203,3 +203,19 @@ def test_c_abi_library_exports_every_declared_symbol():
     assert lib.soc_hip_abi_version() == _lib.ABI_VERSION == 6
     assert lib.soc_xattn_workspace_bytes(240, 10, 1, 8, 32) == 0
     assert lib.soc_xattn_workspace_bytes(10, 1920, 1, 8, 32) == 0
+
+
+def test_msda_fused_rejects_maps_beyond_32_bit_tap_offsets():
+    """The fused MSDA entry point forms tap addresses as 32-bit byte offsets inside a frame (include/soc_hip.h):
+    value maps with S * M * 128 >= 2^31 or S >= 2^24 must come back SOC_EUNSUPPORTED -- decided from the sizes alone,
+    before any launch, so this runs without a GPU (the arguments are never dereferenced)."""
+    import ctypes as C
+    from neurips2023_soc_amd import _lib, build_ext
+    build_ext.build(verbose=False)
+    lib = _lib.load()
+    buf = (C.c_char * 64)()
+    p = C.cast(buf, C.c_void_p)
+    M, D, L, P = 8, 32, 4, 4
+    for S in (1 << 24, (1 << 31) // (M * 128)):
+        code = lib.soc_msda_fused_fwd_f32(p, None, None, p, p, p, 2, p, p, p, 1, S, M, D, L, 5, P, None)
+        assert code == _lib.SOC_EUNSUPPORTED, (S, code)
