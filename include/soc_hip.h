@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SOC_HIP_ABI_VERSION 6
+#define SOC_HIP_ABI_VERSION 7
 
 #define SOC_OK 0
 #define SOC_EINVAL (-1)       /* null pointer / non-positive dimension */
@@ -388,6 +388,37 @@ int soc_upsample_add_tokens_f32(const float* lateral, const float* bias, const f
  */
 int soc_conv3x3_tokens_f32(const float* in, long in_frame_stride, const float* w_taps, const float* bias, float* out,
                            int N, int H, int W, int Cin, int Cout, int out_nchw, int relu, void* stream);
+
+/*
+ * K20 -- the pixel-sized f32 linear layers on the bf16 matrix cores by EXACT operand splitting (f32 in, f32 out, f32
+ * accumulation): nn.Linear as called by the Video-Swin blocks (reference models/video_swin_transformer.py:144-147 qkv,
+ * :163-164 proj, :24-37 Mlp fc1 / GELU / fc2, :254-274 the LayerNorms in front and the residual adds behind), PatchMerging
+ * (:309-311), input_proj (models/soc.py:56-77), the MMF projections (models/vla.py:20-24, incl. `tgt *`) and the
+ * deformable encoder (models/deformable_transformer.py:253-263 FFN, models/ops/modules/ms_deform_attn.py:93-116):
+ *   out[M, N] = mul[M, N] * act( LN(x [+ x_add])[M, K] . w[N, K]^T + bias[N] ) + residual[M, N]
+ * Every f32 operand is split into three bf16 numbers whose sum is the operand exactly; six of the nine bf16 x bf16
+ * products (each exact in f32) are accumulated in f32, the three dropped ones are <= 2^-23 of |a b| -- f32-level error
+ * (no larger than the f32 library GEMM's against an f64 reference) at 6/16 of the f32 MFMA time.
+ *   soc_linear_split_packed_bytes / soc_linear_split_pack_f32: split w [N][K] ONCE into the kernel's weight image
+ *     (opaque; w_packed below); re-pack after the weights change.
+ *   soc_row_stats_f32: stats[M][2] = (mean, 1 / sqrt(biased variance + eps)) of the rows of x [M][K] (K % 4 == 0,
+ *     K <= 1024), as nn.LayerNorm computes them.
+ *   soc_linear_split_f32: x_add, row_stats (+ w_colsum), bias, residual, mul may be NULL; act 0 none, 1 ReLU, 2 exact
+ *     (erf) GELU; K % 8 == 0, N % 4 == 0; every pointer 16-byte aligned; out may alias residual or mul; tile_cfg 0..4 =
+ *     128x256, 256x128, 128x128, 256x96, 128x64 output tiles (speed only).  A LayerNorm in front of the layer is applied
+ *     behind it, exactly: LN(x) w^T + b = rstd (x (w diag(gamma))^T - mean colsum) + (b + w beta).  The CALLER packs
+ *     w diag(gamma), passes bias = b + w beta, w_colsum[n] = sum_k w[n][k] gamma[k] and row_stats = soc_row_stats_f32(x);
+ *     the kernel computes rstd[m] * (acc[m][n] - mean[m] * w_colsum[n]) + bias[n] in front of act / mul / residual.
+ *     out2 != NULL: two layers that read the same input (rows of w stacked): columns [0, n_split) go to out [M, n_split],
+ *     columns [n_split, N) to out2 [M, N - n_split] (n_split % 4 == 0; no residual / mul) -- the deformable encoder's
+ *     sampling_offsets | attention_weights on src + pos (models/ops/modules/ms_deform_attn.py:95-96).
+ */
+size_t soc_linear_split_packed_bytes(int N, int K);
+int soc_linear_split_pack_f32(const float* w, void* packed, int N, int K, void* stream);
+int soc_row_stats_f32(const float* x, float* stats, long M, int K, float eps, void* stream);
+int soc_linear_split_f32(const float* x, const float* x_add, const float* row_stats, const float* w_colsum,
+                         const void* w_packed, const float* bias, const float* residual, const float* mul, float* out,
+                         float* out2, int n_split, long M, int N, int K, int act, int tile_cfg, void* stream);
 
 #ifdef __cplusplus
 }

@@ -19,8 +19,9 @@ EXPORTS = ("soc_hip_abi_version", "soc_hip_error_string", "soc_msda_fwd_f32", "s
            "soc_groupnorm_tokens_f32", "soc_patch_merge_layernorm_f32", "soc_linear_act_f32",
            "soc_linear_act_multi_f32", "soc_ws_linear_f32", "soc_decoder_cross_attn_f32",
            "soc_row_mlp_f32", "soc_groupnorm_nchw_f32", "soc_upsample_add_nchw_f32",
-           "soc_upsample_add_tokens_f32", "soc_conv3x3_tokens_f32")
-ABI_VERSION = 6
+           "soc_upsample_add_tokens_f32", "soc_conv3x3_tokens_f32", "soc_linear_split_packed_bytes",
+           "soc_linear_split_pack_f32", "soc_row_stats_f32", "soc_linear_split_f32")
+ABI_VERSION = 7
 SOC_EUNSUPPORTED = -2      # include/soc_hip.h: shape outside what the kernel is built for
 
 _lib = None
@@ -111,6 +112,14 @@ def load() -> C.CDLL:
     lib.soc_linear_act_f32.argtypes = [p, p, p, p, i, i, i, i, p]
     lib.soc_linear_act_multi_f32.restype = i
     lib.soc_linear_act_multi_f32.argtypes = [p, p, i, p, p, p, p, i, i, i, p]
+    lib.soc_linear_split_packed_bytes.restype = C.c_size_t
+    lib.soc_linear_split_packed_bytes.argtypes = [i, i]
+    lib.soc_linear_split_pack_f32.restype = i
+    lib.soc_linear_split_pack_f32.argtypes = [p, p, i, i, p]
+    lib.soc_row_stats_f32.restype = i
+    lib.soc_row_stats_f32.argtypes = [p, p, C.c_long, i, f, p]
+    lib.soc_linear_split_f32.restype = i
+    lib.soc_linear_split_f32.argtypes = [p] * 10 + [i, C.c_long, i, i, i, i, p]
     if lib.soc_hip_abi_version() != ABI_VERSION:
         raise SocHipError("libsoc_hip.so ABI version mismatch; rebuild it")
     _lib = lib

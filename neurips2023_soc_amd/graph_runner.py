@@ -55,6 +55,14 @@ class ClipGraph:
         """clip [T,3,H,W] or [T,1,3,H,W] on the device; ids / attn [1,L] token ids and attention mask (ones
         when omitted); returns the static output dict (valid until the next run) -- `self.record` holds the
         packed (query, scores, selected masks) result."""
+        self.stage_inputs(clip, ids, attn)
+        return self.replay()
+
+    def stage_inputs(self, clip: torch.Tensor, ids: Optional[torch.Tensor] = None,
+                     attn: Optional[torch.Tensor] = None) -> None:
+        """Copy the inputs into the graph's static buffers (on the current stream).  After this call the caller's `clip`
+        may be overwritten by work ordered behind it -- a streaming feeder releases its device slot here, not after the
+        replay (clip_io.DoubleBufferedH2D)."""
         self.clip.copy_(clip.view(self.clip.shape), non_blocking=True)
         if ids is not None:
             self.ids.copy_(ids.view(self.ids.shape), non_blocking=True)
@@ -62,6 +70,8 @@ class ClipGraph:
                 self.attn.fill_(1)
             else:
                 self.attn.copy_(attn.view(self.attn.shape), non_blocking=True)
+
+    def replay(self) -> Dict[str, torch.Tensor]:
         self.graph.replay()
         return self.out
 
@@ -178,13 +188,12 @@ class PipelinedClipGraph:
     def run(self, clip: torch.Tensor, ids: Optional[torch.Tensor] = None, attn: Optional[torch.Tensor] = None):
         """Submit `clip`.  Returns self.record if this replay finished the clip submitted one call earlier
         (copy it out before the next call), else None."""
-        self.clip.copy_(clip.view(self.clip.shape), non_blocking=True)
-        if ids is not None:
-            self.ids.copy_(ids.view(self.ids.shape), non_blocking=True)
-            if attn is None:
-                self.attn.fill_(1)
-            else:
-                self.attn.copy_(attn.view(self.attn.shape), non_blocking=True)
+        self.stage_inputs(clip, ids, attn)
+        return self.replay()
+
+    stage_inputs = ClipGraph.stage_inputs
+
+    def replay(self):
         self.steady[self._n % 2].replay()
         self._n += 1
         return self.record if self._n >= self.DEPTH else None

@@ -795,3 +795,137 @@ def ws_linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, ln: Opti
                                    _stream())
     _lib.check(rc, "soc_ws_linear_f32")
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# K20: f32 linear layers on the bf16 matrix cores by exact operand splitting
+_SPLIT_ACT = {"none": 0, "relu": 1, "gelu": 2}
+SPLIT_TILES = {0: (128, 256), 1: (256, 128), 2: (128, 128), 3: (256, 96), 4: (128, 64)}
+_split_cache = {}         # id(weight storage) -> (version, packed image)
+
+
+def split_pack(weight: Tensor, bias: Optional[Tensor] = None, gamma: Optional[Tensor] = None,
+               beta: Optional[Tensor] = None) -> Tuple[Tensor, Optional[Tensor], Optional[Tensor]]:
+    """(K20 weight image, effective bias, column sums) of a layer, built once and re-built when a tensor involved is
+    modified in place (load_state_dict) or replaced.  With (gamma, beta) the LayerNorm in front of the layer is folded in:
+        LN(x) w^T + b = rstd (x (w diag(gamma))^T - mean colsum) + (b + w beta)
+    the image holds w * gamma (one f32 rounding per weight), the bias is b + w beta and colsum[n] = sum_k (w * gamma)[n, k]
+    of exactly the f32 values in the image (both summed in f64, rounded once)."""
+    _need_gpu(weight, bias, gamma, beta)
+    lib = _lib.load()
+    w = _f32c(weight.detach())
+    parts = [t for t in (weight, bias, gamma, beta) if t is not None]
+    key = (w.data_ptr(), tuple(w.shape), w.device.index, gamma.data_ptr() if gamma is not None else 0,
+           bias.data_ptr() if bias is not None else 0)
+    version = tuple(t._version for t in parts)
+    hit = _split_cache.get(key)
+    if hit is not None and hit[0] == version:
+        return hit[1], hit[2], hit[3]
+    N, K = w.shape
+    eff_bias = _f32c(bias.detach()) if bias is not None else None
+    colsum = None
+    if gamma is not None:
+        eb = w.double() @ beta.detach().double()
+        if bias is not None:
+            eb = eb + bias.detach().double()
+        eff_bias = eb.float().contiguous()
+        w = (w * gamma.detach()[None, :]).contiguous()
+        colsum = w.double().sum(1).float().contiguous()
+    nbytes = lib.soc_linear_split_packed_bytes(N, K)
+    packed = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    _lib.check(lib.soc_linear_split_pack_f32(w.data_ptr(), packed.data_ptr(), N, K, _stream()), "soc_linear_split_pack_f32")
+    if len(_split_cache) > 4096:
+        _split_cache.clear()
+    _split_cache[key] = (version, packed, eff_bias, colsum, parts)      # `parts` keeps the keyed tensors alive
+    return packed, eff_bias, colsum
+
+
+def row_stats(x: Tensor, eps: float) -> Tensor:
+    """[..., K] -> [rows, 2] (mean, rstd) as nn.LayerNorm computes them (K % 4 == 0, K <= 1024)."""
+    _need_gpu(x)
+    lib = _lib.load()
+    x = _f32c(x)
+    K = x.shape[-1]
+    M = x.numel() // K
+    stats = torch.empty(M, 2, dtype=torch.float32, device=x.device)
+    with _timed("row_stats", 4.0 * M * K):
+        rc = lib.soc_row_stats_f32(x.data_ptr(), stats.data_ptr(), M, K, float(eps), _stream())
+    _lib.check(rc, "soc_row_stats_f32")
+    return stats
+
+
+def split_tile_for(M: int, N: int, K: int) -> int:
+    """Tile configuration of K20 for an [M, K] x [N, K]^T layer: the widest tile that wastes no columns, unless that
+    leaves the 256 CUs with less than about two tiles each (then the 128 x 128 / 128 x 64 tiles)."""
+    def tiles(cfg):
+        bm, bn = SPLIT_TILES[cfg]
+        return -(-M // bm) * -(-N // bn)
+    if N % 96 == 0 and N % 128 != 0:
+        cfg = 3
+    elif N % 256 == 0:
+        cfg = 0
+    elif N % 128 == 0:
+        cfg = 1
+    elif N <= 64:
+        cfg = 4
+    else:
+        cfg = 0
+    if tiles(cfg) < 384 and N % 128 == 0:
+        cfg = 2
+    if tiles(cfg) < 256 and cfg == 2:
+        cfg = 4
+    return cfg
+
+
+def linear_split_supported(x: Tensor, weight: Tensor, ln: bool = False) -> bool:
+    N, K = weight.shape
+    return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.shape[-1] == K
+            and K % 8 == 0 and N % 4 == 0 and (not ln or K <= 1024))
+
+
+def linear_split(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None,
+                 ln: Optional[Tuple[Tensor, Tensor, float]] = None, residual: Optional[Tensor] = None,
+                 act: str = "none", add: Optional[Tensor] = None, mul: Optional[Tensor] = None,
+                 tile: Optional[int] = None, stats: Optional[Tensor] = None, split_at: Optional[int] = None):
+    """K20: mul * act(LN(x + add) @ weight.T + bias) + residual, every part optional; ln = (gamma, beta, eps).
+    f32 in / f32 out with f32-level error (three-way bf16 split of both operands, six exact products, f32 accumulation);
+    the LayerNorm is folded into the cached weight image / bias / column sums (split_pack) and applied in the epilogue.
+    `stats` may carry precomputed row statistics of x (row_stats).  ln and add cannot be combined (no caller does)."""
+    _need_gpu(x, weight, bias, residual, add, mul, *(ln[:2] if ln else ()))
+    lib = _lib.load()
+    x = _f32c(x)
+    N, K = weight.shape
+    M = x.numel() // K
+    packed, bias, colsum = split_pack(weight, bias, *(ln[:2] if ln is not None else (None, None)))
+    out2 = None
+    if split_at is None:
+        out = torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=x.device)
+    else:       # two stacked layers on the same input -> two contiguous outputs
+        out = torch.empty(x.shape[:-1] + (split_at,), dtype=torch.float32, device=x.device)
+        out2 = torch.empty(x.shape[:-1] + (N - split_at,), dtype=torch.float32, device=x.device)
+        if residual is not None or mul is not None:
+            raise _lib.SocHipError("linear_split: split_at cannot be combined with residual / mul")
+    for name, t in (("residual", residual), ("mul", mul)):
+        if t is not None and t.shape != out.shape:
+            raise _lib.SocHipError(f"linear_split: {name} shape {tuple(t.shape)} != output {tuple(out.shape)}")
+    if add is not None and add.shape != x.shape:
+        raise _lib.SocHipError(f"linear_split: add shape {tuple(add.shape)} != input {tuple(x.shape)}")
+    if ln is not None:
+        if add is not None:
+            raise _lib.SocHipError("linear_split: LayerNorm in front of the layer cannot be combined with `add`")
+        if stats is None:
+            stats = row_stats(x, float(ln[2]))
+    residual = _f32c(residual) if residual is not None else None
+    mul = _f32c(mul) if mul is not None else None
+    add = _f32c(add) if add is not None else None
+    b = _f32c(bias) if bias is not None else None
+    if M == 0:
+        return out if out2 is None else (out, out2)
+    cfg = split_tile_for(M, N, K) if tile is None else int(tile)
+    ptr = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
+    with _timed("linear_split", 2.0 * M * N * K):
+        rc = lib.soc_linear_split_f32(x.data_ptr(), ptr(add), ptr(stats) if ln is not None else None, ptr(colsum),
+                                      packed.data_ptr(), ptr(b), ptr(residual), ptr(mul), out.data_ptr(), ptr(out2),
+                                      int(split_at or 0), M, N, K, _SPLIT_ACT[act], cfg, _stream())
+    _lib.check(rc, "soc_linear_split_f32")
+    return out if out2 is None else (out, out2)
