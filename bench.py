@@ -47,6 +47,8 @@ def parse():
                     help="one clip per graph replay (ClipGraph) instead of the software-pipelined PipelinedClipGraph")
     ap.add_argument("--no-stream", action="store_true",
                     help="skip the second, H2D-inclusive timed pass (stream_ms_per_step)")
+    ap.add_argument("--no-f32-pass", action="store_true",
+                    help="skip the extra timed pass with every GEMM on the f32 MFMA path (SOC_MATMUL=f32 arithmetic)")
     return ap.parse_args()
 
 
@@ -233,6 +235,25 @@ def main():
             step(i, results[i])
         prof = hot_ops.profile_end()
 
+    # Third timed pass: the same loop with the pixel-sized linear layers on the f32 MFMA path (K13 / K12 / library) instead
+    # of K20's three-way bf16 split -- the round-2 arithmetic, reported beside the headline so both are on record.
+    f32_pass = None
+    if graph is not None and not a.no_f32_pass and hot_ops.split_enabled():
+        from neurips2023_soc_amd.graph_runner import ClipGraph, PipelinedClipGraph
+        hot_ops.MATMUL_MODE = "f32"
+        try:
+            g32 = (PipelinedClipGraph if pipelined else ClipGraph)(model, T, H, Wd, L, dev)
+            main_graph, graph = graph, g32
+            r32 = torch.zeros_like(results)
+            run_steps(min(a.warmup, 2), r32)
+            torch.cuda.synchronize()
+            t32 = CP.timed_sharded_run(lambda out: run_steps(a.steps, out), r32, dev)
+            f32_pass = {"seconds": t32["seconds"], "record0": r32[0].cpu()}
+            graph = main_graph
+            del g32
+        finally:
+            hot_ops.MATMUL_MODE = "split"
+
     # K1 (the roofline kernel): replay the 12 launches of ONE forward back to back between one event pair
     K1_REPS = 20
     hot_ops.record_window_attention_calls(True)
@@ -266,6 +287,15 @@ def main():
             "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "matmul": ("f32 in / f32 out / f32 accumulation everywhere; pixel-sized linear layers (soc_linear_split_f32) run "
+                       "on the bf16 matrix cores with every operand split EXACTLY into three bf16 terms (6 of 9 products, "
+                       "dropped terms <= 2^-23 |a b|): error vs f64 no larger than the f32 library GEMM's "
+                       "(tests/test_gpu_kernels.py::test_linear_split_is_f32_grade)") if hot_ops.split_enabled()
+                      else "f32 MFMA (SOC_MATMUL=f32)",
+            **({"f32_mfma_only_ms_per_step": 1e3 * f32_pass["seconds"] / a.steps,
+                "f32_mfma_only_value": world * a.steps / f32_pass["seconds"],
+                "f32_mfma_only_record0_max_abs_diff": float((f32_pass["record0"] - timed_records[0]).abs().max())}
+               if f32_pass is not None else {}),
             **({"stream_ms_per_step": 1e3 * stream["seconds"] / a.steps, "stream_value": world * a.steps / stream["seconds"],
                 "stream": f"same loop with every clip copied host->device inside the timed region: {stream['n_host']} "
                           "pinned host clips (seeds seed0 + i), three device slots, copy stream one clip ahead "

@@ -390,6 +390,14 @@ int soc_conv3x3_tokens_f32(const float* in, long in_frame_stride, const float* w
                            int N, int H, int W, int Cin, int Cout, int out_nchw, int relu, void* stream);
 
 /*
+ * K1 arithmetic switch (process-wide, full 8x7x7 windows only): 1 (default) = scores and P.V on the bf16 matrix cores with
+ * every f32 operand split exactly into three bf16 terms (six products, f32 accumulation: f32-level error, see K20 below);
+ * 0 = the f32-input MFMA form of rounds 1-2.  Same results to f32 rounding; soc_win_attn3d_f32 reads it per launch.
+ */
+void soc_win_attn3d_set_split(int on);
+int soc_win_attn3d_get_split(void);
+
+/*
  * K20 -- the pixel-sized f32 linear layers on the bf16 matrix cores by EXACT operand splitting (f32 in, f32 out, f32
  * accumulation): nn.Linear as called by the Video-Swin blocks (reference models/video_swin_transformer.py:144-147 qkv,
  * :163-164 proj, :24-37 Mlp fc1 / GELU / fc2, :254-274 the LayerNorms in front and the residual adds behind), PatchMerging

@@ -20,7 +20,8 @@ EXPORTS = ("soc_hip_abi_version", "soc_hip_error_string", "soc_msda_fwd_f32", "s
            "soc_linear_act_multi_f32", "soc_ws_linear_f32", "soc_decoder_cross_attn_f32",
            "soc_row_mlp_f32", "soc_groupnorm_nchw_f32", "soc_upsample_add_nchw_f32",
            "soc_upsample_add_tokens_f32", "soc_conv3x3_tokens_f32", "soc_linear_split_packed_bytes",
-           "soc_linear_split_pack_f32", "soc_row_stats_f32", "soc_linear_split_f32")
+           "soc_linear_split_pack_f32", "soc_row_stats_f32", "soc_linear_split_f32", "soc_win_attn3d_set_split",
+           "soc_win_attn3d_get_split")
 ABI_VERSION = 7
 SOC_EUNSUPPORTED = -2      # include/soc_hip.h: shape outside what the kernel is built for
 
@@ -112,6 +113,10 @@ def load() -> C.CDLL:
     lib.soc_linear_act_f32.argtypes = [p, p, p, p, i, i, i, i, p]
     lib.soc_linear_act_multi_f32.restype = i
     lib.soc_linear_act_multi_f32.argtypes = [p, p, i, p, p, p, p, i, i, i, p]
+    lib.soc_win_attn3d_set_split.restype = None
+    lib.soc_win_attn3d_set_split.argtypes = [i]
+    lib.soc_win_attn3d_get_split.restype = i
+    lib.soc_win_attn3d_get_split.argtypes = []
     lib.soc_linear_split_packed_bytes.restype = C.c_size_t
     lib.soc_linear_split_packed_bytes.argtypes = [i, i]
     lib.soc_linear_split_pack_f32.restype = i

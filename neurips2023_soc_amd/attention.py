@@ -31,13 +31,16 @@ class HipMultiheadAttention(nn.Module):
     def forward(self, query: torch.Tensor, key: torch.Tensor, value: torch.Tensor,
                 key_padding_mask: Optional[torch.Tensor] = None, query_add: Optional[torch.Tensor] = None,
                 key_add: Optional[torch.Tensor] = None, batch_first: bool = False,
-                attn_mask: Optional[torch.Tensor] = None, post_norm: Optional[nn.LayerNorm] = None) -> torch.Tensor:
+                attn_mask: Optional[torch.Tensor] = None, post_norm: Optional[nn.LayerNorm] = None,
+                out_mul: Optional[torch.Tensor] = None) -> torch.Tensor:
         """attention(query + query_add, key + key_add, value): the *_add terms are the positional
         embeddings the reference adds before calling nn.MultiheadAttention (with_pos_embed).
         batch_first: tensors are [B,L,E] instead of nn.MultiheadAttention's [L,B,E].
         attn_mask: additive float mask as in nn.MultiheadAttention ([Lq,Lk], [B,Lq,Lk] or [B*heads,Lq,Lk]).
         post_norm: return post_norm(query + attention(...)) -- the post-norm residual every caller on the query chain
-        applies next -- with out_proj, the add and the LayerNorm in one launch (K16) when the rows are few."""
+        applies next -- with out_proj, the add and the LayerNorm in one launch (K16) when the rows are few.
+        out_mul: return out_mul * attention(...) (reference models/vla.py:24 `tgt * tgt2`), the product fused into the
+        output projection where that runs on K20."""
         if self.training:
             raise RuntimeError("HipMultiheadAttention is inference-only (no backward kernel)")
         E = self.embed_dim
@@ -68,7 +71,8 @@ class HipMultiheadAttention(nn.Module):
             o = hot_ops.mha_core(q, k, v, self.num_heads, key_padding_mask, batch_first=batch_first,
                                  attn_mask=attn_mask)
         if post_norm is None:
-            return fused.apply(self.out_proj, o)
+            return fused.linear(o, self.out_proj.weight, self.out_proj.bias, mul=out_mul)
+        assert out_mul is None
         if o.shape == query.shape and hot_ops.row_mlp_supported(o, [self.out_proj.weight], has_ln=True):
             return hot_ops.row_mlp(o, [(self.out_proj.weight, self.out_proj.bias)], residual=query,
                                    ln=(post_norm.weight, post_norm.bias, post_norm.eps))

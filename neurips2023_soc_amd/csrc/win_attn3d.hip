@@ -863,6 +863,446 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_full_kernel(
     STAMP_RT(31);
 }
 
+// =============================================================================================
+// K1 on the bf16 matrix cores (round 3).  The f32-input MFMA above runs at the f32 vector rate (1/16 of the bf16 matrix
+// rate) and blocks the vector ALU while it runs; this form keeps f32 semantics -- every f32 operand is split EXACTLY
+// into three bf16 numbers (8 + 8 + 8 significant bits; csrc/linear_split.hip has the arithmetic), six of the nine
+// bf16 x bf16 products (each exact in f32) are accumulated in the f32 accumulators, the dropped three are <= 2^-23 |a b| --
+// at 6/16 of the matrix time and with the softmax's vector work running BESIDE the matrix cores instead of in front of
+// them.  Same algorithm and window enumeration as win_attn3d_full_kernel; what changes:
+//   * K and V of the head are split while they are staged: three planes each of [slot][32 dims] bf16 (64-B rows), 16-B
+//     chunk c of row r at chunk c ^ pi[(r >> 2) & 3], pi = (0, 3, 2, 1): the per-lane ds_read_b128 of the K operand
+//     (lane = key, 8 consecutive dims) and the ds_read_b64_tr_b16 of the V operand are both bank-conflict free, and V needs
+//     no transposed image -- the transposing read hands a lane 4 keys of one dim;
+//   * S^T = K . Q^T is ONE v_mfma_f32_16x16x32_bf16 per key tile and product (head dim 32 = one k-step), Q split per tile;
+//   * P is split in registers after the softmax; O^T = V^T . P^T takes two key tiles per MFMA (k = 32 keys: a lane's 8
+//     P values are its 4 + 4 accumulator registers of the two tiles, the V side reads the matching 4 + 4 keys);
+//   * nothing per-slot is kept in LDS (token offsets and bias codes are recomputed where needed): 160.7 KB of planes +
+//     bias column leave room for nothing else.
+// =============================================================================================
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int KROWB = 64;                          // bytes per plane row: 32 bf16
+constexpr int PLANEB = FN * KROWB;                 // 25 088 B per plane (392 slots; tile 24 reads 8 rows past the end)
+constexpr int SP_TB = 0;                           // [2536] f32 bias column
+constexpr int SP_K = 2536 * 4;                     // 3 K planes
+constexpr int SP_V = SP_K + 3 * PLANEB;            // 3 V planes
+constexpr int SP_MISC = SP_V + 3 * PLANEB;         // wflag[8], gtab[25][4]
+constexpr size_t SPLIT_LDS_BYTES = SP_MISC + 8 * 4 + FNT * 4 * 4 + 512;   // + slack: tile 24 of V plane 2 reads 512 B past the planes
+static_assert(SPLIT_LDS_BYTES <= 160 * 1024, "LDS");
+static_assert((THREADS / 64) * PWS * 4 <= 3 * PLANEB, "shared-tile scratch aliases the K planes");
+
+__device__ __forceinline__ void split8v(const float (&v)[8], bf16x8& h0, bf16x8& h1, bf16x8& h2) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const __bf16 a0 = (__bf16)v[i];
+        const float r1 = v[i] - (float)a0;
+        const __bf16 a1 = (__bf16)r1;
+        const float r2 = r1 - (float)a1;
+        h0[i] = a0; h1[i] = a1; h2[i] = (__bf16)r2;
+    }
+}
+__device__ __forceinline__ void split4v(const f32x4& v, bf16x4& h0, bf16x4& h1, bf16x4& h2) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const __bf16 a0 = (__bf16)v[i];
+        const float r1 = v[i] - (float)a0;
+        const __bf16 a1 = (__bf16)r1;
+        const float r2 = r1 - (float)a1;
+        h0[i] = a0; h1[i] = a1; h2[i] = (__bf16)r2;
+    }
+}
+__device__ __forceinline__ int swz(int row) { return (4 - ((row >> 2) & 3)) & 3; }     // pi[(row >> 2) & 3]
+
+// six products of the three-way split, smallest first
+#define MFMA6_32(acc, a, b)                                                                   \
+    do {                                                                                      \
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], acc, 0, 0, 0);              \
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], acc, 0, 0, 0);              \
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], acc, 0, 0, 0);              \
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], acc, 0, 0, 0);              \
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], acc, 0, 0, 0);              \
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], acc, 0, 0, 0);              \
+    } while (0)
+#define MFMA6_16(acc, a, b)                                                                   \
+    do {                                                                                      \
+        acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[2], b[0], acc, 0, 0, 0);            \
+        acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[1], b[1], acc, 0, 0, 0);            \
+        acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[0], b[2], acc, 0, 0, 0);            \
+        acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[1], b[0], acc, 0, 0, 0);            \
+        acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[0], b[1], acc, 0, 0, 0);            \
+        acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[0], b[0], acc, 0, 0, 0);            \
+    } while (0)
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+// 4 keys x 1 dim for this lane: rows key0 .. key0+3 of a V plane, dims 16 dt .. 16 dt + 15 over the 16 lanes of the group
+__device__ __forceinline__ bf16x4 v_tr(const unsigned vplane_addr, const int key0, const int dt, const int li) {
+    const int q = li >> 2, pp = li & 3;          // this lane supplies the address of row q, dims 4 pp .. 4 pp + 3 of the block
+    // slots 392 .. 399 of the last key tile do not exist: their P is 0, but 0 x (whatever bytes follow the plane) could be
+    // NaN -- those lanes re-read the last real row instead ("pad, don't mask": the transposing read needs every lane)
+    const int row = min(key0 + q, FN - 1);
+    const int c16 = (2 * dt + (pp >> 1)) ^ swz(row);
+    const unsigned a = vplane_addr + (unsigned)(row * KROWB + c16 * 16 + 8 * (pp & 1));
+    return __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)a));
+}
+
+template <bool SHIFTED>
+__global__ __launch_bounds__(THREADS, 2) void win_attn3d_split_kernel(
+    const float* __restrict__ qkv, const float* __restrict__ qkv_bias,
+    const float* __restrict__ table, float* __restrict__ out, const WinParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* Tb = reinterpret_cast<float*>(smem_raw + SP_TB);
+    char* Kp = smem_raw + SP_K;
+    int* wflag = reinterpret_cast<int*>(smem_raw + SP_MISC);
+    int* gtab = wflag + 8;                                      // [25][4] key-group codes: 4 * c | region << 16
+    float* Pw = reinterpret_cast<float*>(Kp);                   // shared-tile scratch, aliases the K planes (behind a barrier)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bid = blockIdx.x;
+    int qpart = 0, qsplit = 1;
+    if (bid >= p.n_main) {
+        const int rem = bid - p.n_main;
+        qsplit = p.qsplit;
+        qpart = rem % qsplit;
+        bid = p.n_main + rem / qsplit;
+    }
+    const int head = bid % p.nH; bid /= p.nH;
+    const int wx = bid % p.nww; bid /= p.nww;
+    const int wy = bid % p.nwh; bid /= p.nwh;
+    const int wz = bid % p.nwd; bid /= p.nwd;
+    const int b = bid;
+    const int C3 = 3 * p.C;
+    const int r = lane & 15, g = lane >> 4;
+
+    // slot = col*8 + dz, col = dy*7 + dx (temporal index fastest)
+    auto slot_info = [&](int i, int& reg, int& ccode) -> int {
+        const int col = i >> 3, dz = i & 7;
+        const int dy = (col * 37) >> 8, dx = col - dy * 7;     // col / 7 for col < 64
+        const int zs = wz * 8 + dz, ys = wy * 7 + dy, xs = wx * 7 + dx;  // shifted frame
+        int z = zs + p.sd; if (z >= p.Dp) z -= p.Dp;
+        int y = ys + p.sh; if (y >= p.Hp) y -= p.Hp;
+        int x = xs + p.sw; if (x >= p.Wp) x -= p.Wp;
+        reg = (region1d(zs, p.Dp, 8, p.sd) * 3 + region1d(ys, p.Hp, 7, p.sh)) * 3 + region1d(xs, p.Wp, 7, p.sw);
+        ccode = ((dy * 13 + dx) * 15 - dz + 8) * 4;
+        return (z < p.D && y < p.H && x < p.W) ? ((b * p.D + z) * p.H + y) * p.W + x : -1;
+    };
+
+    // ---- staging: K and V rows (8 dims per thread) split into three bf16 planes each, bias column, group table
+    {
+        int differs = 0, reg0, c0;
+        (void)slot_info(0, reg0, c0);
+        constexpr int ITEMS = FN * 4;                       // (slot, 8-dim chunk)
+        constexpr int PASSES = (ITEMS + THREADS - 1) / THREADS;
+        float4 kv[PASSES][2], vv[PASSES][2];
+        int ss[PASSES];
+        const int c = tid & 3;
+#pragma unroll
+        for (int it = 0; it < PASSES; ++it) {
+            const int i = (tid + THREADS * it) >> 2;
+            int s = -2, reg = 0, cc = 0;
+            if (i < FN) {
+                s = slot_info(i, reg, cc);
+                differs |= (reg != reg0);
+            }
+            ss[it] = s;
+            if (s >= 0) {
+                const float4* row = reinterpret_cast<const float4*>(qkv + (long)s * C3 + head * HD + 8 * c);
+                kv[it][0] = row[p.C / 4]; kv[it][1] = row[p.C / 4 + 1];
+                vv[it][0] = row[p.C / 2]; vv[it][1] = row[p.C / 2 + 1];
+            } else {
+                const float4* kb = reinterpret_cast<const float4*>(qkv_bias + p.C + head * HD + 8 * c);
+                const float4* vb = reinterpret_cast<const float4*>(qkv_bias + 2 * p.C + head * HD + 8 * c);
+                kv[it][0] = kb[0]; kv[it][1] = kb[1];
+                vv[it][0] = vb[0]; vv[it][1] = vb[1];
+            }
+        }
+        constexpr int TPASS = (TBL + THREADS - 1) / THREADS;
+        float tv[TPASS];
+#pragma unroll
+        for (int it = 0; it < TPASS; ++it) {
+            const int i = it * THREADS + tid;
+            const int yx = i / 15, zz = i - yx * 15;
+            tv[it] = i < TBL ? table[(long)(zz * 169 + yx) * p.nH + head] : 0.f;
+        }
+        const int wave_differs = __any(differs);
+        if (SHIFTED && lane == 0) wflag[wave] = wave_differs ? 1 : 0;
+        if (tid < FNT * 4) {                                // key-group codes: group = slots 16t + 4gg .. +3
+            const int t = tid >> 2, gg = tid & 3;
+            const int col = 2 * t + (gg >> 1);
+            const int dy = (col * 37) >> 8, dx = col - dy * 7;
+            int reg = 0;
+            if (SHIFTED) {
+                const int zs = wz * 8 + 4 * (gg & 1), ys = wy * 7 + dy, xs = wx * 7 + dx;
+                reg = (region1d(zs, p.Dp, 8, p.sd) * 3 + region1d(ys, p.Hp, 7, p.sh)) * 3 + region1d(xs, p.Wp, 7, p.sw);
+            }
+            gtab[tid] = (((dy * 13 + dx) * 15 - 4 * (gg & 1) + 8) * 4) | (reg << 16);
+        }
+#pragma unroll
+        for (int it = 0; it < PASSES; ++it) {
+            const int i = (tid + THREADS * it) >> 2;
+            if (i < FN) {
+                const float kf[8] = {kv[it][0].x, kv[it][0].y, kv[it][0].z, kv[it][0].w, kv[it][1].x, kv[it][1].y, kv[it][1].z, kv[it][1].w};
+                const float vf[8] = {vv[it][0].x, vv[it][0].y, vv[it][0].z, vv[it][0].w, vv[it][1].x, vv[it][1].y, vv[it][1].z, vv[it][1].w};
+                bf16x8 h0, h1, h2;
+                char* dst = Kp + i * KROWB + ((c ^ swz(i)) << 4);
+                split8v(kf, h0, h1, h2);
+                *reinterpret_cast<bf16x8*>(dst) = h0;
+                *reinterpret_cast<bf16x8*>(dst + PLANEB) = h1;
+                *reinterpret_cast<bf16x8*>(dst + 2 * PLANEB) = h2;
+                split8v(vf, h0, h1, h2);
+                *reinterpret_cast<bf16x8*>(dst + 3 * PLANEB) = h0;
+                *reinterpret_cast<bf16x8*>(dst + 4 * PLANEB) = h1;
+                *reinterpret_cast<bf16x8*>(dst + 5 * PLANEB) = h2;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < TPASS; ++it) {
+            const int i = it * THREADS + tid;
+            const int yx = i / 15, zz = i - yx * 15;
+            if (i < TBL) Tb[yx * 15 + 14 - zz] = tv[it] * LOG2E;
+        }
+    }
+    __syncthreads();
+    bool has_mask = false;
+    if (SHIFTED) {
+        int f = 0;
+#pragma unroll
+        for (int w8 = 0; w8 < THREADS / 64; ++w8) f |= wflag[w8];
+        has_mask = f != 0;
+    }
+
+    const unsigned tbase = (unsigned)(uintptr_t)(lds_cfloat*)Tb;
+    const unsigned kaddr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)Kp;
+    const unsigned vaddr = kaddr + 3 * PLANEB;
+    const float scale = 0.17677669529663687f * LOG2E;
+    const int C0 = ((6 * 13 + 6) * 15 + 7) * 4;
+    // K operand of key tile t, plane pl: lane (key r, dims 8g .. 8g+7)
+    const unsigned kfrag = kaddr + (unsigned)(r * KROWB + ((g ^ swz(r)) << 4));
+
+    // Q fragment of a tile: lane (query r, dims 8g .. 8g+7), scaled, split; + the query's token / bias code / region
+    auto load_q = [&](int qt, float (&qf)[8], int& qsrc, int& qcode) {
+        int reg, cc;
+        const int slot = qt * 16 + r;
+        qsrc = -2; qcode = 0;
+        if (slot < FN) {
+            qsrc = slot_info(slot, reg, cc);
+            qcode = cc | (reg << 16);
+        }
+        if (qsrc >= 0) {
+            const float4* qrow = reinterpret_cast<const float4*>(qkv + (long)qsrc * C3 + head * HD + 8 * g);
+            const float4 a = qrow[0], c = qrow[1];
+            qf[0] = a.x; qf[1] = a.y; qf[2] = a.z; qf[3] = a.w; qf[4] = c.x; qf[5] = c.y; qf[6] = c.z; qf[7] = c.w;
+        } else if (qsrc == -1) {
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) qf[kk] = qkv_bias[head * HD + 8 * g + kk];
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) qf[kk] = 0.f;
+        }
+    };
+
+    // scores of key tile kt for the query fragment qs: bias gather + 6 MFMAs (+ mask)
+    auto score_tile = [&](int kt, const bf16x8 (&qs)[3], unsigned qaddr, int qreg) -> f32x4 {
+        const int gc = gtab[kt * 4 + g];
+        lds_cfloat* bp = (lds_cfloat*)(uintptr_t)(qaddr - (unsigned)(gc & 0xFFFF));
+        f32x4 a = (f32x4){bp[0], bp[1], bp[2], bp[3]};
+        bf16x8 kf[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+            kf[pl] = *(const __attribute__((address_space(3))) bf16x8*)(uintptr_t)(kfrag + (unsigned)(kt * 16 * KROWB + pl * PLANEB));
+        MFMA6_32(a, kf, qs);
+        if (has_mask) {
+            const float pen = ((gc >> 16) != qreg) ? -100.0f * LOG2E : 0.f;
+            a += (f32x4){pen, pen, pen, pen};
+        }
+        return a;
+    };
+
+    const bool share_last = qsplit == 1;
+    const int ntile = share_last ? FNT - 1 : FNT;
+    const int stride = (THREADS / 64) * qsplit;
+    float qn[8];
+    int qsrc_n = -2, qcode_n = 0;
+    int qt = qpart + qsplit * wave;
+    if (qt < ntile) load_q(qt, qn, qsrc_n, qcode_n);
+
+    for (; qt < ntile; qt += stride) {
+        const int qsrc = qsrc_n;
+        const unsigned qaddr = tbase + (unsigned)((qcode_n & 0xFFFF) + C0);
+        const int qreg = qcode_n >> 16;
+        bf16x8 qs[3];
+        {
+            float qf[8];
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) qf[kk] = qn[kk] * scale;
+            split8v(qf, qs[0], qs[1], qs[2]);
+        }
+        f32x4 acc[FNT];
+#pragma unroll
+        for (int t = 0; t < FNT; ++t) {
+            acc[t] = score_tile(t, qs, qaddr, qreg);
+            if (t & 1) __builtin_amdgcn_sched_barrier(0);     // two key tiles per scheduling window: the LDS reads of one
+        }                                                     // overlap the MFMAs of the other, no more fragments live
+        if (qt + stride < ntile) load_q(qt + stride, qn, qsrc_n, qcode_n);   // next tile's Q, hidden behind softmax + PV
+
+        if (g >= 2) acc[FNT - 1] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};  // slots 392..399
+        float mx = vmax3(acc[0][0], acc[0][1], acc[0][2]);
+        mx = fmaxf(mx, acc[0][3]);
+#pragma unroll
+        for (int t = 1; t < FNT; ++t) {
+            mx = vmax3(mx, acc[t][0], acc[t][1]);
+            mx = vmax3(mx, acc[t][2], acc[t][3]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        // softmax is shift-invariant; the subtraction is only needed when 2^score could leave the f32 range
+        if (!__all(fabsf(mx) < 96.f)) {
+#pragma unroll
+            for (int t = 0; t < FNT; ++t) acc[t] -= (f32x4){mx, mx, mx, mx};
+        }
+        float sum = 0.f;
+        f32x4 o0 = (f32x4){0.f, 0.f, 0.f, 0.f}, o1 = o0;
+        // exp, row sums, split of P and O^T = V^T . P^T, two key tiles (32 keys) per MFMA k-step
+#pragma unroll
+        for (int t = 0; t < FNT - 1; t += 2) {
+            float pv[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                pv[i] = __builtin_amdgcn_exp2f(acc[t][i]);
+                pv[4 + i] = __builtin_amdgcn_exp2f(acc[t + 1][i]);
+            }
+            sum += ((pv[0] + pv[1]) + (pv[2] + pv[3])) + ((pv[4] + pv[5]) + (pv[6] + pv[7]));
+            bf16x8 ps[3];
+            split8v(pv, ps[0], ps[1], ps[2]);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                bf16x8 vf[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    const bf16x4 lo = v_tr(vaddr + pl * PLANEB, 16 * t + 4 * g, dt, r);
+                    const bf16x4 hi = v_tr(vaddr + pl * PLANEB, 16 * (t + 1) + 4 * g, dt, r);
+                    vf[pl] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                }
+                if (dt == 0) MFMA6_32(o0, vf, ps); else MFMA6_32(o1, vf, ps);
+            }
+            __builtin_amdgcn_sched_barrier(0);                // one key-tile pair per scheduling window
+        }
+        {   // the 25th key tile alone: k = 16
+            constexpr int t = FNT - 1;
+            f32x4 pe;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pe[i] = __builtin_amdgcn_exp2f(acc[t][i]);
+            sum += (pe[0] + pe[1]) + (pe[2] + pe[3]);
+            bf16x4 ps[3];
+            split4v(pe, ps[0], ps[1], ps[2]);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                bf16x4 vf[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) vf[pl] = v_tr(vaddr + pl * PLANEB, 16 * t + 4 * g, dt, r);
+                if (dt == 0) MFMA6_16(o0, vf, ps); else MFMA6_16(o1, vf, ps);
+            }
+        }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        if (qsrc >= 0) {
+            const float inv = 1.f / sum;
+            float* orow = out + (long)qsrc * p.C + head * HD + 4 * g;
+            *reinterpret_cast<float4*>(orow) = make_float4(o0[0] * inv, o0[1] * inv, o0[2] * inv, o0[3] * inv);
+            *reinterpret_cast<float4*>(orow + 16) = make_float4(o1[0] * inv, o1[1] * inv, o1[2] * inv, o1[3] * inv);
+        }
+    }
+
+    if (share_last) {
+        // the 25th query tile (8 real queries) is shared: wave w takes key tiles w, w + 8, ...; partial (O, max, sum) are
+        // merged through LDS (the scratch aliases the K planes: every wave must be done with them first)
+        constexpr int QT = FNT - 1;
+        float qf[8];
+        int qsrc, qcode;
+        load_q(QT, qf, qsrc, qcode);
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) qf[kk] *= scale;
+        bf16x8 qs[3];
+        split8v(qf, qs[0], qs[1], qs[2]);
+        const unsigned qaddr = tbase + (unsigned)((qcode & 0xFFFF) + C0);
+        const int qreg = qcode >> 16;
+        constexpr int NJ = (FNT + THREADS / 64 - 1) / (THREADS / 64);
+        f32x4 a4[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int kt = wave + (THREADS / 64) * j;          // wave-uniform
+            a4[j] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            if (kt < FNT) {
+                f32x4 a = score_tile(kt, qs, qaddr, qreg);
+                if (kt == FNT - 1 && g >= 2) a = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                a4[j] = a;
+            }
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) mx = fmaxf(fmaxf(mx, fmaxf(a4[j][0], a4[j][1])), fmaxf(a4[j][2], a4[j][3]));
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+        f32x4 o0 = (f32x4){0.f, 0.f, 0.f, 0.f}, o1 = o0;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int kt = wave + (THREADS / 64) * j;
+            if (kt < FNT) {
+                f32x4 pe;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) pe[i] = __builtin_amdgcn_exp2f(a4[j][i] - mx);
+                sum += (pe[0] + pe[1]) + (pe[2] + pe[3]);
+                bf16x4 ps[3];
+                split4v(pe, ps[0], ps[1], ps[2]);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    bf16x4 vf[3];
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) vf[pl] = v_tr(vaddr + pl * PLANEB, 16 * kt + 4 * g, dt, r);
+                    if (dt == 0) MFMA6_16(o0, vf, ps); else MFMA6_16(o1, vf, ps);
+                }
+            }
+        }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        __syncthreads();                                   // every wave has finished reading the K planes
+        float* pw = Pw + wave * PWS;
+        *reinterpret_cast<float4*>(pw + r * PRS + 4 * g) = make_float4(o0[0], o0[1], o0[2], o0[3]);
+        *reinterpret_cast<float4*>(pw + r * PRS + 16 + 4 * g) = make_float4(o1[0], o1[1], o1[2], o1[3]);
+        if (g == 0) {
+            pw[16 * PRS + r] = mx;
+            pw[16 * PRS + 16 + r] = sum;
+        }
+        __syncthreads();
+        const int q = tid >> 5, d = tid & 31;
+        int osrc = -1;
+        if (q < FN - QT * 16) {
+            int reg, cc;
+            osrc = slot_info(QT * 16 + q, reg, cc);
+        }
+        if (osrc >= 0) {
+            float M = -INFINITY;
+#pragma unroll
+            for (int w8 = 0; w8 < THREADS / 64; ++w8) M = fmaxf(M, Pw[w8 * PWS + 16 * PRS + q]);
+            float num = 0.f, den = 0.f;
+#pragma unroll
+            for (int w8 = 0; w8 < THREADS / 64; ++w8) {
+                const float f = __builtin_amdgcn_exp2f(Pw[w8 * PWS + 16 * PRS + q] - M);
+                num += f * Pw[w8 * PWS + q * PRS + d];
+                den += f * Pw[w8 * PWS + 16 * PRS + 16 + q];
+            }
+            out[(long)osrc * p.C + head * HD + d] = num / den;
+        }
+    }
+}
+
 int launch_full(const float* qkv, const float* qkv_bias, const float* table, float* out,
                 const WinParams& p, long blocks, hipStream_t st) {
     const size_t lds = FULL_LDS_BYTES;
@@ -882,6 +1322,29 @@ int launch_full(const float* qkv, const float* qkv_bias, const float* table, flo
                            qkv_bias, table, out, p);
     else
         hipLaunchKernelGGL((win_attn3d_full_kernel<false>), dim3((unsigned)blocks), dim3(THREADS), lds, st, qkv,
+                           qkv_bias, table, out, p);
+    return soc_check_launch();
+}
+
+int launch_split(const float* qkv, const float* qkv_bias, const float* table, float* out,
+                 const WinParams& p, long blocks, hipStream_t st) {
+    const size_t lds = SPLIT_LDS_BYTES;
+    static std::atomic<bool> attr_set[SOC_MAX_DEVICES];
+    const int dev = soc_current_device();
+    if (dev < 0) return SOC_ELAUNCH;
+    if (!attr_set[dev].load(std::memory_order_acquire)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(win_attn3d_split_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(win_attn3d_split_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return SOC_ELAUNCH;
+        attr_set[dev].store(true, std::memory_order_release);
+    }
+    if (p.shifted)
+        hipLaunchKernelGGL((win_attn3d_split_kernel<true>), dim3((unsigned)blocks), dim3(THREADS), lds, st, qkv,
+                           qkv_bias, table, out, p);
+    else
+        hipLaunchKernelGGL((win_attn3d_split_kernel<false>), dim3((unsigned)blocks), dim3(THREADS), lds, st, qkv,
                            qkv_bias, table, out, p);
     return soc_check_launch();
 }
@@ -940,8 +1403,14 @@ int num_cus() {
 // ---------------------------------------------------------------------------------------------
 struct Plan { int n_main, qsplit; };
 
-double simulate_tail(long pairs, int NT, int cus, int n_main, int q, bool shared_last, std::vector<double>& heap) {
-    constexpr double SIGMA = 0.86, SHARE = 0.27;
+struct CostModel { double sigma, share; };
+constexpr CostModel COST_F32{0.86, 0.27};
+// split kernel: a tile-slot is ~2.6x shorter, staging (global-load latency + the operand split) is not
+constexpr CostModel COST_SPLIT{2.3, 0.6};
+
+double simulate_tail(long pairs, int NT, int cus, int n_main, int q, bool shared_last, std::vector<double>& heap,
+                     const CostModel& cm) {
+    const double SIGMA = cm.sigma, SHARE = cm.share;
     const double full = SIGMA + (shared_last ? NT / 4.0 + SHARE : (double)((NT + 3) / 4));
     const long rounds = n_main / cus, extra = n_main % cus;
     heap.assign(cus, rounds * full);
@@ -965,10 +1434,11 @@ double simulate_tail(long pairs, int NT, int cus, int n_main, int q, bool shared
     return makespan + 1e-4 * (double)(n_main + (pairs - n_main) * q);
 }
 
-Plan plan_schedule(long pairs, int NT, int cus, bool shared_last) {
+Plan plan_schedule(long pairs, int NT, int cus, bool shared_last, bool split) {
     static std::mutex mu;
-    static std::map<std::tuple<long, int, int, bool>, Plan> cache;     // one entry per launch geometry
-    const auto key = std::make_tuple(pairs, NT, cus, shared_last);
+    static std::map<std::tuple<long, int, int, bool, bool>, Plan> cache;     // one entry per launch geometry
+    const auto key = std::make_tuple(pairs, NT, cus, shared_last, split);
+    const CostModel& cm = split ? COST_SPLIT : COST_F32;
     {
         std::lock_guard<std::mutex> lk(mu);
         auto it = cache.find(key);
@@ -976,13 +1446,13 @@ Plan plan_schedule(long pairs, int NT, int cus, bool shared_last) {
     }
     std::vector<double> heap;
     Plan best{(int)pairs, 1};
-    double best_t = simulate_tail(pairs, NT, cus, (int)pairs, 1, shared_last, heap);
+    double best_t = simulate_tail(pairs, NT, cus, (int)pairs, 1, shared_last, heap, cm);
     const int max_q = NT < 8 ? NT : 8;
     // only the last two rounds' worth of pairs are candidates for splitting: earlier rounds are full anyway
     const long lo = pairs > 2L * cus ? (pairs - 2L * cus) / 8 * 8 : 0;
     for (int q = 2; q <= max_q; ++q)
         for (long nm = lo; nm < pairs; nm += 8) {
-            const double t = simulate_tail(pairs, NT, cus, (int)nm, q, shared_last, heap);
+            const double t = simulate_tail(pairs, NT, cus, (int)nm, q, shared_last, heap, cm);
             if (t < best_t - 1e-9) { best_t = t; best = Plan{(int)nm, q}; }
         }
     std::lock_guard<std::mutex> lk(mu);
@@ -994,7 +1464,13 @@ Plan plan_schedule(long pairs, int NT, int cus, bool shared_last) {
 int g_force_n_main = 0, g_force_qsplit = 0;
 #endif
 
+// full 8x7x7 windows: 1 = the bf16 matrix-core form (exact three-way operand split), 0 = the f32 MFMA form
+std::atomic<int> g_k1_split{1};
+
 }  // namespace
+
+extern "C" void soc_win_attn3d_set_split(int on) { g_k1_split.store(on ? 1 : 0, std::memory_order_relaxed); }
+extern "C" int soc_win_attn3d_get_split(void) { return g_k1_split.load(std::memory_order_relaxed); }
 
 #ifdef SOC_K1_TUNE
 extern "C" void soc_debug_force_k1_plan(int n_main, int qsplit) { g_force_n_main = n_main; g_force_qsplit = qsplit; }
@@ -1029,8 +1505,9 @@ extern "C" int soc_win_attn3d_f32(const float* qkv, const float* qkv_bias, const
     if ((long)B * D * H * W * 3 * C >= (1L << 31)) return SOC_EUNSUPPORTED;  // int token offsets
     const long pairs = (long)B * p.nwd * p.nwh * p.nww * n_heads;
     const bool full_window = win_d == 8 && win_h == 7 && win_w == 7 && tab_d == 8 && tab_h == 7 && tab_w == 7;
+    const bool split = full_window && g_k1_split.load(std::memory_order_relaxed) != 0;
     {
-        const Plan pl = plan_schedule(pairs, p.NT, num_cus(), full_window);
+        const Plan pl = plan_schedule(pairs, p.NT, num_cus(), full_window, split);
         p.n_main = pl.n_main;
         p.qsplit = pl.qsplit;
     }
@@ -1045,6 +1522,8 @@ extern "C" int soc_win_attn3d_f32(const float* qkv, const float* qkv_bias, const
     hipStream_t st = (hipStream_t)stream;
     // key/query tiles are a compile-time constant (fully unrolled MFMA schedule); a window with
     // fewer tokens runs on the next larger instantiation with the surplus keys masked out.
+    if (split)
+        return launch_split(qkv, qkv_bias, bias_table, out, p, blocks, st);
     if (full_window)
         return launch_full(qkv, qkv_bias, bias_table, out, p, blocks, st);
     if (p.NT <= 7) return launch_nt<7, 0>(qkv, qkv_bias, bias_table, out, p, blocks, st);

@@ -23,14 +23,34 @@ def is_small(x: torch.Tensor) -> bool:
             and x.numel() // K <= hot_ops.SMALL_LINEAR_MAX_ROWS)
 
 
+def _split_ok(x: torch.Tensor, weight: torch.Tensor, fused_passes: int, site: str = "plain") -> bool:
+    K = x.shape[-1]
+    return (x.is_cuda and x.dtype == torch.float32 and hot_ops.linear_split_supported(x, weight)
+            and hot_ops.split_wins(x.numel() // K, weight.shape[0], K, fused_passes, site))
+
+
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
-           add: Optional[torch.Tensor] = None, relu: bool = False) -> torch.Tensor:
-    """act((x [+ add]) @ weight.T + bias); `add` broadcasts like `x + add`."""
+           add: Optional[torch.Tensor] = None, relu: bool = False, mul: Optional[torch.Tensor] = None,
+           residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """mul * act((x [+ add]) @ weight.T + bias) + residual; `add` broadcasts like `x + add`."""
     K = x.shape[-1]
     if is_small(x):
         if add is not None and add.shape != x.shape:
             add = add.expand_as(x)
-        return hot_ops.linear_small(x, weight, bias, add, relu)
+        y = hot_ops.linear_small(x, weight, bias, add, relu)
+        if mul is not None:
+            y = y * mul
+        return y if residual is None else y + residual
+    n_fused = int(add is not None) + int(relu) + int(mul is not None) + int(residual is not None)
+    site = "relu" if relu else ("mul" if mul is not None else ("res" if residual is not None else ("add" if add is not None else "plain")))
+    if _split_ok(x, weight, n_fused, site) and (add is None or add.shape == x.shape):
+        # K20: the positional add in front and ReLU / mul / residual behind are part of the launch
+        return hot_ops.linear_split(x, weight, bias, None, residual, "relu" if relu else "none", add, mul)
+    if mul is not None or residual is not None:
+        y = linear(x, weight, bias, add, relu)
+        if mul is not None:
+            y = y * mul
+        return y if residual is None else y + residual
     if add is not None:
         x = x + add
     if relu and bias is not None:
@@ -48,6 +68,12 @@ def linear_multi(x: torch.Tensor, layers, add: Optional[torch.Tensor] = None):
         return hot_ops.linear_small_multi(x, layers, add)
     K = x.shape[-1]
     if (x.is_cuda and x.dtype == torch.float32 and len(layers) == 2 and add is not None and add.shape == x.shape
+            and all(u for _, _, u in layers) and all(b is not None for _, b, _ in layers)
+            and _split_ok(x, layers[0][0], 2, "multi") and layers[0][0].shape[0] % 4 == 0 and layers[1][0].shape[0] % 4 == 0):
+        # K20 with two outputs: both layers' rows stacked into one weight image (cached), x + pos in the loader
+        w, b = _stacked(layers[0][0], layers[0][1], layers[1][0], layers[1][1])
+        return list(hot_ops.linear_split(x, w, b, add=add, split_at=layers[0][0].shape[0]))
+    if (x.is_cuda and x.dtype == torch.float32 and len(layers) == 2 and add is not None and add.shape == x.shape
             and all(u for _, _, u in layers) and K % 16 == 0 and K <= 256
             and all(w.shape[0] % 4 == 0 for w, _, _ in layers)):
         # two pixel-sized layers on x + pos (the deformable encoder's sampling offsets and attention weights):
@@ -55,6 +81,23 @@ def linear_multi(x: torch.Tensor, layers, add: Optional[torch.Tensor] = None):
         return hot_ops.linear_act_multi(x, [(w, b) for w, b, _ in layers], add)
     xa = x + add if (add is not None and any(u for _, _, u in layers)) else x
     return [F.linear(xa if u else x, w, b) for w, b, u in layers]
+
+
+_stack_cache = {}
+
+
+def _stacked(w0, b0, w1, b1):
+    """cat of two layers' (weight, bias), cached until one of them changes (K20 packs the stacked matrix once)."""
+    key = (w0.data_ptr(), w1.data_ptr(), b0.data_ptr(), b1.data_ptr())
+    ver = (w0._version, w1._version, b0._version, b1._version)
+    hit = _stack_cache.get(key)
+    if hit is None or hit[0] != ver:
+        if len(_stack_cache) > 256:
+            _stack_cache.clear()
+        hit = (ver, torch.cat([w0.detach(), w1.detach()], 0).contiguous(),
+               torch.cat([b0.detach(), b1.detach()], 0).contiguous(), (w0, w1, b0, b1))
+        _stack_cache[key] = hit
+    return hit[1], hit[2]
 
 
 def linear_relu(x: torch.Tensor, lin: nn.Linear) -> torch.Tensor:
@@ -70,6 +113,8 @@ def linear_gelu(x: torch.Tensor, lin: nn.Linear) -> torch.Tensor:
     faster than K12 by more than the separate GELU pass costs (tools/gemm_probe.py) and is kept."""
     K = x.shape[-1]
     rows = x.numel() // K
+    if _split_ok(x, lin.weight, 1, "gelu"):
+        return hot_ops.linear_split(x, lin.weight, lin.bias, act="gelu")      # K20: GELU on the accumulators
     if (x.is_cuda and x.dtype == torch.float32 and rows >= 16384 and K <= 256 and K % 16 == 0
             and lin.out_features % 4 == 0):
         return hot_ops.linear_act(x, lin.weight, lin.bias, "gelu")

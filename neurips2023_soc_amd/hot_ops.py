@@ -411,6 +411,7 @@ def window_attention3d(qkv: Tensor, qkv_bias: Tensor, bias_table: Tensor, n_head
     # algorithmic FLOPs: QK^T + PV = 4 * N^2 * head_dim per (window, head)
     n_win = B * -(-D // win[0]) * -(-H // win[1]) * -(-W // win[2])
     n_tok = win[0] * win[1] * win[2]
+    lib.soc_win_attn3d_set_split(int(k1_split_enabled()))
     with _timed("win_attn3d", 4.0 * n_tok * n_tok * (C // n_heads) * n_win * n_heads):
         code = lib.soc_win_attn3d_f32(qkv.data_ptr(), qkv_bias.data_ptr(), bias_table.data_ptr(),
                                       out.data_ptr(), B, D, H, W, C, n_heads, *win, *sh, *window, _stream())
@@ -799,6 +800,42 @@ def ws_linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, ln: Opti
 
 # ---------------------------------------------------------------------------------------------
 # K20: f32 linear layers on the bf16 matrix cores by exact operand splitting
+import os as _os
+
+# "split" (default): the pixel-sized linear layers listed in split_wins() run on K20; "f32": every GEMM stays on the f32
+# MFMA path (K13 / K12 / library), i.e. the round-2 arithmetic.  bench.py reports both.
+MATMUL_MODE = _os.environ.get("SOC_MATMUL", "split")
+
+
+def split_enabled() -> bool:
+    return MATMUL_MODE == "split"
+
+
+def k1_split_enabled() -> bool:
+    """K1 (full 8x7x7 windows) on the bf16 matrix cores with the exact three-way split; SOC_SPLIT_OFF=k1 or
+    SOC_MATMUL=f32 keep the f32-input MFMA form."""
+    return MATMUL_MODE == "split" and "k1" not in _os.environ.get("SOC_SPLIT_OFF", "").split(",")
+
+
+_SPLIT_OFF = set(filter(None, _os.environ.get("SOC_SPLIT_OFF", "").split(",")))   # debugging: sites forced back to f32
+
+
+def split_wins(rows: int, N: int, K: int, fused_passes: int = 0, site: str = "plain") -> bool:
+    """Does K20 beat the f32 path for a [rows, K] x [N, K]^T layer?  From tools/split_probe.py on MI355X (round 3): K20
+    runs at 100-125 TFLOP/s f32-equivalent once the grid fills the chip and K is short, about what the tuned f32 library
+    GEMM reaches, so it wins where it also removes separate passes (`fused_passes`: LayerNorm, GELU, residual / mul /
+    positional adds), and loses on long-K layers with few row tiles (K >= 768 with < 30 000 rows)."""
+    if not split_enabled() or K % 8 or N % 4 or rows < 1024 or K > 768 or site in _SPLIT_OFF:
+        return False
+    if rows * N < 5_500_000:                    # too few tiles to fill 256 CUs (stage-2/3 proj, stage-3 qkv, coarse levels)
+        return False
+    if K > 512:                                 # K = 768: only the wide, GELU-fused fc1 of stage 3 (1920 x 768 -> 3072)
+        return fused_passes >= 1 and N >= 1024
+    if fused_passes == 0 and rows < 16384:      # bare GEMM on a short token map: a tie at best
+        return False
+    return True
+
+
 _SPLIT_ACT = {"none": 0, "relu": 1, "gelu": 2}
 SPLIT_TILES = {0: (128, 256), 1: (256, 128), 2: (128, 128), 3: (256, 96), 4: (128, 64)}
 _split_cache = {}         # id(weight storage) -> (version, packed image)

@@ -105,6 +105,19 @@ class BasicLayer(nn.Module):
         with the LayerNorm that consumes its result (K5): x += attn -> norm2, x += mlp -> next block's norm1.  Same
         values as block-by-block."""
         blocks = self.blocks
+        if self._split_flow(x):
+            # K20 (bf16 matrix cores, exact three-way split): LayerNorm folded into the layer, GELU / residual in its
+            # epilogue -- norm1 + qkv | K1 | proj + residual | norm2 + fc1 + GELU | fc2 + residual
+            for blk in blocks:
+                a, m = blk.attn, blk.mlp
+                qkv = hot_ops.linear_split(x, a.qkv.weight, a.qkv.bias, ln=(blk.norm1.weight, blk.norm1.bias, blk.norm1.eps))
+                o = hot_ops.window_attention3d(qkv, a.qkv.bias, a.relative_position_bias_table, a.num_heads,
+                                               a.window_size, blk.shift_size)
+                x = hot_ops.linear_split(o, a.proj.weight, a.proj.bias, residual=x)
+                h = hot_ops.linear_split(x, m.fc1.weight, m.fc1.bias, ln=(blk.norm2.weight, blk.norm2.bias, blk.norm2.eps),
+                                         act="gelu")
+                x = fused.linear(h, m.fc2.weight, m.fc2.bias, residual=x)      # K20 or library + add (split_wins)
+            return x
         if self._weight_stationary(x):
             for blk in blocks:
                 a = blk.attn
@@ -130,6 +143,16 @@ class BasicLayer(nn.Module):
             else:
                 x = x + m
         return x
+
+    def _split_flow(self, x: torch.Tensor) -> bool:
+        """Tall stages wider than K13's sweet spot (C >= 192: stage 1 of Swin-T / -S, stages 1 of Swin-B): every layer on
+        K20 (tools/split_probe.py: 66 / 29 / 80 us against 75 / 36 / 99-108 us for K13 at Swin-T stage 1)."""
+        blk = self.blocks[0]
+        C = x.shape[-1]
+        rows = x.numel() // C
+        return (x.is_cuda and x.dtype == torch.float32 and C >= 192 and rows >= 16384
+                and hot_ops.split_wins(rows, 3 * C, C, 1, "swin") and hot_ops.split_wins(rows, C, C, 1, "swin")
+                and hot_ops.linear_split_supported(x, blk.attn.qkv.weight, True))
 
     def _weight_stationary(self, x: torch.Tensor) -> bool:
         """K13 pays where the token map is tall and the weights of a layer fit a CU's LDS in a few column ranges."""

@@ -15,5 +15,6 @@ class MMF(nn.Module):
 
     def forward(self, tgt: Tensor, memory: Tensor, memory_key_padding_mask: Optional[Tensor] = None,
                 pos: Optional[Tensor] = None, query_pos: Optional[Tensor] = None) -> Tensor:
-        return tgt * self.multihead_attn(tgt, memory, memory, memory_key_padding_mask, query_add=query_pos,
-                                         key_add=pos)
+        # `tgt *` is applied in the epilogue of the output projection where that is a K20 launch (pixel-sized tgt)
+        return self.multihead_attn(tgt, memory, memory, memory_key_padding_mask, query_add=query_pos, key_add=pos,
+                                   out_mul=tgt)
