@@ -80,16 +80,29 @@ extern "C" void soc_debug_set_buffer_k20(void* ptr) { g_dbg20 = (unsigned long l
 
 // exact (erf) GELU with erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, ~1 ulp of the 1 + erf it is added to),
 // branch-free (libm's erff is piecewise: 16 divergent branches per tile row group) -- the form K13 uses
-__device__ __forceinline__ float gelu_erf(float x) {
-    const float z = fabsf(x) * 0.70710678118654752f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-    float p = fmaf(1.061405429f, t, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    const float e = __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);
-    const float erf_abs = fmaf(-p * t, e, 1.0f);          // erf(|x| / sqrt 2)
-    const float half = 0.5f * x;
+// The constants live in vector registers (GeluConsts, filled through an opaque v_mov): the compiler would otherwise feed
+// them to v_pk_fma_f32 from SGPR pairs, the operand form that is unsafe beside LDS-DMA + MFMA waves (see the kernel).
+struct GeluConsts { float rs2, a0, one, c5, c4, c3, c2, c1, nlog2e, half; };
+__device__ __forceinline__ float in_vgpr(float c) {
+    float r;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(c));
+    return r;
+}
+__device__ __forceinline__ GeluConsts gelu_consts() {
+    return {in_vgpr(0.70710678118654752f), in_vgpr(0.3275911f), in_vgpr(1.0f), in_vgpr(1.061405429f), in_vgpr(-1.453152027f),
+            in_vgpr(1.421413741f), in_vgpr(-0.284496736f), in_vgpr(0.254829592f), in_vgpr(-1.4426950408889634f),
+            in_vgpr(0.5f)};
+}
+__device__ __forceinline__ float gelu_erf(float x, const GeluConsts& k) {
+    const float z = fabsf(x) * k.rs2;
+    const float t = __builtin_amdgcn_rcpf(fmaf(k.a0, z, k.one));
+    float p = fmaf(k.c5, t, k.c4);
+    p = fmaf(p, t, k.c3);
+    p = fmaf(p, t, k.c2);
+    p = fmaf(p, t, k.c1);
+    const float e = __builtin_amdgcn_exp2f(z * z * k.nlog2e);
+    const float erf_abs = fmaf(-p * t, e, k.one);         // erf(|x| / sqrt 2)
+    const float half = k.half * x;
     return fmaf(half, copysignf(erf_abs, x), half);        // 0.5 x (1 + erf(x / sqrt 2))
 }
 
@@ -124,10 +137,20 @@ __global__ __launch_bounds__(THREADS, 2) void linear_split_kernel(const SplitPar
     constexpr int BUF_BYTES = 3 * (BM + BN) * ROWB;
     static_assert(8 * SCR_BYTES <= BUF_BYTES, "epilogue scratch lives in a tile buffer");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];      // [buf 0][buf 1]
+#ifndef SOC_K20_SHARE_CU
+    // The kernel owns its CUs.  Measured on MI355X (tools/experiments/pk_mfma_probe.hip): while a wave that issues
+    // LDS-DMA loads next to bf16 MFMAs is resident, v_pk_*_f32 instructions with an SGPR source that OTHER waves of the
+    // same SIMD execute return wrong low halves in lanes 48..63 -- other kernels included (the dynamic mask head beside
+    // this kernel in the pipelined replay: 20-30 % of its launches).  Claiming all 256 architectural VGPRs makes the two
+    // waves per SIMD of one workgroup fill the 512-entry register file, so nothing else can be resident beside them;
+    // this kernel's own VALU code keeps packed f32 arithmetic away from SGPR operands (checked in the build's ISA test).
+    asm volatile("v_mov_b32 v255, 0" ::: "v255");
+#endif
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
+    const GeluConsts gk = gelu_consts();
 #ifdef SOC_K20_STAMPS
     unsigned long long phase_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long last_ = __builtin_amdgcn_s_memtime();
@@ -219,10 +242,12 @@ __global__ __launch_bounds__(THREADS, 2) void linear_split_kernel(const SplitPar
             *reinterpret_cast<u32x4*>(dst + BM * ROWB) = p1;
             *reinterpret_cast<u32x4*>(dst + 2 * BM * ROWB) = p2;
         }
-#ifdef SOC_K20_DBG_NOP
-        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
-#endif
-#ifdef SOC_K20_DBG_WAIT
+#ifndef SOC_K20_NO_COMMIT_WAIT
+        // The three 16-B LDS stores of an item must have left the register file before anything reuses their data / address
+        // registers.  Observed on MI355X / ROCm 7.2 (tools/experiments/README.md, "K20: rows of a tile that went stale"):
+        // inside the pipelined replay, with other kernels' waves sharing the CU, a launch in ~1e-4 came back with the A rows
+        // of lanes 48-63 of one wave (4 token rows) not written for one K-step -- the lanes an LDS store instruction
+        // transfers last.  Waiting for the stores here costs ~2 % and has not failed since.
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
     };
@@ -324,8 +349,8 @@ __global__ __launch_bounds__(THREADS, 2) void linear_split_kernel(const SplitPar
                 } else if (p.act == 2) {
 #pragma unroll
                     for (int it = 0; it < 4; ++it) {
-                        v[it].x = gelu_erf(v[it].x); v[it].y = gelu_erf(v[it].y);
-                        v[it].z = gelu_erf(v[it].z); v[it].w = gelu_erf(v[it].w);
+                        v[it].x = gelu_erf(v[it].x, gk); v[it].y = gelu_erf(v[it].y, gk);
+                        v[it].z = gelu_erf(v[it].z, gk); v[it].w = gelu_erf(v[it].w, gk);
                     }
                 }
                 if (p.mul) {
@@ -505,6 +530,9 @@ int launch_cfg(const SplitParams& p0, hipStream_t st) {
         attr_set[dev] = true;
     }
     long blocks = num_cus();
+#ifdef SOC_K20_DBG_BLOCKS_PER_CU
+    blocks *= SOC_K20_DBG_BLOCKS_PER_CU;
+#endif
     if (blocks > p.total_tiles) blocks = p.total_tiles;
     hipLaunchKernelGGL((linear_split_kernel<MT, NT, WM, WN>), dim3((unsigned)blocks), dim3(THREADS), lds, st, p);
     return soc_check_launch();

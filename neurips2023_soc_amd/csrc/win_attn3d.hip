@@ -939,15 +939,12 @@ __device__ __forceinline__ int swz(int row) { return (4 - ((row >> 2) & 3)) & 3;
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
-// 4 keys x 1 dim for this lane: rows key0 .. key0+3 of a V plane, dims 16 dt .. 16 dt + 15 over the 16 lanes of the group
-__device__ __forceinline__ bf16x4 v_tr(const unsigned vplane_addr, const int key0, const int dt, const int li) {
-    const int q = li >> 2, pp = li & 3;          // this lane supplies the address of row q, dims 4 pp .. 4 pp + 3 of the block
-    // slots 392 .. 399 of the last key tile do not exist: their P is 0, but 0 x (whatever bytes follow the plane) could be
-    // NaN -- those lanes re-read the last real row instead ("pad, don't mask": the transposing read needs every lane)
-    const int row = min(key0 + q, FN - 1);
-    const int c16 = (2 * dt + (pp >> 1)) ^ swz(row);
-    const unsigned a = vplane_addr + (unsigned)(row * KROWB + c16 * 16 + 8 * (pp & 1));
-    return __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)a));
+// The transposing read: a group of 16 lanes (one k-chunk g of the MFMA) reads a block of 4 keys x 16 dims of a V plane; lane
+// li = 4 q + pp of the group supplies the address of key row q, dims 4 pp .. 4 pp + 3, and receives dim li of the 4 keys.
+// For key rows 16 t + 4 g + q the swizzle term pi[(row >> 2) & 3] is pi[g] whatever t is, so the address is a per-lane base
+// (one per plane and 16-dim half) plus the compile-time offset 1024 t.
+__device__ __forceinline__ bf16x4 tr_read(const unsigned addr) {
+    return __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)addr));
 }
 
 template <bool SHIFTED>
@@ -955,6 +952,10 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_split_kernel(
     const float* __restrict__ qkv, const float* __restrict__ qkv_bias,
     const float* __restrict__ table, float* __restrict__ out, const WinParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    // Like K20 the kernel owns its CUs (all 256 architectural VGPRs x 2 waves per SIMD = the whole register file): beside
+    // its bf16 MFMA + LDS waves, v_pk_fma_f32 with an SGPR source in a neighbouring kernel's wave returned wrong values in
+    // lanes 48..63 (the dynamic mask head in the pipelined replay).
+    asm volatile("v_mov_b32 v255, 0" ::: "v255");
     float* Tb = reinterpret_cast<float*>(smem_raw + SP_TB);
     char* Kp = smem_raw + SP_K;
     int* wflag = reinterpret_cast<int*>(smem_raw + SP_MISC);
@@ -979,6 +980,9 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_split_kernel(
     const int b = bid;
     const int C3 = 3 * p.C;
     const int r = lane & 15, g = lane >> 4;
+    STAMP_RT(30);
+    STAMP_HWID(29);
+    STAMP(0);
 
     // slot = col*8 + dz, col = dy*7 + dx (temporal index fastest)
     auto slot_info = [&](int i, int& reg, int& ccode) -> int {
@@ -1032,6 +1036,7 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_split_kernel(
         }
         const int wave_differs = __any(differs);
         if (SHIFTED && lane == 0) wflag[wave] = wave_differs ? 1 : 0;
+        STAMP(1);
         if (tid < FNT * 4) {                                // key-group codes: group = slots 16t + 4gg .. +3
             const int t = tid >> 2, gg = tid & 3;
             const int col = 2 * t + (gg >> 1);
@@ -1068,6 +1073,7 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_split_kernel(
             if (i < TBL) Tb[yx * 15 + 14 - zz] = tv[it] * LOG2E;
         }
     }
+    STAMP(2);
     __syncthreads();
     bool has_mask = false;
     if (SHIFTED) {
@@ -1076,14 +1082,34 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_split_kernel(
         for (int w8 = 0; w8 < THREADS / 64; ++w8) f |= wflag[w8];
         has_mask = f != 0;
     }
+    STAMP(3);
+    int stamp_slot = 4;
+    (void)stamp_slot;
 
     const unsigned tbase = (unsigned)(uintptr_t)(lds_cfloat*)Tb;
     const unsigned kaddr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)Kp;
     const unsigned vaddr = kaddr + 3 * PLANEB;
-    const float scale = 0.17677669529663687f * LOG2E;
+    // The scale lives in a vector register: as an SGPR operand of v_pk_fma_f32 it would be the form that returns wrong
+    // lanes beside waves mixing bf16 MFMAs with LDS traffic (tools/experiments/pk_mfma_probe.hip) -- this kernel's own.
+    float scale;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(scale) : "v"(0.17677669529663687f * LOG2E));
     const int C0 = ((6 * 13 + 6) * 15 + 7) * 4;
-    // K operand of key tile t, plane pl: lane (key r, dims 8g .. 8g+7)
-    const unsigned kfrag = kaddr + (unsigned)(r * KROWB + ((g ^ swz(r)) << 4));
+    // K operand of key tile t, plane pl: lane (key r, dims 8g .. 8g+7); + 1024 t
+    unsigned kfrag[3];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) kfrag[pl] = kaddr + (unsigned)(pl * PLANEB + r * KROWB + ((g ^ swz(r)) << 4));
+    // V operand bases: lane li = r of group g supplies key row 4 g + (r >> 2), dims 16 dt + 4 (r & 3) ..; + 1024 t
+    unsigned vfrag[3][2];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            const int row = 4 * g + (r >> 2), pp = r & 3;
+            vfrag[pl][dt] = vaddr + (unsigned)(pl * PLANEB + row * KROWB + (((2 * dt + (pp >> 1)) ^ swz(row)) << 4) + 8 * (pp & 1));
+        }
+    // slots 392 .. 399 of the last key tile do not exist (k-chunks g >= 2): their P is 0, but 0 x (whatever bytes follow
+    // the plane) could be NaN -- those lanes re-read tile 23 instead ("pad, don't mask": the transposing read needs every lane)
+    const unsigned last_off = (unsigned)((g >= 2 ? FNT - 2 : FNT - 1) * 16 * KROWB);
 
     // Q fragment of a tile: lane (query r, dims 8g .. 8g+7), scaled, split; + the query's token / bias code / region
     auto load_q = [&](int qt, float (&qf)[8], int& qsrc, int& qcode) {
@@ -1115,7 +1141,7 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_split_kernel(
         bf16x8 kf[3];
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
-            kf[pl] = *(const __attribute__((address_space(3))) bf16x8*)(uintptr_t)(kfrag + (unsigned)(kt * 16 * KROWB + pl * PLANEB));
+            kf[pl] = *(const __attribute__((address_space(3))) bf16x8*)(uintptr_t)(kfrag[pl] + (unsigned)(kt * 16 * KROWB));
         MFMA6_32(a, kf, qs);
         if (has_mask) {
             const float pen = ((gc >> 16) != qreg) ? -100.0f * LOG2E : 0.f;
@@ -1149,6 +1175,7 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_split_kernel(
             acc[t] = score_tile(t, qs, qaddr, qreg);
             if (t & 1) __builtin_amdgcn_sched_barrier(0);     // two key tiles per scheduling window: the LDS reads of one
         }                                                     // overlap the MFMAs of the other, no more fragments live
+        STAMP(stamp_slot); ++stamp_slot;
         if (qt + stride < ntile) load_q(qt + stride, qn, qsrc_n, qcode_n);   // next tile's Q, hidden behind softmax + PV
 
         if (g >= 2) acc[FNT - 1] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};  // slots 392..399
@@ -1166,6 +1193,7 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_split_kernel(
 #pragma unroll
             for (int t = 0; t < FNT; ++t) acc[t] -= (f32x4){mx, mx, mx, mx};
         }
+        STAMP(stamp_slot); ++stamp_slot;
         float sum = 0.f;
         f32x4 o0 = (f32x4){0.f, 0.f, 0.f, 0.f}, o1 = o0;
         // exp, row sums, split of P and O^T = V^T . P^T, two key tiles (32 keys) per MFMA k-step
@@ -1185,8 +1213,8 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_split_kernel(
                 bf16x8 vf[3];
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) {
-                    const bf16x4 lo = v_tr(vaddr + pl * PLANEB, 16 * t + 4 * g, dt, r);
-                    const bf16x4 hi = v_tr(vaddr + pl * PLANEB, 16 * (t + 1) + 4 * g, dt, r);
+                    const bf16x4 lo = tr_read(vfrag[pl][dt] + (unsigned)(t * 16 * KROWB));
+                    const bf16x4 hi = tr_read(vfrag[pl][dt] + (unsigned)((t + 1) * 16 * KROWB));
                     vf[pl] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 }
                 if (dt == 0) MFMA6_32(o0, vf, ps); else MFMA6_32(o1, vf, ps);
@@ -1205,7 +1233,7 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_split_kernel(
             for (int dt = 0; dt < 2; ++dt) {
                 bf16x4 vf[3];
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) vf[pl] = v_tr(vaddr + pl * PLANEB, 16 * t + 4 * g, dt, r);
+                for (int pl = 0; pl < 3; ++pl) vf[pl] = tr_read(vfrag[pl][dt] + last_off);
                 if (dt == 0) MFMA6_16(o0, vf, ps); else MFMA6_16(o1, vf, ps);
             }
         }
@@ -1217,6 +1245,7 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_split_kernel(
             *reinterpret_cast<float4*>(orow) = make_float4(o0[0] * inv, o0[1] * inv, o0[2] * inv, o0[3] * inv);
             *reinterpret_cast<float4*>(orow + 16) = make_float4(o1[0] * inv, o1[1] * inv, o1[2] * inv, o1[3] * inv);
         }
+        STAMP(stamp_slot); ++stamp_slot;
     }
 
     if (share_last) {
@@ -1265,7 +1294,8 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_split_kernel(
                 for (int dt = 0; dt < 2; ++dt) {
                     bf16x4 vf[3];
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) vf[pl] = v_tr(vaddr + pl * PLANEB, 16 * kt + 4 * g, dt, r);
+                    for (int pl = 0; pl < 3; ++pl)
+                        vf[pl] = tr_read(vfrag[pl][dt] + (kt == FNT - 1 ? last_off : (unsigned)(kt * 16 * KROWB)));
                     if (dt == 0) MFMA6_16(o0, vf, ps); else MFMA6_16(o1, vf, ps);
                 }
             }
@@ -1301,6 +1331,11 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_split_kernel(
             out[(long)osrc * p.C + head * HD + d] = num / den;
         }
     }
+    // The waves retire together: a wave that ended early would free its half of the SIMD's registers for another kernel's
+    // wave while its neighbour is still issuing MFMAs -- the co-residence the register claim at the top rules out.
+    __syncthreads();
+    STAMP(stamp_slot);
+    STAMP_RT(31);
 }
 
 int launch_full(const float* qkv, const float* qkv_bias, const float* table, float* out,

@@ -1072,3 +1072,44 @@ def test_linear_split_layernorm_is_repeatable(ops, tile):
     for _ in range(150):
         bad += int(not torch.equal(ops.linear_split(x, w, None, (gam, bet, 1e-5), tile=tile, stats=stats), first))
     assert bad == 0, bad
+
+
+@pytest.mark.parametrize("neighbour", ["k20_stage2", "k20_stage0", "k1_split"])
+def test_bf16_mfma_kernels_leave_concurrent_kernels_alone(ops, neighbour):
+    """Regression for the round-3 soak failure.  On MI355X a wave mixing bf16 MFMAs with LDS traffic makes v_pk_fma_f32
+    with an SGPR source return wrong low halves in lanes 48..63 in OTHER waves of the same SIMD -- another kernel's
+    included: K4 (169 scalar-cache weights per instance feeding packed FMAs, no LDS, few registers) launched beside K20
+    came back wrong in 20-30 % of its launches (tools/experiments/pk_mfma_probe.hip, k20_vs_dynmask.py).  K20 and the
+    split K1 now own their CUs (whole register file claimed, waves retire together); K4 beside them must stay bit-exact."""
+    from neurips2023_soc_amd import _lib
+    g = torch.Generator().manual_seed(0)
+    T, Q, h, w = 8, 20, 90, 160
+    feats = torch.randn(T, 8, h, w, generator=g).cuda()
+    params = (torch.randn(T * Q, 169, generator=g) * 0.3).cuda()
+    refs = torch.rand(T * Q, 2, generator=g).cuda()
+    if neighbour == "k20_stage2":
+        x, wt = torch.randn(7360, 384, generator=g).cuda(), (torch.randn(1536, 384, generator=g) / 20).cuda()
+        b = torch.randn(1536, generator=g).cuda()
+        big = lambda: ops.linear_split(x, wt, b, act="gelu")                         # noqa: E731
+    elif neighbour == "k20_stage0":
+        x, wt = torch.randn(117760, 96, generator=g).cuda(), (torch.randn(384, 96, generator=g) / 10).cuda()
+        b = torch.randn(384, generator=g).cuda()
+        big = lambda: ops.linear_split(x, wt, b, act="gelu")                         # noqa: E731
+    else:
+        qkv = torch.randn(1, 4, 48, 80, 3 * 192, generator=g).cuda()
+        qb, table = torch.randn(3 * 192, generator=g).cuda(), (torch.randn(2535, 6, generator=g) * 0.1).cuda()
+        assert _lib.load().soc_win_attn3d_get_split() == 1 or ops.MATMUL_MODE != "split"
+        big = lambda: ops.window_attention3d(qkv, qb, table, 6, (8, 7, 7), (4, 3, 3))   # noqa: E731
+    first = ops.dynamic_mask(feats, params, refs, (360.0, 640.0), 4).clone()
+    big()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    bad = torch.zeros((), dtype=torch.int64, device="cuda")
+    for _ in range(120):
+        for _ in range(4):
+            big()
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                bad += (ops.dynamic_mask(feats, params, refs, (360.0, 640.0), 4) != first).any()
+    torch.cuda.synchronize()
+    assert int(bad) == 0, f"{int(bad)} of 360 mask-head launches beside {neighbour} differ from the first"
