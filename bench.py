@@ -29,6 +29,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32-input MFMA peak
 PEAK_HBM_GBS = 8000.0          # HBM3E spec
+PEAK_BF16_MFMA_TFLOPS = 2500.0 # MI355X_MICROARCH.md: dense bf16 MFMA peak (spec; the clock held on random data is lower)
 WEIGHT_SEED = 2023
 
 
@@ -277,6 +278,37 @@ def main():
         k1_per_launch_us = [round(1e3 * replay([c], K1_REPS), 1) for c in k1_calls]
     del k1_calls[:]
 
+    # K20 (the kernel with the largest share of a clip): the same back-to-back replay of one forward's launches
+    hot_ops.record_linear_split_calls(True)
+    step(0)
+    k20_calls = hot_ops.record_linear_split_calls(False)
+    torch.cuda.synchronize()
+    k20_ms_per_forward, k20_flop, k20_shapes = 0.0, 0.0, []
+    if k20_calls:
+        def replay20(calls, reps):
+            torch.cuda._sleep(40_000_000)
+            s_ev, e_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s_ev.record()
+            for _ in range(reps):
+                for c in calls:
+                    hot_ops.linear_split(**c)
+            e_ev.record()
+            torch.cuda.synchronize()
+            return s_ev.elapsed_time(e_ev) / reps
+        replay20(k20_calls, 3)
+        k20_ms_per_forward = replay20(k20_calls, K1_REPS)
+        seen = {}
+        for c in k20_calls:
+            Nn, Kk = c["weight"].shape
+            Mm = c["x"].numel() // Kk
+            k20_flop += 2.0 * Mm * Nn * Kk
+            seen.setdefault((Mm, Nn, Kk), []).append(c)
+        for (Mm, Nn, Kk), cs in seen.items():
+            us = 1e3 * replay20(cs[:1], K1_REPS)
+            k20_shapes.append({"M": Mm, "N": Nn, "K": Kk, "launches": len(cs), "us": round(us, 1),
+                               "tflops": round(2.0 * Mm * Nn * Kk / us / 1e6, 1)})
+    del k20_calls[:]
+
     assert gathered.shape[0] == world == a.gpus and timed["ranks_seen"] == list(range(world)), timed["ranks_seen"]
 
     if rank == 0:
@@ -312,7 +344,7 @@ def main():
         # HBM bytes per clip from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE collected
         # separately and corrected as MI355X_MICROARCH.md prescribes): profiles/r01_hbm_traffic_pmc.json
         traffic, traffic_file = {}, None
-        for name in ("r02_hbm_traffic_pmc.json", "r01_hbm_traffic_pmc.json"):
+        for name in ("r03_hbm_traffic_pmc.json", "r02_hbm_traffic_pmc.json", "r01_hbm_traffic_pmc.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as f:
                     traffic = {k: v["hbm_total"] for k, v in json.load(f)["per_clip_bytes"].items()}
@@ -321,11 +353,16 @@ def main():
             except (OSError, KeyError, ValueError):
                 continue
         default_cfg = (a.backbone, T, H, Wd) == ("video-swin-t", 8, 360, 640)
+        split_k1 = hot_ops.k1_split_enabled()
+        issued = ("the products run on the bf16 matrix cores, six bf16 MFMA products per f32 product (exact three-way operand "
+                  "split); `achieved` counts the ALGORITHMIC f32 FLOPs once and is priced against the f32-input MFMA peak, the "
+                  "rate the f32 form of the same kernel is bound by; bf16_* prices the issued bf16 MFMA FLOPs against the bf16 peak")
+        blocks = {}
         k1 = prof.get("win_attn3d")
         if k1 and k1_ms_per_forward > 0:
             flop_per_clip = k1["work"] / a.steps
             ach = flop_per_clip / (k1_ms_per_forward * 1e-3) / 1e12
-            line["roofline"] = {
+            blocks["win_attn3d"] = {
                 "kernel": "soc_win_attn3d_f32 (all 12 launches of a forward)", "bound": "mfma",
                 "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
                 "traffic": traffic.get("win_attn3d") if default_cfg else None,
@@ -337,8 +374,35 @@ def main():
                 "measured": f"HIP events on the launch stream around {K1_REPS} back-to-back replays of the {len(k1_per_launch_us)} "
                             "K1 launches of one forward (the forward's own qkv / bias tensors), right after the timed region",
                 "per_launch_event_pairs_ms_per_clip": k1["ms"] / a.steps,
-                "source": "profiles/r02_bench_kernel_stats.csv rows win_attn3d_full_kernel<false|true> "
+                "source": "profiles/r03_bench_kernel_stats.csv rows win_attn3d_split_kernel<false|true> "
                           "(rocprofv3 --kernel-trace --stats of this command): TotalDurationNs / clips"}
+            if split_k1:        # 6 products; 400 x 400 issued for 392 x 392 (query and key tiles of 16)
+                bf = 6.0 * ach * (400.0 * 400.0) / (392.0 * 392.0)
+                blocks["win_attn3d"].update(arithmetic=issued, bf16_issued_tflops=bf, bf16_peak=PEAK_BF16_MFMA_TFLOPS,
+                                            bf16_frac=bf / PEAK_BF16_MFMA_TFLOPS)
+        k20 = prof.get("linear_split")
+        if k20 and k20_ms_per_forward > 0:
+            ach = k20_flop / (k20_ms_per_forward * 1e-3) / 1e12
+            n20 = sum(sh["launches"] for sh in k20_shapes)
+            blocks["linear_split"] = {
+                "kernel": f"soc_linear_split_f32 (all {n20} launches of a forward)", "bound": "mfma",
+                "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
+                "traffic": traffic.get("linear_split") if default_cfg else None,
+                "traffic_unit": f"HBM bytes per clip ({n20} launches), rocprofv3 PMC, {traffic_file}",
+                "algorithmic_flop_per_clip": k20_flop, "avg_launch_us": 1e3 * k20_ms_per_forward / max(n20, 1),
+                "ms_per_clip": k20_ms_per_forward, "per_shape": k20_shapes,
+                "arithmetic": issued, "bf16_issued_tflops": 6.0 * ach, "bf16_peak": PEAK_BF16_MFMA_TFLOPS,
+                "bf16_frac": 6.0 * ach / PEAK_BF16_MFMA_TFLOPS,
+                "measured": f"HIP events on the launch stream around {K1_REPS} back-to-back replays of the K20 launches of one "
+                            "forward (the forward's own activations, weights and row statistics), right after the timed region; "
+                            "algorithmic FLOPs = sum of 2 M N K",
+                "per_launch_event_pairs_ms_per_clip": k20["ms"] / a.steps,
+                "source": "profiles/r03_bench_kernel_stats.csv rows linear_split_kernel<...>: TotalDurationNs / clips"}
+        if blocks:      # the roofline object is the kernel with the largest share of a clip; the other one follows
+            order = sorted(blocks, key=lambda n: -blocks[n]["ms_per_clip"])
+            line["roofline"] = blocks[order[0]]
+            for n in order[1:]:
+                line["roofline_" + n] = blocks[n]
         other = {}
         for name in ("msda_fwd", "xattn", "dyn_mask", "add_layernorm", "groupnorm_tokens", "patch_merge_layernorm"):
             if name in prof:

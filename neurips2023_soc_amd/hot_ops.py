@@ -36,6 +36,19 @@ def record_window_attention_calls(on: bool):
     return calls
 
 
+_k20_calls = None  # bench.py: when a list, linear_split appends its arguments (row statistics included)
+
+
+def record_linear_split_calls(on: bool):
+    """As record_window_attention_calls, for K20: the recorded dicts are keyword arguments of linear_split."""
+    global _k20_calls
+    if on:
+        _k20_calls = []
+        return None
+    calls, _k20_calls = _k20_calls, None
+    return calls
+
+
 def profile_begin() -> None:
     global _prof
     _prof = {}
@@ -933,6 +946,7 @@ def linear_split(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None,
     x = _f32c(x)
     N, K = weight.shape
     M = x.numel() // K
+    bias_in = bias
     packed, bias, colsum = split_pack(weight, bias, *(ln[:2] if ln is not None else (None, None)))
     out2 = None
     if split_at is None:
@@ -959,6 +973,9 @@ def linear_split(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None,
     if M == 0:
         return out if out2 is None else (out, out2)
     cfg = split_tile_for(M, N, K) if tile is None else int(tile)
+    if _k20_calls is not None:
+        _k20_calls.append(dict(x=x, weight=weight, bias=bias_in, ln=ln, residual=residual, act=act, add=add, mul=mul,
+                               tile=cfg, stats=stats, split_at=split_at))
     ptr = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
     with _timed("linear_split", 2.0 * M * N * K):
         rc = lib.soc_linear_split_f32(x.data_ptr(), ptr(add), ptr(stats) if ln is not None else None, ptr(colsum),

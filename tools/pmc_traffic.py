@@ -9,7 +9,8 @@ import json
 import sys
 
 GROUPS = collections.OrderedDict([
-    ("win_attn3d", ("win_attn3d",)), ("msda_fwd", ("msda_fwd", "msda_fused")), ("xattn", ("xattn_",)), ("dyn_mask", ("dyn_mask",)),
+    ("win_attn3d", ("win_attn3d",)), ("linear_split", ("linear_split_kernel",)), ("row_stats", ("row_stats_kernel",)),
+    ("msda_fwd", ("msda_fwd", "msda_fused")), ("xattn", ("xattn_",)), ("dyn_mask", ("dyn_mask",)),
     ("add_layernorm", ("add_layernorm",)), ("linear_small", ("linear_small",)), ("linear_act", ("gemm_nt_kernel",)),
     ("groupnorm_tokens", ("gn_stats", "gn_apply")), ("patch_merge_layernorm", ("patch_merge",)), ("ws_linear", ("ws_linear_kernel",)),
     ("box_refine", ("box_refine",)), ("decoder_cross_attn", ("dec_cross_attn_kernel",)), ("row_mlp", ("row_mlp_kernel",)),

@@ -1,5 +1,6 @@
 """Launch one hot kernel repeatedly at a BASELINE-config geometry (for rocprofv3 --pmc passes).
-usage: python tools/run_kernel.py {k1s0|k1s1|k1s2|k1s3|msda|vlf|dyn} [reps]"""
+usage: python tools/run_kernel.py {k1s0|k1s1|k1s2|k1s3|msda|vlf|dyn|k20ffn|k20qkv1|k20fc1s2} [reps]
+(SOC_MATMUL=f32 in the environment keeps K1 on the f32-input MFMA form: the ablation partner of the default split form)"""
 import sys
 
 import torch
@@ -33,6 +34,17 @@ elif which == "vlf":
     k = torch.randn(10, 1, 256, generator=g).to(dev)
     v = torch.randn(10, 1, 256, generator=g).to(dev)
     fn = lambda: hot_ops.mha_core(q, k, v, 8)  # noqa: E731
+elif which.startswith("k20"):
+    # K20 at three of its call sites: encoder FFN up-projection (+ReLU), stage-1 qkv with the LayerNorm in front,
+    # stage-2 fc1 + GELU
+    M, N, K, act, use_ln = {"k20ffn": (38560, 2048, 256, "relu", False), "k20qkv1": (28800, 576, 192, "none", True),
+                            "k20fc1s2": (7360, 1536, 384, "gelu", False)}[which]
+    x = torch.randn(M, K, generator=g).to(dev)
+    wt = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
+    b = torch.randn(N, generator=g).to(dev)
+    ln = ((torch.rand(K, generator=g) + 0.5).to(dev), torch.randn(K, generator=g).to(dev), 1e-5) if use_ln else None
+    stats = hot_ops.row_stats(x, 1e-5) if use_ln else None
+    fn = lambda: hot_ops.linear_split(x, wt, b, ln=ln, act=act, stats=stats)  # noqa: E731
 elif which.startswith("ln"):
     rows, C = {"ln0": (115200, 96), "ln1": (28800, 192), "lnenc": (38560, 256), "ln2": (7360, 384)}[which]
     x = torch.randn(rows, C, generator=g).to(dev)
