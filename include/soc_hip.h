@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SOC_HIP_ABI_VERSION 7
+#define SOC_HIP_ABI_VERSION 8
 
 #define SOC_OK 0
 #define SOC_EINVAL (-1)       /* null pointer / non-positive dimension */
@@ -234,6 +234,18 @@ int soc_groupnorm_tokens_f32(const float* x, const float* gamma, const float* be
  */
 int soc_patch_merge_layernorm_f32(const float* x, const float* gamma, const float* beta, float* out, int BD,
                                   int H, int W, int C, float eps, void* stream);
+
+/*
+ * K21 -- Video-Swin patch embedding: the (1,4,4) / stride (1,4,4) convolution + LayerNorm(C) in one pass.  Replaces
+ * PatchEmbed3D.forward (models/video_swin_transformer.py:438-456: F.pad to multiples of the patch, the Conv3d `proj`,
+ * flatten(2).transpose(1, 2), `norm`) for the patch size SOC builds the backbone with (:676, temporal patch 1).
+ *   frames [N, 3, H, W] (N = batch * frames), weight [C, 3, 1, 4, 4] as stored in the reference's state_dict,
+ *   bias [C] or NULL, gamma / beta [C]  ->  out [N, ceil(H/4), ceil(W/4), C] token-major;
+ *   pixels past the right / bottom edge count as zeros (the reference's F.pad).
+ * C = 96 (Swin-T / -S) or 128 (Swin-B); anything else returns SOC_EUNSUPPORTED.
+ */
+int soc_patch_embed_layernorm_f32(const float* frames, const float* weight, const float* bias, const float* gamma,
+                                  const float* beta, float* out, int N, int H, int W, int C, float eps, void* stream);
 
 /*
  * K12 -- tiled fp32 MFMA GEMM with a fused activation: out = act(x W^T + bias), act 0 = none, 1 = ReLU,

@@ -727,6 +727,29 @@ def patch_merge_layernorm(x: Tensor, weight: Tensor, bias: Tensor, eps: float = 
     return out
 
 
+def patch_embed_supported(frames: Tensor, weight: Tensor) -> bool:
+    return (frames.is_cuda and frames.dtype == torch.float32 and frames.dim() == 4 and frames.shape[1] == 3
+            and weight.shape[0] in (96, 128) and tuple(weight.shape[1:]) == (3, 1, 4, 4))
+
+
+def patch_embed_layernorm(frames: Tensor, weight: Tensor, bias: Optional[Tensor], gamma: Tensor, beta: Tensor,
+                          eps: float = 1e-5) -> Tensor:
+    """K21.  frames [N,3,H,W], conv weight [C,3,1,4,4] -> LayerNorm(conv4x4/4(frames)) [N,ceil(H/4),ceil(W/4),C]."""
+    _need_gpu(frames, weight, bias, gamma, beta)
+    lib = _lib.load()
+    frames = _f32c(frames)
+    N, _, H, W = frames.shape
+    C_ = weight.shape[0]
+    out = torch.empty((N, (H + 3) // 4, (W + 3) // 4, C_), dtype=torch.float32, device=frames.device)
+    with _timed("patch_embed_layernorm", frames.numel() * 4 + out.numel() * 4):
+        code = lib.soc_patch_embed_layernorm_f32(frames.data_ptr(), _f32c(weight).data_ptr(),
+                                                 None if bias is None else _f32c(bias).data_ptr(),
+                                                 _f32c(gamma).data_ptr(), _f32c(beta).data_ptr(), out.data_ptr(),
+                                                 N, H, W, C_, float(eps), _stream())
+    _lib.check(code, "soc_patch_embed_layernorm_f32")
+    return out
+
+
 def linear_act(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, act: str = "none") -> Tensor:
     """K12.  act(x @ weight.T + bias) with act in {"none", "relu", "gelu"} (gelu = exact erf form) in one tiled
     MFMA GEMM; x [..., K] with K % 16 == 0, weight [N, K] with N % 4 == 0."""

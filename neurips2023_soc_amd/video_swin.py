@@ -10,6 +10,7 @@ that exists here.  Module / parameter names follow the reference so its checkpoi
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional, Sequence
 
 import torch
@@ -116,7 +117,10 @@ class BasicLayer(nn.Module):
                 x = hot_ops.linear_split(o, a.proj.weight, a.proj.bias, residual=x)
                 h = hot_ops.linear_split(x, m.fc1.weight, m.fc1.bias, ln=(blk.norm2.weight, blk.norm2.bias, blk.norm2.eps),
                                          act="gelu")
-                x = fused.linear(h, m.fc2.weight, m.fc2.bias, residual=x)      # K20 or library + add (split_wins)
+                if _FORCE_SPLIT_FLOW:
+                    x = hot_ops.linear_split(h, m.fc2.weight, m.fc2.bias, residual=x)
+                else:
+                    x = fused.linear(h, m.fc2.weight, m.fc2.bias, residual=x)  # K20 or library + add (split_wins)
             return x
         if self._weight_stationary(x):
             for blk in blocks:
@@ -150,6 +154,10 @@ class BasicLayer(nn.Module):
         blk = self.blocks[0]
         C = x.shape[-1]
         rows = x.numel() // C
+        if _FORCE_SPLIT_FLOW:       # experiment switch (tools/experiments/README.md): every stage with rows >= the value
+            return (x.is_cuda and x.dtype == torch.float32 and C >= 192 and rows >= _FORCE_SPLIT_FLOW
+                    and hot_ops.split_enabled()
+                    and hot_ops.linear_split_supported(x, blk.attn.qkv.weight, True))
         return (x.is_cuda and x.dtype == torch.float32 and C >= 192 and rows >= 16384
                 and hot_ops.split_wins(rows, 3 * C, C, 1, "swin") and hot_ops.split_wins(rows, C, C, 1, "swin")
                 and hot_ops.linear_split_supported(x, blk.attn.qkv.weight, True))
@@ -161,6 +169,9 @@ class BasicLayer(nn.Module):
                 and hot_ops.ws_linear_supported(x, blk.attn.qkv.weight, True)
                 and hot_ops.ws_linear_supported(x, blk.attn.proj.weight, False)
                 and hot_ops.ws_linear_supported(x, blk.mlp.fc1.weight, True))
+
+
+_FORCE_SPLIT_FLOW = int(os.environ.get("SOC_FORCE_SPLIT_FLOW_ROWS", "0"))
 
 
 class PatchMerging(nn.Module):
@@ -191,6 +202,12 @@ class PatchEmbed3D(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """[B,3,T,H,W] -> token-major [B,T,H/4,W/4,C]; the (1,4,4) conv is a per-frame 4x4/4 conv."""
         B, _, T, H, W = x.shape
+        frames = x.transpose(1, 2)                                      # [B,T,3,H,W]: the caller's own layout
+        if frames.is_contiguous() and hot_ops.patch_embed_supported(frames.reshape(B * T, 3, H, W), self.proj.weight):
+            # K21: convolution + LayerNorm in one pass over the clip (edge padding included)
+            f = hot_ops.patch_embed_layernorm(frames.reshape(B * T, 3, H, W), self.proj.weight, self.proj.bias,
+                                              self.norm.weight, self.norm.bias, self.norm.eps)
+            return f.view(B, T, f.shape[1], f.shape[2], -1)
         if W % 4:
             x = F.pad(x, (0, 4 - W % 4))
         if H % 4:

@@ -1113,3 +1113,44 @@ def test_bf16_mfma_kernels_leave_concurrent_kernels_alone(ops, neighbour):
                 bad += (ops.dynamic_mask(feats, params, refs, (360.0, 640.0), 4) != first).any()
     torch.cuda.synchronize()
     assert int(bad) == 0, f"{int(bad)} of 360 mask-head launches beside {neighbour} differ from the first"
+
+
+@pytest.mark.parametrize("N,H,W,C", [(8, 360, 640, 96), (2, 30, 41, 96), (3, 250, 300, 128), (1, 4, 4, 96), (5, 37, 52, 128)])
+def test_patch_embed_layernorm_vs_f64(ops, N, H, W, C):
+    """K21 against the reference recipe (PatchEmbed3D.forward, models/video_swin_transformer.py:438-456: pad to multiples
+    of 4, the (1,4,4) convolution, LayerNorm) in f64 on the CPU; odd sizes exercise the edge padding and ragged tiles."""
+    g = torch.Generator().manual_seed(N * 1000 + W)
+    frames = torch.randn(N, 3, H, W, generator=g)
+    w = torch.randn(C, 3, 1, 4, 4, generator=g) * 0.2
+    b = torch.randn(C, generator=g) * 0.1
+    gam, bet = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1
+    x = torch.nn.functional.pad(frames.double(), (0, -W % 4, 0, -H % 4))
+    want = torch.nn.functional.conv2d(x, w[:, :, 0].double(), b.double(), stride=4).permute(0, 2, 3, 1)
+    want = torch.nn.functional.layer_norm(want, (C,), gam.double(), bet.double(), 1e-5)
+    got = ops.patch_embed_layernorm(frames.cuda(), w.cuda(), b.cuda(), gam.cuda(), bet.cuda(), 1e-5)
+    assert got.shape == want.shape
+    assert maxdiff(got, want) < 2e-5
+    nob = ops.patch_embed_layernorm(frames.cuda(), w.cuda(), None, gam.cuda(), bet.cuda(), 1e-5)
+    want0 = torch.nn.functional.layer_norm(
+        torch.nn.functional.conv2d(x, w[:, :, 0].double(), None, stride=4).permute(0, 2, 3, 1), (C,), gam.double(),
+        bet.double(), 1e-5)
+    assert maxdiff(nob, want0) < 2e-5
+
+
+def test_patch_embed_module_uses_fused_kernel_and_matches_library_path(ops):
+    from neurips2023_soc_amd import video_swin
+    torch.manual_seed(0)
+    pe = video_swin.PatchEmbed3D(96).cuda().eval()
+    clip = torch.randn(8, 3, 90, 122).cuda()                   # '(b t) c h w' as the backbone receives it
+    x = clip.view(1, 8, 3, 90, 122).transpose(1, 2)
+    ops.profile_begin()
+    with torch.no_grad():
+        got = pe(x)
+    prof = ops.profile_end()
+    assert prof.get("patch_embed_layernorm", {}).get("launches") == 1, prof.keys()
+    with torch.no_grad():
+        xp = torch.nn.functional.pad(x.double().cpu(), (0, 2, 0, 2))
+        f = torch.nn.functional.conv3d(xp, pe.proj.weight.double().cpu(), pe.proj.bias.double().cpu(), stride=(1, 4, 4))
+        want = torch.nn.functional.layer_norm(f.permute(0, 2, 3, 4, 1), (96,), pe.norm.weight.double().cpu(),
+                                              pe.norm.bias.double().cpu(), pe.norm.eps)
+    assert got.shape == want.shape and maxdiff(got, want) < 2e-5
