@@ -15,11 +15,13 @@ from neurips2023_soc_amd.clip_io import DoubleBufferedH2D  # noqa: E402
 from neurips2023_soc_amd.graph_runner import PipelinedClipGraph  # noqa: E402
 
 dev = torch.device("cuda")
-T, H, Wd, L, N = 8, 360, 640, 10, 40
+T, H, Wd, L = 8, 360, 640, 10
+N = int(os.environ.get('PROBE_N', 40))
+NH = int(os.environ.get('PROBE_NHOST', 8))
 model, _, _ = S.build_model(S.default_args("video-swin-t", text_encoder_random_init=True))
 W.load_synthetic(model, 2023)
 model = model.to(dev).eval()
-host = [W.synthetic_clip(1 + i, T, H, Wd).pin_memory() for i in range(8)]
+host = [W.synthetic_clip(1 + i, T, H, Wd).pin_memory() for i in range(NH)]
 ids = W.synthetic_token_ids(1, L).to(dev)
 res = {}
 
@@ -28,7 +30,7 @@ dst = torch.empty(T, 3, H, Wd, device=dev)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for i in range(N):
-    dst.copy_(host[i % 8], non_blocking=True)
+    dst.copy_(host[i % NH], non_blocking=True)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / N
 res["h2d_ms"] = 1e3 * dt
@@ -48,7 +50,7 @@ def run(feed_depth=None, release_early=False):
         for i in range(N):
             if feeder:
                 if i + 1 < N:
-                    feeder.submit(host[(i + 1) % 8])
+                    feeder.submit(host[(i + 1) % NH])
                 c = feeder.acquire()
             else:
                 c = clips[i % 4]
