@@ -1,4 +1,4 @@
-"""Ordered kernel launches of the last forward in a rocprofv3 --kernel-trace CSV (one line per launch).
+"""Ordered kernel launches of one steady-state forward in a rocprofv3 --kernel-trace CSV (one line per launch).
 usage: python tools/launch_sequence.py <kernel_trace.csv>"""
 import csv
 import re
@@ -7,7 +7,10 @@ import sys
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if "spin_kernel" not in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(rows) if "dyn_mask" in r["Kernel_Name"]]
-seg = rows[idx[-2] + 1: idx[-1] + 1]
+# a steady-state forward of the timed region: forward 10 (bench.py: 3 warm-up + 20 timed steps, then the streamed and
+# f32 passes and the back-to-back K1 / K20 replays, which are not forwards); short traces fall back to the last one
+k = 10 if len(idx) > 12 else len(idx) - 1
+seg = rows[idx[k - 1] + 1: idx[k] + 1]
 t0 = int(seg[0]["Start_Timestamp"])
 prev_end = t0
 for i, r in enumerate(seg):
