@@ -172,9 +172,8 @@ __global__ __launch_bounds__(THREADS, 2) void linear_split_kernel(const SplitPar
     const int a_row0 = tid >> 2;                                  // + 128 u
     float4 a_raw[A_ITEMS][2], a_add[A_ITEMS][2];
     const bool has_add = p.x_add != nullptr;
-    // Address registers of the per-lane loads below are kept live until the barrier whose vmcnt wait covers the loads
-    // (keep_alive() after it): a precaution from the hunt for a sporadic failure (tools/experiments/README.md, "K20: the
-    // LayerNorm prologue that was dropped").
+    // (keep_addr / keep_alive: the address registers of the per-lane loads stay live until the barrier whose vmcnt wait
+    // covers the loads -- free, the kernel claims all 256 VGPRs anyway)
     const void* keep_addr[A_ITEMS][2] = {};
     auto keep_alive = [&]() {
 #pragma unroll
@@ -242,14 +241,6 @@ __global__ __launch_bounds__(THREADS, 2) void linear_split_kernel(const SplitPar
             *reinterpret_cast<u32x4*>(dst + BM * ROWB) = p1;
             *reinterpret_cast<u32x4*>(dst + 2 * BM * ROWB) = p2;
         }
-#ifndef SOC_K20_NO_COMMIT_WAIT
-        // The three 16-B LDS stores of an item must have left the register file before anything reuses their data / address
-        // registers.  Observed on MI355X / ROCm 7.2 (tools/experiments/README.md, "K20: rows of a tile that went stale"):
-        // inside the pipelined replay, with other kernels' waves sharing the CU, a launch in ~1e-4 came back with the A rows
-        // of lanes 48-63 of one wave (4 token rows) not written for one K-step -- the lanes an LDS store instruction
-        // transfers last.  Waiting for the stores here costs ~2 % and has not failed since.
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
     };
 
     // ---- MFMA fragment addresses (byte offsets inside a buffer), one per k-substep

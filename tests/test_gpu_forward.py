@@ -78,6 +78,38 @@ def test_full_config_matches_reference(gpu_model, golden):
     assert maxdiff(out["pred_logit"], g["pred_logit"]) < 1e-4
 
 
+def test_full_config_f32_mfma_mode_matches_reference_and_split_mode(gpu_model, golden):
+    """SOC_MATMUL=f32 (hot_ops.MATMUL_MODE): every product on the f32-input MFMA, no bf16 matrix-core kernel launched; the
+    default split mode launches K20 and the split K1.  Both meet the reference, and differ from each other by f32 noise."""
+    from neurips2023_soc_amd import hot_ops
+    g = golden("full_forward.npz")
+    assert hot_ops.MATMUL_MODE == "split"
+    hot_ops.profile_begin()
+    out_split = run_cfg(gpu_model, g["cfg"])
+    prof_split = hot_ops.profile_end()
+    hot_ops.MATMUL_MODE = "f32"
+    try:
+        hot_ops.profile_begin()
+        out_f32 = run_cfg(gpu_model, g["cfg"])
+        prof_f32 = hot_ops.profile_end()
+    finally:
+        hot_ops.MATMUL_MODE = "split"
+    assert prof_split.get("linear_split", {}).get("launches", 0) >= 20 and "linear_split" not in prof_f32
+    from neurips2023_soc_amd import _lib
+    assert _lib.load().soc_win_attn3d_get_split() == 0          # the last K1 launch ran in f32 mode
+    for out in (out_split, out_f32):
+        idx, masks = P.select_trajectory(out)
+        assert int(idx) == int(g["selected_query"])
+        assert maxdiff(masks, g["selected_masks"]) < 1e-3
+        assert maxdiff(sub(out["pred_masks"], 1 << 17), g["pred_masks_sub"]) < 1e-3
+        assert maxdiff(out["pred_cls"], g["pred_cls"]) < 1e-4
+    d = maxdiff(out_split["pred_masks"], out_f32["pred_masks"].cpu())
+    print("split vs f32 MFMA: max|dlogit|", d)
+    assert d < 5e-4
+    run_cfg(gpu_model, golden("tiny_forward.npz")["cfg"])       # leaves the library switch back on "split"
+    assert _lib.load().soc_win_attn3d_get_split() == 1
+
+
 @pytest.fixture(scope="module")
 def gpu_model_b(ref_shapes):
     shapes = {k: v[0] for k, v in ref_shapes("b").items() if v[1].startswith("float")}
