@@ -60,6 +60,20 @@ def _covered(layer, hidden_states, args, kwargs) -> bool:
     return hidden_states.dim() == 3 and fused.is_small(hidden_states)
 
 
+def _additive_mask(mask, dtype):
+    """HF passes the SAME boolean [B,1,L,L] mask object to all 12 layers and SDPA turns a boolean mask into an additive
+    one inside every call (two fills, a where and a copy: 48 tiny launches per clip).  Converted once per forward here;
+    the result rides on the mask object itself, so it cannot outlive it (graph captures make new masks)."""
+    if mask is None or mask.dtype != torch.bool:
+        return mask
+    cached = getattr(mask, "_soc_additive", None)
+    if cached is None or cached[0] != (mask._version, dtype):
+        add = torch.zeros(mask.shape, dtype=dtype, device=mask.device).masked_fill_(~mask, float("-inf"))
+        cached = ((mask._version, dtype), add)
+        mask._soc_additive = cached
+    return cached[1]
+
+
 def _layer_forward(self, hidden_states, attention_mask=None, *args, **kwargs):
     if not _covered(self, hidden_states, args, kwargs):
         return self._soc_orig_forward(hidden_states, attention_mask, *args, **kwargs)       # the parent class's forward
@@ -72,7 +86,8 @@ def _layer_forward(self, hidden_states, attention_mask=None, *args, **kwargs):
                                                  (att.key.weight, att.key.bias, False),
                                                  (att.value.weight, att.value.bias, False)])
     q, k, v = (t.view(B, L, nh, E // nh).transpose(1, 2) for t in (q, k, v))
-    ctx = F.scaled_dot_product_attention(q, k, v, attn_mask=attention_mask, scale=getattr(att, "scaling", None))
+    ctx = F.scaled_dot_product_attention(q, k, v, attn_mask=_additive_mask(attention_mask, q.dtype),
+                                         scale=getattr(att, "scaling", None))
     ctx = ctx.transpose(1, 2).reshape(B, L, E)
     h = hot_ops.add_layernorm(hidden_states, fused.linear(ctx, att_out.dense.weight, att_out.dense.bias),
                               att_out.LayerNorm.weight, att_out.LayerNorm.bias, att_out.LayerNorm.eps, return_sum=False)[1]
