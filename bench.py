@@ -53,22 +53,22 @@ def parse():
     return ap.parse_args()
 
 
-def granted_cpus():
+def granted_cpus(cgroup_root="/sys/fs/cgroup"):
     """CPUs this process may actually use: the cgroup CPU quota (v2 cpu.max, v1 cfs_quota_us / cfs_period_us) rounded
     up, capped by the affinity mask.  The GPU boxes show 256 logical CPUs behind a 16-CPU quota: timing the CPU
     baseline at 128 'physical' threads there measures oversubscription, not the machine (VERDICT r2 weak #8)."""
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     quota = None
     try:
-        with open("/sys/fs/cgroup/cpu.max") as f:
+        with open(os.path.join(cgroup_root, "cpu.max")) as f:
             q, per = f.read().split()[:2]
             if q != "max":
                 quota = -(-int(q) // int(per))
     except (OSError, ValueError):
         try:
-            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            with open(os.path.join(cgroup_root, "cpu", "cpu.cfs_quota_us")) as f:
                 q = int(f.read())
-            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            with open(os.path.join(cgroup_root, "cpu", "cpu.cfs_period_us")) as f:
                 per = int(f.read())
             if q > 0:
                 quota = -(-q // per)
