@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SOC_HIP_ABI_VERSION 8
+#define SOC_HIP_ABI_VERSION 9
 
 #define SOC_OK 0
 #define SOC_EINVAL (-1)       /* null pointer / non-positive dimension */
@@ -319,6 +319,10 @@ int soc_box_refine_f32(const float* delta, const float* ref, int ref_dim, const 
 int soc_ws_linear_f32(const float* x, const float* ln_gamma, const float* ln_beta, float ln_eps, const float* w,
                       const float* bias, const float* residual, float* out, long M, int N, int K, int act,
                       void* stream);
+/* Process-wide switch for K13's arithmetic: 1 (default) = K = 96 / 128 layers run on the bf16 matrix cores with the exact
+ * three-way operand split (K13b, f32-grade results, see soc_linear_split_f32); 0 = f32-input MFMA for every width. */
+void soc_ws_linear_set_split(int on);
+int soc_ws_linear_get_split(void);
 
 /*
  * K15 -- the cross-attention block of a deformable-decoder layer in one launch (reference

@@ -17,12 +17,12 @@ EXPORTS = ("soc_hip_abi_version", "soc_hip_error_string", "soc_msda_fwd_f32", "s
            "soc_upsample_merge_labels_u8", "soc_resize_workspace_bytes", "soc_resize_normalize_u8_f32",
            "soc_msda_bwd_f32", "soc_msda_bwd_f64", "soc_groupnorm_tokens_workspace_bytes",
            "soc_groupnorm_tokens_f32", "soc_patch_merge_layernorm_f32", "soc_patch_embed_layernorm_f32", "soc_linear_act_f32",
-           "soc_linear_act_multi_f32", "soc_ws_linear_f32", "soc_decoder_cross_attn_f32",
+           "soc_linear_act_multi_f32", "soc_ws_linear_f32", "soc_ws_linear_set_split", "soc_ws_linear_get_split", "soc_decoder_cross_attn_f32",
            "soc_row_mlp_f32", "soc_groupnorm_nchw_f32", "soc_upsample_add_nchw_f32",
            "soc_upsample_add_tokens_f32", "soc_conv3x3_tokens_f32", "soc_linear_split_packed_bytes",
            "soc_linear_split_pack_f32", "soc_row_stats_f32", "soc_linear_split_f32", "soc_win_attn3d_set_split",
            "soc_win_attn3d_get_split")
-ABI_VERSION = 8
+ABI_VERSION = 9
 SOC_EUNSUPPORTED = -2      # include/soc_hip.h: shape outside what the kernel is built for
 
 _lib = None
@@ -75,6 +75,10 @@ def load() -> C.CDLL:
     lib.soc_msda_fused_fwd_f32.argtypes = [p, p, p, p, p, p, i, p, p, p, i, i, i, i, i, i, i, p]
     lib.soc_ws_linear_f32.restype = i
     lib.soc_ws_linear_f32.argtypes = [p, p, p, f, p, p, p, p, C.c_long, i, i, i, p]
+    lib.soc_ws_linear_set_split.restype = None
+    lib.soc_ws_linear_set_split.argtypes = [i]
+    lib.soc_ws_linear_get_split.restype = i
+    lib.soc_ws_linear_get_split.argtypes = []
     lib.soc_decoder_cross_attn_f32.restype = i
     lib.soc_decoder_cross_attn_f32.argtypes = [p, p, i, p, i, p, p, p, p, p] + [p] * 10 + [f, p] + [i] * 7 + [p]
     lib.soc_row_mlp_f32.restype = i

@@ -261,6 +261,14 @@ int launch_act(int act, const float* x, const float* gamma, const float* beta, f
 
 }  // namespace
 
+// K13b (ws_linear_split.hip): the same layer on the bf16 matrix cores, exact three-way split
+int soc_ws_linear_split_dispatch(const float* x, const float* ln_gamma, const float* ln_beta, float ln_eps, const float* w,
+                                 const float* bias, const float* residual, float* out, long M, int N, int K, int act,
+                                 hipStream_t st);
+static std::atomic<int> g_ws_split{1};
+extern "C" void soc_ws_linear_set_split(int on) { g_ws_split.store(on != 0, std::memory_order_relaxed); }
+extern "C" int soc_ws_linear_get_split(void) { return g_ws_split.load(std::memory_order_relaxed); }
+
 extern "C" int soc_ws_linear_f32(const float* x, const float* ln_gamma, const float* ln_beta, float ln_eps,
                                  const float* w, const float* bias, const float* residual, float* out, long M,
                                  int N, int K, int act, void* stream) {
@@ -273,6 +281,10 @@ extern "C" int soc_ws_linear_f32(const float* x, const float* ln_gamma, const fl
           (uintptr_t)ln_beta) & 15) != 0)
         return SOC_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
+    if (g_ws_split.load(std::memory_order_relaxed)) {
+        const int rc = soc_ws_linear_split_dispatch(x, ln_gamma, ln_beta, ln_eps, w, bias, residual, out, M, N, K, act, st);
+        if (rc != SOC_EUNSUPPORTED) return rc;
+    }
     switch (K) {
         case 96: return launch_act<96>(act, x, ln_gamma, ln_beta, ln_eps, w, bias, residual, out, M, N, st);
         case 128: return launch_act<128>(act, x, ln_gamma, ln_beta, ln_eps, w, bias, residual, out, M, N, st);

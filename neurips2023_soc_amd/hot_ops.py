@@ -824,6 +824,7 @@ def ws_linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, ln: Opti
     b = _f32c(bias) if bias is not None else None
     code = {"none": 0, "relu": 1, "gelu": 2}[act]
     work = 2.0 * M * N * K
+    lib.soc_ws_linear_set_split(int(split_enabled() and "k13" not in _SPLIT_OFF))      # K13b for K = 96 / 128
     with _timed("ws_linear", work):
         rc = lib.soc_ws_linear_f32(x.data_ptr(), g.data_ptr() if g is not None else None,
                                    be.data_ptr() if be is not None else None, eps, weight.data_ptr(),

@@ -936,6 +936,44 @@ def test_ws_linear_vs_torch(ops, M, K, N, ln, res, act, bias):
     assert maxdiff(got, y) < 2e-5 * max(1.0, float(y.abs().max()))
 
 
+@pytest.mark.parametrize("M,K,N,ln,res,act", [
+    (115200, 96, 288, True, False, "none"), (115200, 96, 96, False, True, "none"), (115200, 96, 384, True, False, "gelu"),
+    (30011, 128, 384, True, True, "relu"), (30011, 128, 128, False, False, "none"), (17, 96, 48, True, False, "gelu"),
+])
+def test_ws_linear_split_form_is_f32_grade(ops, M, K, N, ln, res, act):
+    """K13b (K = 96 / 128 on the bf16 matrix cores, exact three-way split) against the f32-MFMA form of the same entry
+    point and against f64: the error of the split form is no larger than the f32 form's (plus rounding noise), both forms
+    are launched (the switch is honoured), and the split form is bit-repeatable."""
+    from neurips2023_soc_amd import _lib
+    g = torch.Generator().manual_seed(M + K + N)
+    x = (torch.randn(M, K, generator=g) * 1.5 + 0.2).cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    lnp = ((torch.rand(K, generator=g) + 0.5).cuda(), (torch.randn(K, generator=g) * 0.1).cuda(), 1e-5) if ln else None
+    r = torch.randn(M, N, generator=g).cuda() if res else None
+    assert ops.MATMUL_MODE == "split"
+    got = ops.ws_linear(x, w, b, lnp, r, act)
+    assert _lib.load().soc_ws_linear_get_split() == 1
+    again = ops.ws_linear(x, w, b, lnp, r, act)
+    assert torch.equal(got, again)
+    ops.MATMUL_MODE = "f32"
+    try:
+        f32 = ops.ws_linear(x, w, b, lnp, r, act)
+        assert _lib.load().soc_ws_linear_get_split() == 0
+    finally:
+        ops.MATMUL_MODE = "split"
+    h = torch.nn.functional.layer_norm(x.double(), (K,), lnp[0].double(), lnp[1].double(), 1e-5) if ln else x.double()
+    y = torch.nn.functional.linear(h, w.double(), b.double())
+    y = torch.nn.functional.gelu(y) if act == "gelu" else (y.relu() if act == "relu" else y)
+    if res:
+        y = y + r.double()
+    scale = max(1.0, float(y.abs().max()))
+    e_split, e_f32 = float((got.double() - y).abs().max()), float((f32.double() - y).abs().max())
+    print(f"K13b {M}x{N}x{K}: split {e_split / scale:.2e}  f32 MFMA {e_f32 / scale:.2e}")
+    assert e_split < 2e-5 * scale and e_split <= 1.25 * e_f32 + 2e-7 * scale, (e_split, e_f32)
+    assert not torch.equal(got, f32) or M < 64          # two different kernels
+
+
 def test_ws_linear_rejects_unsupported(ops):
     x = torch.zeros(32, 100).cuda()
     assert not ops.ws_linear_supported(x, torch.zeros(96, 100).cuda(), False)          # K not a supported width
@@ -1074,13 +1112,13 @@ def test_linear_split_layernorm_is_repeatable(ops, tile):
     assert bad == 0, bad
 
 
-@pytest.mark.parametrize("neighbour", ["k20_stage2", "k20_stage0", "k1_split"])
+@pytest.mark.parametrize("neighbour", ["k20_stage2", "k20_stage0", "k1_split", "k13b"])
 def test_bf16_mfma_kernels_leave_concurrent_kernels_alone(ops, neighbour):
     """Regression for the round-3 soak failure.  On MI355X a wave mixing bf16 MFMAs with LDS traffic makes v_pk_fma_f32
     with an SGPR source return wrong low halves in lanes 48..63 in OTHER waves of the same SIMD -- another kernel's
     included: K4 (169 scalar-cache weights per instance feeding packed FMAs, no LDS, few registers) launched beside K20
-    came back wrong in 20-30 % of its launches (tools/experiments/pk_mfma_probe.hip, k20_vs_dynmask.py).  K20 and the
-    split K1 now own their CUs (whole register file claimed, waves retire together); K4 beside them must stay bit-exact."""
+    came back wrong in 20-30 % of its launches (tools/experiments/pk_mfma_probe.hip, k20_vs_dynmask.py).  K20, the
+    split K1 and K13b own their CUs (whole register file claimed, waves retire together); K4 beside them must stay bit-exact."""
     from neurips2023_soc_amd import _lib
     g = torch.Generator().manual_seed(0)
     T, Q, h, w = 8, 20, 90, 160
@@ -1095,6 +1133,10 @@ def test_bf16_mfma_kernels_leave_concurrent_kernels_alone(ops, neighbour):
         x, wt = torch.randn(117760, 96, generator=g).cuda(), (torch.randn(384, 96, generator=g) / 10).cuda()
         b = torch.randn(384, generator=g).cuda()
         big = lambda: ops.linear_split(x, wt, b, act="gelu")                         # noqa: E731
+    elif neighbour == "k13b":
+        x, wt = torch.randn(115200, 96, generator=g).cuda(), (torch.randn(384, 96, generator=g) / 10).cuda()
+        b = torch.randn(384, generator=g).cuda()
+        big = lambda: ops.ws_linear(x, wt, b, act="gelu")                            # noqa: E731
     else:
         qkv = torch.randn(1, 4, 48, 80, 3 * 192, generator=g).cuda()
         qb, table = torch.randn(3 * 192, generator=g).cuda(), (torch.randn(2535, 6, generator=g) * 0.1).cuda()

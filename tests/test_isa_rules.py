@@ -72,3 +72,22 @@ def test_k1_split_follows_the_same_rules(k1_asm):
         assert not bad, (name, bad[:4])
     counts = re.findall(r"\.name:\s+(_Z\w*win_attn3d_split_kernel\w*)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)", k1_asm)
     assert len(counts) == 2 and all(int(v) == 256 for _, v in counts), counts
+
+
+@pytest.fixture(scope="module")
+def k13b_asm(tmp_path_factory):
+    return _asm(tmp_path_factory, "ws_linear_split.hip")
+
+
+def test_k13b_follows_the_same_rules(k13b_asm):
+    bodies = list(_kernel_bodies(k13b_asm, "ws_linear_split_kernel"))
+    assert len(bodies) >= 20, len(bodies)
+    for name, body in bodies:
+        assert "v_mfma_f32_16x16x32_bf16" in body and "s_barrier" in body, name
+        bad = [ln.strip() for ln in body.splitlines()
+               if re.search(r"\bv_pk_(fma|mul|add)_f32\b", ln) and re.search(r"[ ,]s\[\d+:\d+\]", ln)]
+        assert not bad, (name, bad[:4])
+    counts = re.findall(r"\.name:\s+(_Z\w*ws_linear_split_kernel\w*)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)", k13b_asm)
+    assert len(counts) == len(bodies) and all(int(v) == 256 for _, v in counts), counts[:3]
+    spills = re.findall(r"\.name:\s+_Z\w*ws_linear_split_kernel\w*\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)", k13b_asm)
+    assert spills and all(int(v) == 0 for v in spills), spills

@@ -53,7 +53,7 @@ def make(mode):
         return lambda: k1(True)
     if mode == "k1f32":
         return lambda: k1(False)
-    if mode == "k13":
+    if mode == "k13":                     # K13b (bf16 matrix cores) in the default mode, the f32-MFMA K13 under SOC_MATMUL=f32
         return lambda: hot_ops.ws_linear(x0, w0, b0, act="gelu")
     if mode == "lib":
         return lambda: torch.nn.functional.linear(x2, w2, b2)
