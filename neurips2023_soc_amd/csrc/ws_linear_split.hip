@@ -65,7 +65,9 @@ __device__ __forceinline__ void split8(const float (&v)[8], bf16x8& h0, bf16x8& 
     }
 }
 
-template <int K, int ACT, bool HAS_LN, bool HAS_RES, int CT, int RT>
+// FLY (K > 128, no LayerNorm, one column group per row group): the rows are split step by step inside the MFMA loop instead
+// of up front -- K / 32 x 12 VGPRs of split operands would not fit beside the K / 4 raw words of a K = 384 / 512 row
+template <int K, int ACT, bool HAS_LN, bool HAS_RES, int CT, int RT, bool FLY>
 __global__ __launch_bounds__(THREADS, 2) void ws_linear_split_kernel(
     const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
     const float* __restrict__ w, const float* __restrict__ bias, const float* __restrict__ res,
@@ -132,9 +134,9 @@ __global__ __launch_bounds__(THREADS, 2) void ws_linear_split_kernel(
     for (; t * gpt < g1; ++t) {
         const int ct_lo = t * gpt < g0 ? (int)(g0 - t * gpt) * CT : 0;
         const int ct_hi = (t + 1) * gpt > g1 ? (int)(g1 - t * gpt) * CT : nct;
-        bf16x8 xb[RT][KS][3];
+        bf16x8 xb[FLY ? 1 : RT][FLY ? 1 : KS][3];
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
+        for (int rt = 0; rt < (FLY ? 0 : RT); ++rt) {
             float v[KS][8];
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
@@ -171,8 +173,9 @@ __global__ __launch_bounds__(THREADS, 2) void ws_linear_split_kernel(
 #pragma unroll
             for (int s = 0; s < KS; ++s) split8(v[s], xb[rt][s][0], xb[rt][s][1], xb[rt][s][2]);
         }
-        if ((t + 1) * gpt < g1) load_rows(t + 1);               // the next group's rows fly during this group's MFMAs
-        for (int ct = ct_lo; ct < ct_hi; ct += CT) {
+        if (!FLY && (t + 1) * gpt < g1) load_rows(t + 1);       // the next group's rows fly during this group's MFMAs
+        if (FLY && t != g0 / gpt) load_rows(t);                 // (the first group's rows were loaded behind the weight staging)
+        auto column_group = [&](int ct) {
             f32x4 acc[RT][CT];
             const u32x4* wp = wimg + (ct * KS * 3) * 64 + lane;
 #pragma unroll
@@ -189,16 +192,27 @@ __global__ __launch_bounds__(THREADS, 2) void ws_linear_split_kernel(
 #pragma unroll
                     for (int pl = 0; pl < 3; ++pl) wf[i][pl] = __builtin_bit_cast(bf16x8, wp[((i * KS + s) * 3 + pl) * 64]);
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt)
+                for (int rt = 0; rt < RT; ++rt) {
+                    bf16x8 xs[3];
+                    if (FLY) {
+                        const float v[8] = {xn[rt][s][0].x, xn[rt][s][0].y, xn[rt][s][0].z, xn[rt][s][0].w,
+                                            xn[rt][s][1].x, xn[rt][s][1].y, xn[rt][s][1].z, xn[rt][s][1].w};
+                        split8(v, xs[0], xs[1], xs[2]);
+                    } else {
+                        xs[0] = xb[FLY ? 0 : rt][FLY ? 0 : s][0]; xs[1] = xb[FLY ? 0 : rt][FLY ? 0 : s][1];
+                        xs[2] = xb[FLY ? 0 : rt][FLY ? 0 : s][2];
+                    }
 #pragma unroll
                     for (int i = 0; i < CT; ++i) {      // smallest terms first
-                        acc[rt][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i][2], xb[rt][s][0], acc[rt][i], 0, 0, 0);
-                        acc[rt][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i][1], xb[rt][s][1], acc[rt][i], 0, 0, 0);
-                        acc[rt][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i][0], xb[rt][s][2], acc[rt][i], 0, 0, 0);
-                        acc[rt][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i][1], xb[rt][s][0], acc[rt][i], 0, 0, 0);
-                        acc[rt][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i][0], xb[rt][s][1], acc[rt][i], 0, 0, 0);
-                        acc[rt][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i][0], xb[rt][s][0], acc[rt][i], 0, 0, 0);
+                        acc[rt][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i][2], xs[0], acc[rt][i], 0, 0, 0);
+                        acc[rt][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i][1], xs[1], acc[rt][i], 0, 0, 0);
+                        acc[rt][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i][0], xs[2], acc[rt][i], 0, 0, 0);
+                        acc[rt][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i][1], xs[0], acc[rt][i], 0, 0, 0);
+                        acc[rt][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i][0], xs[1], acc[rt][i], 0, 0, 0);
+                        acc[rt][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i][0], xs[0], acc[rt][i], 0, 0, 0);
                     }
+                }
+                if (FLY && (s & 1)) __builtin_amdgcn_sched_barrier(0);   // keep the weight reads of later steps from piling up
             }
             // lane (r, kq) holds out[m][n0 + 4 kq .. + 3] of every column tile: 16-B stores
 #pragma unroll
@@ -219,6 +233,11 @@ __global__ __launch_bounds__(THREADS, 2) void ws_linear_split_kernel(
                     }
                 }
             }
+        };
+        if (FLY) {          // one column group per row group (the host checks): no loop the split could be hoisted out of
+            column_group(0);
+        } else {
+            for (int ct = ct_lo; ct < ct_hi; ct += CT) column_group(ct);
         }
     }
     __syncthreads();        // the waves retire together: no foreign wave beside a partner that still issues MFMAs
@@ -244,7 +263,9 @@ template <int K, int ACT, bool HAS_LN, bool HAS_RES, int CT>
 int launch_ct(const float* x, const float* gamma, const float* beta, float eps, const float* w, const float* bias,
               const float* res, float* out, long M, int N, hipStream_t st) {
     constexpr int RT = K <= 96 ? 2 : 1;
-    const void* fn = reinterpret_cast<const void*>(ws_linear_split_kernel<K, ACT, HAS_LN, HAS_RES, CT, RT>);
+    constexpr bool FLY = K > 128;
+    if (FLY && (HAS_LN || split_columns(N, K) / 16 != CT)) return SOC_EUNSUPPORTED;     // K13 takes those
+    const void* fn = reinterpret_cast<const void*>(ws_linear_split_kernel<K, ACT, HAS_LN, HAS_RES, CT, RT, FLY>);
     static std::atomic<bool> attr_set[SOC_MAX_DEVICES];
     const int dev = soc_current_device();
     if (dev < 0) return SOC_ELAUNCH;
@@ -259,7 +280,7 @@ int launch_ct(const float* x, const float* gamma, const float* beta, float eps, 
     long per_split = cus / nsplit > 0 ? cus / nsplit : 1;
     if (per_split * 8 > ngroups) per_split = (ngroups + 7) / 8;       // never more waves than row groups
     const size_t lds = (size_t)nc_per_split * (6 * K + 4) + 8 * K;
-    hipLaunchKernelGGL((ws_linear_split_kernel<K, ACT, HAS_LN, HAS_RES, CT, RT>), dim3((unsigned)(per_split * nsplit)),
+    hipLaunchKernelGGL((ws_linear_split_kernel<K, ACT, HAS_LN, HAS_RES, CT, RT, FLY>), dim3((unsigned)(per_split * nsplit)),
                        dim3(THREADS), lds, st, x, gamma, beta, eps, w, bias, res, out, M, N, nc_per_split, (int)per_split);
     return soc_check_launch();
 }
@@ -279,8 +300,12 @@ template <int K, int ACT>
 int launch_k(const float* x, const float* gamma, const float* beta, float eps, const float* w, const float* bias,
              const float* res, float* out, long M, int N, hipStream_t st) {
     if (gamma) {
-        if (res) return launch_one<K, ACT, true, true>(x, gamma, beta, eps, w, bias, res, out, M, N, st);
-        return launch_one<K, ACT, true, false>(x, gamma, beta, eps, w, bias, res, out, M, N, st);
+        if constexpr (K > 128) {
+            return SOC_EUNSUPPORTED;
+        } else {
+            if (res) return launch_one<K, ACT, true, true>(x, gamma, beta, eps, w, bias, res, out, M, N, st);
+            return launch_one<K, ACT, true, false>(x, gamma, beta, eps, w, bias, res, out, M, N, st);
+        }
     }
     if (res) return launch_one<K, ACT, false, true>(x, gamma, beta, eps, w, bias, res, out, M, N, st);
     return launch_one<K, ACT, false, false>(x, gamma, beta, eps, w, bias, res, out, M, N, st);
@@ -297,13 +322,16 @@ int launch_act(int act, const float* x, const float* gamma, const float* beta, f
 }  // namespace
 
 // K13b entry used by soc_ws_linear_f32 when the split arithmetic is switched on and the width is covered here
-// (K = 96 / 128: the stage-0 widths of Swin-T / -S and Swin-B); SOC_EUNSUPPORTED sends the caller back to K13.
+// (K = 96 / 128: the stage-0 widths of Swin-T / -S and Swin-B, and their fc2 layers with K = 384 / 512 when a column range
+// is one group of column tiles); SOC_EUNSUPPORTED sends the caller back to K13.
 int soc_ws_linear_split_dispatch(const float* x, const float* ln_gamma, const float* ln_beta, float ln_eps, const float* w,
                                  const float* bias, const float* residual, float* out, long M, int N, int K, int act,
                                  hipStream_t st) {
     switch (K) {
         case 96: return launch_act<96>(act, x, ln_gamma, ln_beta, ln_eps, w, bias, residual, out, M, N, st);
         case 128: return launch_act<128>(act, x, ln_gamma, ln_beta, ln_eps, w, bias, residual, out, M, N, st);
+        case 384: return launch_act<384>(act, x, ln_gamma, ln_beta, ln_eps, w, bias, residual, out, M, N, st);
+        case 512: return launch_act<512>(act, x, ln_gamma, ln_beta, ln_eps, w, bias, residual, out, M, N, st);
         default: return SOC_EUNSUPPORTED;
     }
 }
