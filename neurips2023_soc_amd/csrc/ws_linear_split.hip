@@ -65,7 +65,7 @@ __device__ __forceinline__ void split8(const float (&v)[8], bf16x8& h0, bf16x8& 
     }
 }
 
-// FLY (K > 128, no LayerNorm, one column group per row group): the rows are split step by step inside the MFMA loop instead
+// FLY (K > 192, no LayerNorm, one column group per row group): the rows are split step by step inside the MFMA loop instead
 // of up front -- K / 32 x 12 VGPRs of split operands would not fit beside the K / 4 raw words of a K = 384 / 512 row
 template <int K, int ACT, bool HAS_LN, bool HAS_RES, int CT, int RT, bool FLY>
 __global__ __launch_bounds__(THREADS, 2) void ws_linear_split_kernel(
@@ -110,7 +110,6 @@ __global__ __launch_bounds__(THREADS, 2) void ws_linear_split_kernel(
         }
     }
     const float inv_k = in_vgpr(1.0f / K), eps_v = in_vgpr(eps);
-    const GeluK gk = gelu_k();
     // Work = (group of RT row tiles, group of CT column tiles) units, dealt to the waves of this column range as contiguous,
     // equal shares (as K13): a row group cut by a share boundary is loaded by both neighbours
     const long ngroups = (M + 16 * RT - 1) / (16 * RT);
@@ -195,8 +194,8 @@ __global__ __launch_bounds__(THREADS, 2) void ws_linear_split_kernel(
                 for (int rt = 0; rt < RT; ++rt) {
                     bf16x8 xs[3];
                     if (FLY) {
-                        const float v[8] = {xn[rt][s][0].x, xn[rt][s][0].y, xn[rt][s][0].z, xn[rt][s][0].w,
-                                            xn[rt][s][1].x, xn[rt][s][1].y, xn[rt][s][1].z, xn[rt][s][1].w};
+                        float v[8] = {xn[rt][s][0].x, xn[rt][s][0].y, xn[rt][s][0].z, xn[rt][s][0].w,
+                                      xn[rt][s][1].x, xn[rt][s][1].y, xn[rt][s][1].z, xn[rt][s][1].w};
                         split8(v, xs[0], xs[1], xs[2]);
                     } else {
                         xs[0] = xb[FLY ? 0 : rt][FLY ? 0 : s][0]; xs[1] = xb[FLY ? 0 : rt][FLY ? 0 : s][1];
@@ -215,6 +214,7 @@ __global__ __launch_bounds__(THREADS, 2) void ws_linear_split_kernel(
                 if (FLY && (s & 1)) __builtin_amdgcn_sched_barrier(0);   // keep the weight reads of later steps from piling up
             }
             // lane (r, kq) holds out[m][n0 + 4 kq .. + 3] of every column tile: 16-B stores
+            const GeluK gk = gelu_k();      // materialised here: ten registers the MFMA loop does not carry
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
                 const long m = (t * RT + rt) * 16 + r;
@@ -250,10 +250,16 @@ int num_cus() {
     return 256;
 }
 
-// columns of W per workgroup: even ranges, multiples of 16, whose three planes (+ bias) fit the LDS; 0 if impossible
+// columns of W per workgroup: even ranges, multiples of 16, whose three planes (+ bias) fit the LDS; 0 if impossible.
+// K > 192 (rows split step by step): a range is ONE group of 3, 2 or 1 column tiles.
 int split_columns(int N, int K) {
     const int nc_max = ((LDS_BYTES - 8 * K) / (6 * K + 4)) & ~15;          // 8 K bytes: gamma / beta
     if (nc_max <= 0) return 0;
+    if (K > 192) {
+        for (int nc = 48; nc >= 16; nc -= 16)
+            if (nc <= nc_max && N % nc == 0) return nc;
+        return 0;
+    }
     for (int nsplit = (N + nc_max - 1) / nc_max; nsplit <= N / 16; ++nsplit)
         if ((N / 16) % nsplit == 0) return N / nsplit;
     return 0;
@@ -263,7 +269,7 @@ template <int K, int ACT, bool HAS_LN, bool HAS_RES, int CT>
 int launch_ct(const float* x, const float* gamma, const float* beta, float eps, const float* w, const float* bias,
               const float* res, float* out, long M, int N, hipStream_t st) {
     constexpr int RT = K <= 96 ? 2 : 1;
-    constexpr bool FLY = K > 128;
+    constexpr bool FLY = K > 192;
     if (FLY && (HAS_LN || split_columns(N, K) / 16 != CT)) return SOC_EUNSUPPORTED;     // K13 takes those
     const void* fn = reinterpret_cast<const void*>(ws_linear_split_kernel<K, ACT, HAS_LN, HAS_RES, CT, RT, FLY>);
     static std::atomic<bool> attr_set[SOC_MAX_DEVICES];
@@ -300,7 +306,7 @@ template <int K, int ACT>
 int launch_k(const float* x, const float* gamma, const float* beta, float eps, const float* w, const float* bias,
              const float* res, float* out, long M, int N, hipStream_t st) {
     if (gamma) {
-        if constexpr (K > 128) {
+        if constexpr (K > 192) {          // the step-by-step form (K > 192) has no LayerNorm: K13 / the library take those
             return SOC_EUNSUPPORTED;
         } else {
             if (res) return launch_one<K, ACT, true, true>(x, gamma, beta, eps, w, bias, res, out, M, N, st);
@@ -330,6 +336,7 @@ int soc_ws_linear_split_dispatch(const float* x, const float* ln_gamma, const fl
     switch (K) {
         case 96: return launch_act<96>(act, x, ln_gamma, ln_beta, ln_eps, w, bias, residual, out, M, N, st);
         case 128: return launch_act<128>(act, x, ln_gamma, ln_beta, ln_eps, w, bias, residual, out, M, N, st);
+        case 192: return launch_act<192>(act, x, ln_gamma, ln_beta, ln_eps, w, bias, residual, out, M, N, st);
         case 384: return launch_act<384>(act, x, ln_gamma, ln_beta, ln_eps, w, bias, residual, out, M, N, st);
         case 512: return launch_act<512>(act, x, ln_gamma, ln_beta, ln_eps, w, bias, residual, out, M, N, st);
         default: return SOC_EUNSUPPORTED;

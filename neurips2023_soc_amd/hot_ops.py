@@ -794,6 +794,11 @@ def linear_act_multi(x: Tensor, layers: Sequence[Tuple[Tensor, Optional[Tensor]]
 
 
 WS_LINEAR_K = (96, 128, 192, 256, 384, 512)
+WS_SPLIT_LN_K = (96, 128, 192)      # widths K13b (bf16 matrix cores) covers with a LayerNorm in front; 384 / 512 without
+
+
+def k13_split_enabled() -> bool:
+    return split_enabled() and "k13" not in _SPLIT_OFF
 
 
 def ws_linear_supported(x: Tensor, weight: Tensor, has_ln: bool) -> bool:
@@ -824,7 +829,7 @@ def ws_linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, ln: Opti
     b = _f32c(bias) if bias is not None else None
     code = {"none": 0, "relu": 1, "gelu": 2}[act]
     work = 2.0 * M * N * K
-    lib.soc_ws_linear_set_split(int(split_enabled() and "k13" not in _SPLIT_OFF))      # K13b for K = 96 / 128
+    lib.soc_ws_linear_set_split(int(k13_split_enabled()))          # K13b where it covers the width
     with _timed("ws_linear", work):
         rc = lib.soc_ws_linear_f32(x.data_ptr(), g.data_ptr() if g is not None else None,
                                    be.data_ptr() if be is not None else None, eps, weight.data_ptr(),

@@ -106,7 +106,10 @@ class BasicLayer(nn.Module):
         with the LayerNorm that consumes its result (K5): x += attn -> norm2, x += mlp -> next block's norm1.  Same
         values as block-by-block."""
         blocks = self.blocks
-        if self._split_flow(x):
+        # stage 1 (C = 192) in the split arithmetic: K13b beats K20 on qkv / proj / fc1 (49 / 24 / 71 against 60 / 30 / 74 us,
+        # tools/experiments/k13b_time.py); with SOC_SPLIT_OFF=k13 the K20 flow below takes it
+        prefer_ws = hot_ops.k13_split_enabled() and x.shape[-1] in hot_ops.WS_SPLIT_LN_K and self._weight_stationary(x)
+        if not prefer_ws and self._split_flow(x):
             # K20 (bf16 matrix cores, exact three-way split): LayerNorm folded into the layer, GELU / residual in its
             # epilogue -- norm1 + qkv | K1 | proj + residual | norm2 + fc1 + GELU | fc2 + residual
             for blk in blocks:

@@ -78,6 +78,12 @@ def test_full_config_matches_reference(gpu_model, golden):
     assert maxdiff(out["pred_logit"], g["pred_logit"]) < 1e-4
 
 
+def _lib_split_state():
+    from neurips2023_soc_amd import _lib
+    lib = _lib.load()
+    return lib.soc_win_attn3d_get_split(), lib.soc_ws_linear_get_split()
+
+
 def test_full_config_f32_mfma_mode_matches_reference_and_split_mode(gpu_model, golden):
     """SOC_MATMUL=f32 (hot_ops.MATMUL_MODE): every product on the f32-input MFMA, no bf16 matrix-core kernel launched; the
     default split mode launches K20 and the split K1.  Both meet the reference, and differ from each other by f32 noise."""
@@ -87,6 +93,7 @@ def test_full_config_f32_mfma_mode_matches_reference_and_split_mode(gpu_model, g
     hot_ops.profile_begin()
     out_split = run_cfg(gpu_model, g["cfg"])
     prof_split = hot_ops.profile_end()
+    assert _lib_split_state() == (1, 1)                         # K1 and K13 launched in their bf16-matrix-core forms
     hot_ops.MATMUL_MODE = "f32"
     try:
         hot_ops.profile_begin()
@@ -94,9 +101,8 @@ def test_full_config_f32_mfma_mode_matches_reference_and_split_mode(gpu_model, g
         prof_f32 = hot_ops.profile_end()
     finally:
         hot_ops.MATMUL_MODE = "split"
-    assert prof_split.get("linear_split", {}).get("launches", 0) >= 20 and "linear_split" not in prof_f32
-    from neurips2023_soc_amd import _lib
-    assert _lib.load().soc_win_attn3d_get_split() == 0          # the last K1 launch ran in f32 mode
+    assert prof_split.get("linear_split", {}).get("launches", 0) >= 12 and "linear_split" not in prof_f32
+    assert _lib_split_state() == (0, 0)                         # the last K1 / K13 launches ran in f32 mode
     for out in (out_split, out_f32):
         idx, masks = P.select_trajectory(out)
         assert int(idx) == int(g["selected_query"])
@@ -106,8 +112,8 @@ def test_full_config_f32_mfma_mode_matches_reference_and_split_mode(gpu_model, g
     d = maxdiff(out_split["pred_masks"], out_f32["pred_masks"].cpu())
     print("split vs f32 MFMA: max|dlogit|", d)
     assert d < 5e-4
-    run_cfg(gpu_model, golden("tiny_forward.npz")["cfg"])       # leaves the library switch back on "split"
-    assert _lib.load().soc_win_attn3d_get_split() == 1
+    run_cfg(gpu_model, g["cfg"])                                # leaves the library switches back on "split"
+    assert _lib_split_state() == (1, 1)
 
 
 @pytest.fixture(scope="module")

@@ -2,7 +2,7 @@ import sys, torch
 sys.path.insert(0, ".")
 from neurips2023_soc_amd import hot_ops
 g = torch.Generator().manual_seed(0)
-M = 115200
+M0 = 115200
 def t(fn, reps=30):
     for _ in range(3): fn()
     torch.cuda.synchronize(); torch.cuda._sleep(20_000_000)
@@ -11,16 +11,23 @@ def t(fn, reps=30):
     for _ in range(reps): fn()
     e.record(); torch.cuda.synchronize()
     return 1e3 * s.elapsed_time(e) / reps
-for name, K, N, ln, res, act in [("qkv", 96, 288, True, False, "none"), ("proj", 96, 96, False, True, "none"),
-                                 ("fc1", 96, 384, True, False, "gelu"), ("fc2", 384, 96, False, True, "none"),
-                                 ("qkvB", 128, 384, True, False, "none"), ("fc1B", 128, 512, True, False, "gelu")]:
+for name, M, K, N, ln, res, act in [("qkv", M0, 96, 288, True, False, "none"), ("proj", M0, 96, 96, False, True, "none"),
+                                    ("fc1", M0, 96, 384, True, False, "gelu"), ("fc2", M0, 384, 96, False, True, "none"),
+                                    ("qkvB", M0, 128, 384, True, False, "none"), ("fc1B", M0, 128, 512, True, False, "gelu"),
+                                    ("s1.qkv", 28800, 192, 576, True, False, "none"), ("s1.proj", 28800, 192, 192, False, True, "none"),
+                                    ("s1.fc1", 28800, 192, 768, True, False, "gelu"),
+                                    ("s2.qkv", 7360, 384, 1152, True, False, "none"), ("s2.proj", 7360, 384, 384, False, True, "none"),
+                                    ("s2.fc1", 7360, 384, 1536, True, False, "gelu")]:
     x = torch.randn(M, K, generator=g).cuda(); w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda(); b = torch.randn(N, generator=g).cuda()
     lnp = ((torch.rand(K, generator=g) + 0.5).cuda(), torch.randn(K, generator=g).cuda() * 0.1, 1e-5) if ln else None
     r = torch.randn(M, N, generator=g).cuda() if res else None
     out = {}
     for mode in ("split", "f32"):
         hot_ops.MATMUL_MODE = mode
-        out[mode] = t(lambda: hot_ops.ws_linear(x, w, b, lnp, r, act))
+        try:
+            out[mode] = t(lambda: hot_ops.ws_linear(x, w, b, lnp, r, act))
+        except Exception:                      # the f32 form has no LayerNorm at K = 384
+            out[mode] = float("nan")
     hot_ops.MATMUL_MODE = "split"
     fl = 2.0 * M * N * K
     print(f"{name:5s} {M}x{N}x{K}: K13b {out['split']:.1f} us ({fl / out['split'] / 1e6:.1f} TFLOP/s)   K13 {out['f32']:.1f} us ({fl / out['f32'] / 1e6:.1f})")
