@@ -9,10 +9,10 @@ import json
 import sys
 
 GROUPS = collections.OrderedDict([
-    ("win_attn3d", ("win_attn3d",)), ("linear_split", ("linear_split_kernel",)), ("row_stats", ("row_stats_kernel",)),
+    ("win_attn3d", ("win_attn3d",)), ("linear_split", ("::linear_split_kernel",)), ("row_stats", ("row_stats_kernel",)),
     ("msda_fwd", ("msda_fwd", "msda_fused")), ("xattn", ("xattn_",)), ("dyn_mask", ("dyn_mask",)),
     ("add_layernorm", ("add_layernorm",)), ("linear_small", ("linear_small",)), ("linear_act", ("gemm_nt_kernel",)),
-    ("groupnorm_tokens", ("gn_stats", "gn_apply")), ("patch_merge_layernorm", ("patch_merge",)), ("ws_linear", ("ws_linear_kernel",)),
+    ("groupnorm_tokens", ("gn_stats", "gn_apply")), ("patch_merge_layernorm", ("patch_merge",)), ("patch_embed_layernorm", ("patch_embed_ln",)), ("ws_linear", ("ws_linear_kernel", "ws_linear_split_kernel")),
     ("box_refine", ("box_refine",)), ("decoder_cross_attn", ("dec_cross_attn_kernel",)), ("row_mlp", ("row_mlp_kernel",)),
     ("fpn_elementwise", ("groupnorm_nchw_kernel", "upsample_add_nchw_kernel", "upsample_add_tokens_kernel")),
     ("conv3x3_tokens", ("conv3x3_tokens_kernel",)),
