@@ -328,8 +328,8 @@ int launch_act(int act, const float* x, const float* gamma, const float* beta, f
 }  // namespace
 
 // K13b entry used by soc_ws_linear_f32 when the split arithmetic is switched on and the width is covered here
-// (K = 96 / 128: the stage-0 widths of Swin-T / -S and Swin-B, and their fc2 layers with K = 384 / 512 when a column range
-// is one group of column tiles); SOC_EUNSUPPORTED sends the caller back to K13.
+// (K = 96 / 128 / 192 with or without a LayerNorm in front: stages 0-1; K = 384 / 512 without one: the stage-0 fc2 layers and
+// the stage-2 qkv / proj / fc1 layers behind K5's LayerNorm); SOC_EUNSUPPORTED sends the caller back to K13.
 int soc_ws_linear_split_dispatch(const float* x, const float* ln_gamma, const float* ln_beta, float ln_eps, const float* w,
                                  const float* bias, const float* residual, float* out, long M, int N, int K, int act,
                                  hipStream_t st) {

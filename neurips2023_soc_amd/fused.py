@@ -23,6 +23,15 @@ def is_small(x: torch.Tensor) -> bool:
             and x.numel() // K <= hot_ops.SMALL_LINEAR_MAX_ROWS)
 
 
+def ws_dense_ok(x: torch.Tensor, weight: torch.Tensor) -> bool:
+    """K13b's step-by-step form (K = 384 / 512, no LayerNorm in front) for a plain linear layer on a pixel-sized, already
+    normalised input: Video-Swin stage 2 qkv / proj / fc1 (53 / 26 / 71 us against the library's 74 / 30 and K20's 75-80,
+    tools/experiments/k13b_time.py)."""
+    K = x.shape[-1]
+    return (x.is_cuda and x.dtype == torch.float32 and K in (384, 512) and hot_ops.k13_split_enabled()
+            and x.numel() // K >= 4096 and hot_ops.ws_linear_supported(x, weight, False))
+
+
 def _split_ok(x: torch.Tensor, weight: torch.Tensor, fused_passes: int, site: str = "plain") -> bool:
     K = x.shape[-1]
     return (x.is_cuda and x.dtype == torch.float32 and hot_ops.linear_split_supported(x, weight)
@@ -113,6 +122,8 @@ def linear_gelu(x: torch.Tensor, lin: nn.Linear) -> torch.Tensor:
     faster than K12 by more than the separate GELU pass costs (tools/gemm_probe.py) and is kept."""
     K = x.shape[-1]
     rows = x.numel() // K
+    if ws_dense_ok(x, lin.weight):
+        return hot_ops.ws_linear(x, lin.weight, lin.bias, act="gelu")           # K13b, GELU on the accumulators
     if _split_ok(x, lin.weight, 1, "gelu"):
         return hot_ops.linear_split(x, lin.weight, lin.bias, act="gelu")      # K20: GELU on the accumulators
     if (x.is_cuda and x.dtype == torch.float32 and rows >= 16384 and K <= 256 and K % 16 == 0

@@ -57,9 +57,12 @@ class WindowAttention3D(nn.Module):
 
     def forward(self, x: torch.Tensor, shift: Sequence[int]) -> torch.Tensor:
         """x [B,D,H,W,C] (after norm1, un-padded) -> attention branch output [B,D,H,W,C]."""
-        qkv = self.qkv(x)
+        ws = fused.ws_dense_ok(x, self.qkv.weight)              # stage 2: K13b instead of the library GEMMs
+        qkv = hot_ops.ws_linear(x, self.qkv.weight, self.qkv.bias) if ws else self.qkv(x)
         attn = hot_ops.window_attention3d(qkv, self.qkv.bias, self.relative_position_bias_table,
                                           self.num_heads, self.window_size, shift)
+        if ws and fused.ws_dense_ok(attn, self.proj.weight):
+            return hot_ops.ws_linear(attn, self.proj.weight, self.proj.bias)
         return self.proj(attn)
 
 

@@ -16,8 +16,11 @@ for name, M, K, N, ln, res, act in [("qkv", M0, 96, 288, True, False, "none"), (
                                     ("qkvB", M0, 128, 384, True, False, "none"), ("fc1B", M0, 128, 512, True, False, "gelu"),
                                     ("s1.qkv", 28800, 192, 576, True, False, "none"), ("s1.proj", 28800, 192, 192, False, True, "none"),
                                     ("s1.fc1", 28800, 192, 768, True, False, "gelu"),
-                                    ("s2.qkv", 7360, 384, 1152, True, False, "none"), ("s2.proj", 7360, 384, 384, False, True, "none"),
-                                    ("s2.fc1", 7360, 384, 1536, True, False, "gelu")]:
+                                    ("s2.qkv", 7360, 384, 1152, False, False, "none"), ("s2.proj", 7360, 384, 384, False, True, "none"),
+                                    ("s2.fc1", 7360, 384, 1536, False, False, "gelu"),
+                                    ("enc.value", 38560, 256, 256, False, False, "none"), ("enc.out", 38560, 256, 256, False, True, "none"),
+                                    ("enc.offw", 38560, 256, 384, False, False, "none"), ("enc.ffn1", 38560, 256, 2048, False, False, "relu"),
+                                    ("vlf.q", 28800, 256, 256, False, False, "none")]:
     x = torch.randn(M, K, generator=g).cuda(); w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda(); b = torch.randn(N, generator=g).cuda()
     lnp = ((torch.rand(K, generator=g) + 0.5).cuda(), torch.randn(K, generator=g).cuda() * 0.1, 1e-5) if ln else None
     r = torch.randn(M, N, generator=g).cuda() if res else None
