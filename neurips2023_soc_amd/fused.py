@@ -32,6 +32,15 @@ def ws_dense_ok(x: torch.Tensor, weight: torch.Tensor) -> bool:
             and x.numel() // K >= 4096 and hot_ops.ws_linear_supported(x, weight, False))
 
 
+def ws_plain_ok(x: torch.Tensor, weight: torch.Tensor) -> bool:
+    """K13b for a linear layer without a LayerNorm in front: the K = 384 / 512 form above, or the K = 96 / 128 / 192 form on
+    a tall input (patch-merging reductions, input_proj of the finer levels)."""
+    K = x.shape[-1]
+    return ws_dense_ok(x, weight) or (
+        x.is_cuda and x.dtype == torch.float32 and K in hot_ops.WS_SPLIT_LN_K and hot_ops.k13_split_enabled()
+        and x.numel() // K >= 16384 and hot_ops.ws_linear_supported(x, weight, False))
+
+
 def _split_ok(x: torch.Tensor, weight: torch.Tensor, fused_passes: int, site: str = "plain") -> bool:
     K = x.shape[-1]
     return (x.is_cuda and x.dtype == torch.float32 and hot_ops.linear_split_supported(x, weight)
@@ -50,6 +59,8 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
         if mul is not None:
             y = y * mul
         return y if residual is None else y + residual
+    if add is None and mul is None and ws_plain_ok(x, weight):
+        return hot_ops.ws_linear(x, weight, bias, None, residual, "relu" if relu else "none")       # K13b
     n_fused = int(add is not None) + int(relu) + int(mul is not None) + int(residual is not None)
     site = "relu" if relu else ("mul" if mul is not None else ("res" if residual is not None else ("add" if add is not None else "plain")))
     if _split_ok(x, weight, n_fused, site) and (add is None or add.shape == x.shape):

@@ -187,7 +187,10 @@ class PatchMerging(nn.Module):
         self.norm = nn.LayerNorm(4 * dim)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        return self.reduction(hot_ops.patch_merge_layernorm(x, self.norm.weight, self.norm.bias, self.norm.eps))
+        h = hot_ops.patch_merge_layernorm(x, self.norm.weight, self.norm.bias, self.norm.eps)
+        if fused.ws_plain_ok(h, self.reduction.weight):          # K = 384 / 512 reductions: K13b (stage 0 -> 1)
+            return hot_ops.ws_linear(h, self.reduction.weight, None)
+        return self.reduction(h)
 
     def forward_unfused(self, x: torch.Tensor) -> torch.Tensor:
         """The reference's sequence of ops (pad, four strided slices, cat, norm, reduction)."""
