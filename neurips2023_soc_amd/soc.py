@@ -192,7 +192,7 @@ class SOC(nn.Module):
         tok = src.permute(0, 2, 3, 1)                              # a view of the backbone's native layout
         if not (src.is_cuda and tok.is_contiguous() and conv.kernel_size == (1, 1)):
             return self._seq(self.input_proj[l](src), B, T)
-        y = F.linear(tok.reshape(n, h * w, cin), conv.weight.view(conv.out_channels, cin), conv.bias)
+        y = fused.linear(tok.reshape(n, h * w, cin), conv.weight.view(conv.out_channels, cin), conv.bias)   # K13b / K20 / library
         y = hot_ops.groupnorm_tokens(y, gn.weight, gn.bias, gn.num_groups, gn.eps)    # '(b t) (h w) c'
         c = y.shape[-1]
         return y.view(B, T, h * w, c).permute(1, 2, 0, 3).reshape(T * h * w, B, c)  # a view for B = 1
