@@ -317,6 +317,37 @@ def main():
                                "tflops": round(2.0 * Mm * Nn * Kk / us / 1e6, 1)})
     del k20_calls[:]
 
+    # K13 / K13b (weight-stationary linear layers): the same replay
+    hot_ops.record_ws_linear_calls(True)
+    step(0)
+    k13_calls = hot_ops.record_ws_linear_calls(False)
+    torch.cuda.synchronize()
+    k13_ms_per_forward, k13_flop, k13_shapes = 0.0, 0.0, []
+    if k13_calls:
+        def replay13(calls, reps):
+            torch.cuda._sleep(40_000_000)
+            s_ev, e_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s_ev.record()
+            for _ in range(reps):
+                for c in calls:
+                    hot_ops.ws_linear(**c)
+            e_ev.record()
+            torch.cuda.synchronize()
+            return s_ev.elapsed_time(e_ev) / reps
+        replay13(k13_calls, 3)
+        k13_ms_per_forward = replay13(k13_calls, K1_REPS)
+        seen13 = {}
+        for c in k13_calls:
+            Nn, Kk = c["weight"].shape
+            Mm = c["x"].numel() // Kk
+            k13_flop += 2.0 * Mm * Nn * Kk
+            seen13.setdefault((Mm, Nn, Kk, c["ln"] is not None, c["act"], c["residual"] is not None), []).append(c)
+        for (Mm, Nn, Kk, has_ln, act_, has_res), cs in seen13.items():
+            us = 1e3 * replay13(cs[:1], K1_REPS)
+            k13_shapes.append({"M": Mm, "N": Nn, "K": Kk, "ln": has_ln, "act": act_, "residual": has_res,
+                               "launches": len(cs), "us": round(us, 1), "tflops": round(2.0 * Mm * Nn * Kk / us / 1e6, 1)})
+    del k13_calls[:]
+
     assert gathered.shape[0] == world == a.gpus and timed["ranks_seen"] == list(range(world)), timed["ranks_seen"]
 
     if rank == 0:
@@ -407,6 +438,30 @@ def main():
                             "algorithmic FLOPs = sum of 2 M N K",
                 "per_launch_event_pairs_ms_per_clip": k20["ms"] / a.steps,
                 "source": "profiles/r03_bench_kernel_stats.csv rows linear_split_kernel<...>: TotalDurationNs / clips"}
+        k13 = prof.get("ws_linear")
+        if k13 and k13_ms_per_forward > 0:
+            ach = k13_flop / (k13_ms_per_forward * 1e-3) / 1e12
+            n13 = sum(sh["launches"] for sh in k13_shapes)
+            split13 = hot_ops.k13_split_enabled()
+            blocks["ws_linear"] = {
+                "kernel": f"soc_ws_linear_f32 (all {n13} launches of a forward; K13b on the bf16 matrix cores where it covers "
+                          "the width)" if split13 else f"soc_ws_linear_f32 (all {n13} launches of a forward, f32 MFMA)",
+                "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": ach / PEAK_F32_MFMA_TFLOPS,
+                "traffic": traffic.get("ws_linear") if default_cfg else None,
+                "traffic_unit": f"HBM bytes per clip ({n13} launches), rocprofv3 PMC, {traffic_file}",
+                "algorithmic_flop_per_clip": k13_flop, "avg_launch_us": 1e3 * k13_ms_per_forward / max(n13, 1),
+                "ms_per_clip": k13_ms_per_forward, "per_shape": k13_shapes,
+                "measured": f"HIP events on the launch stream around {K1_REPS} back-to-back replays of the K13 launches of one "
+                            "forward (the forward's own activations and weights), right after the timed region; algorithmic "
+                            "FLOPs = sum of 2 M N K.  The stage-0 layers (K = 96) sit on the HBM side of their roofline "
+                            "(177-221 MB per launch), the wider ones on the matrix-core side",
+                "per_launch_event_pairs_ms_per_clip": k13["ms"] / a.steps,
+                "source": "profiles/r03_bench_kernel_stats.csv rows ws_linear_split_kernel<...> (+ ws_linear_kernel<...>): "
+                          "TotalDurationNs / clips"}
+            if split13:
+                blocks["ws_linear"].update(arithmetic=issued, bf16_issued_tflops=6.0 * ach, bf16_peak=PEAK_BF16_MFMA_TFLOPS,
+                                           bf16_frac=6.0 * ach / PEAK_BF16_MFMA_TFLOPS)
         if blocks:      # the roofline object is the kernel with the largest share of a clip; the other one follows
             order = sorted(blocks, key=lambda n: -blocks[n]["ms_per_clip"])
             line["roofline"] = blocks[order[0]]

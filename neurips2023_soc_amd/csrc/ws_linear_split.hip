@@ -65,7 +65,7 @@ __device__ __forceinline__ void split8(const float (&v)[8], bf16x8& h0, bf16x8& 
     }
 }
 
-// FLY (K > 192, no LayerNorm, one column group per row group): the rows are split step by step inside the MFMA loop instead
+// FLY (K > 256, no LayerNorm, one column group per row group): the rows are split step by step inside the MFMA loop instead
 // of up front -- K / 32 x 12 VGPRs of split operands would not fit beside the K / 4 raw words of a K = 384 / 512 row
 template <int K, int ACT, bool HAS_LN, bool HAS_RES, int CT, int RT, bool FLY>
 __global__ __launch_bounds__(THREADS, 2) void ws_linear_split_kernel(
@@ -251,11 +251,11 @@ int num_cus() {
 }
 
 // columns of W per workgroup: even ranges, multiples of 16, whose three planes (+ bias) fit the LDS; 0 if impossible.
-// K > 192 (rows split step by step): a range is ONE group of 3, 2 or 1 column tiles.
+// K > 256 (rows split step by step): a range is ONE group of 3, 2 or 1 column tiles.
 int split_columns(int N, int K) {
     const int nc_max = ((LDS_BYTES - 8 * K) / (6 * K + 4)) & ~15;          // 8 K bytes: gamma / beta
     if (nc_max <= 0) return 0;
-    if (K > 192) {
+    if (K > 256) {
         for (int nc = 48; nc >= 16; nc -= 16)
             if (nc <= nc_max && N % nc == 0) return nc;
         return 0;
@@ -269,7 +269,7 @@ template <int K, int ACT, bool HAS_LN, bool HAS_RES, int CT>
 int launch_ct(const float* x, const float* gamma, const float* beta, float eps, const float* w, const float* bias,
               const float* res, float* out, long M, int N, hipStream_t st) {
     constexpr int RT = K <= 96 ? 2 : 1;
-    constexpr bool FLY = K > 192;
+    constexpr bool FLY = K > 256;
     if (FLY && (HAS_LN || split_columns(N, K) / 16 != CT)) return SOC_EUNSUPPORTED;     // K13 takes those
     const void* fn = reinterpret_cast<const void*>(ws_linear_split_kernel<K, ACT, HAS_LN, HAS_RES, CT, RT, FLY>);
     static std::atomic<bool> attr_set[SOC_MAX_DEVICES];
@@ -306,7 +306,7 @@ template <int K, int ACT>
 int launch_k(const float* x, const float* gamma, const float* beta, float eps, const float* w, const float* bias,
              const float* res, float* out, long M, int N, hipStream_t st) {
     if (gamma) {
-        if constexpr (K > 192) {          // the step-by-step form (K > 192) has no LayerNorm: K13 / the library take those
+        if constexpr (K > 192) {          // no LayerNorm beyond K = 192 (K = 256: registers; K > 256: step-by-step form)
             return SOC_EUNSUPPORTED;
         } else {
             if (res) return launch_one<K, ACT, true, true>(x, gamma, beta, eps, w, bias, res, out, M, N, st);
@@ -328,7 +328,7 @@ int launch_act(int act, const float* x, const float* gamma, const float* beta, f
 }  // namespace
 
 // K13b entry used by soc_ws_linear_f32 when the split arithmetic is switched on and the width is covered here
-// (K = 96 / 128 / 192 with or without a LayerNorm in front: stages 0-1; K = 384 / 512 without one: the stage-0 fc2 layers and
+// (K = 96 / 128 / 192 with or without a LayerNorm in front: stages 0-1; K = 256 / 384 / 512 without one: the encoder's value_proj, the stage-0 fc2 layers and
 // the stage-2 qkv / proj / fc1 layers behind K5's LayerNorm); SOC_EUNSUPPORTED sends the caller back to K13.
 int soc_ws_linear_split_dispatch(const float* x, const float* ln_gamma, const float* ln_beta, float ln_eps, const float* w,
                                  const float* bias, const float* residual, float* out, long M, int N, int K, int act,
@@ -337,6 +337,7 @@ int soc_ws_linear_split_dispatch(const float* x, const float* ln_gamma, const fl
         case 96: return launch_act<96>(act, x, ln_gamma, ln_beta, ln_eps, w, bias, residual, out, M, N, st);
         case 128: return launch_act<128>(act, x, ln_gamma, ln_beta, ln_eps, w, bias, residual, out, M, N, st);
         case 192: return launch_act<192>(act, x, ln_gamma, ln_beta, ln_eps, w, bias, residual, out, M, N, st);
+        case 256: return launch_act<256>(act, x, ln_gamma, ln_beta, ln_eps, w, bias, residual, out, M, N, st);
         case 384: return launch_act<384>(act, x, ln_gamma, ln_beta, ln_eps, w, bias, residual, out, M, N, st);
         case 512: return launch_act<512>(act, x, ln_gamma, ln_beta, ln_eps, w, bias, residual, out, M, N, st);
         default: return SOC_EUNSUPPORTED;

@@ -37,7 +37,7 @@ def ws_plain_ok(x: torch.Tensor, weight: torch.Tensor) -> bool:
     a tall input (patch-merging reductions, input_proj of the finer levels)."""
     K = x.shape[-1]
     return ws_dense_ok(x, weight) or (
-        x.is_cuda and x.dtype == torch.float32 and K in hot_ops.WS_SPLIT_LN_K and hot_ops.k13_split_enabled()
+        x.is_cuda and x.dtype == torch.float32 and K in (96, 128, 192, 256) and hot_ops.k13_split_enabled()
         and x.numel() // K >= 16384 and hot_ops.ws_linear_supported(x, weight, False))
 
 

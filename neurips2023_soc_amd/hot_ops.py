@@ -49,6 +49,19 @@ def record_linear_split_calls(on: bool):
     return calls
 
 
+_k13_calls = None  # bench.py: when a list, ws_linear appends its arguments
+
+
+def record_ws_linear_calls(on: bool):
+    """As record_linear_split_calls, for K13 / K13b: the recorded dicts are keyword arguments of ws_linear."""
+    global _k13_calls
+    if on:
+        _k13_calls = []
+        return None
+    calls, _k13_calls = _k13_calls, None
+    return calls
+
+
 def profile_begin() -> None:
     global _prof
     _prof = {}
@@ -830,6 +843,8 @@ def ws_linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, ln: Opti
     code = {"none": 0, "relu": 1, "gelu": 2}[act]
     work = 2.0 * M * N * K
     lib.soc_ws_linear_set_split(int(k13_split_enabled()))          # K13b where it covers the width
+    if _k13_calls is not None:
+        _k13_calls.append(dict(x=x, weight=weight, bias=bias, ln=ln, residual=residual, act=act))
     with _timed("ws_linear", work):
         rc = lib.soc_ws_linear_f32(x.data_ptr(), g.data_ptr() if g is not None else None,
                                    be.data_ptr() if be is not None else None, eps, weight.data_ptr(),

@@ -49,9 +49,11 @@ def test_committed_bench_line_keeps_the_driver_contract():
     r = line["roofline"]
     assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["traffic"] is not None
-    # the roofline object is the kernel with the largest share of a clip, the other MFMA kernel follows in the same form
-    other = line["roofline_win_attn3d"]
-    assert r["ms_per_clip"] >= other["ms_per_clip"] and abs(other["frac"] - other["achieved"] / other["peak"]) < 1e-9
+    # the roofline object is the kernel with the largest share of a clip, the other MFMA kernels follow in the same form
+    others = [line[k] for k in line if k.startswith("roofline_") and k != "roofline_other"]
+    assert others and all(r["ms_per_clip"] >= o["ms_per_clip"] for o in others)
+    assert all(abs(o["frac"] - o["achieved"] / o["peak"]) < 1e-9 for o in others)
+    assert any("win_attn3d" in o["kernel"] for o in others + [r])
     c = line["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["unit"] == "clips/s" and c["cores"] >= 1 and c["sample"]
     assert c["value"] > 0 and line["value"] / c["value"] > 100

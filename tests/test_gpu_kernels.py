@@ -942,6 +942,7 @@ def test_ws_linear_vs_torch(ops, M, K, N, ln, res, act, bias):
     (115200, 384, 96, False, True, "none"), (30011, 512, 128, False, True, "none"), (4099, 384, 48, False, False, "gelu"),
     (28800, 192, 576, True, False, "none"), (28800, 192, 192, False, True, "none"), (9001, 192, 768, True, False, "gelu"),
     (7360, 384, 384, False, True, "none"), (7360, 384, 1536, False, False, "gelu"),
+    (38560, 256, 256, False, False, "none"), (38560, 256, 256, False, True, "relu"),
 ])
 def test_ws_linear_split_form_is_f32_grade(ops, M, K, N, ln, res, act):
     """K13b (K = 96 / 128 on the bf16 matrix cores, exact three-way split) against the f32-MFMA form of the same entry
