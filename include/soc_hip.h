@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SOC_HIP_ABI_VERSION 9
+#define SOC_HIP_ABI_VERSION 10
 
 #define SOC_OK 0
 #define SOC_EINVAL (-1)       /* null pointer / non-positive dimension */
@@ -234,6 +234,20 @@ int soc_groupnorm_tokens_f32(const float* x, const float* gamma, const float* be
  */
 int soc_patch_merge_layernorm_f32(const float* x, const float* gamma, const float* beta, float* out, int BD,
                                   int H, int W, int C, float eps, void* stream);
+
+/*
+ * K22 -- the deformable encoder's feed-forward block in one launch, on the bf16 matrix cores (exact three-way operand
+ * split, f32-grade results -- see soc_linear_split_f32): out = ReLU(x W1^T + b1) W2^T + b2 (+ residual).  Replaces
+ * linear1 -> activation -> linear2 of DeformableTransformerEncoderLayer.forward_ffn (models/deformable_transformer.py:
+ * 253-263); the [M, F] hidden tensor is never written.
+ *   x [M, C], w1 [F, C], b1 [F], w2 [C, F], b2 [C], residual [M, C] or NULL, out [M, C]; C = 256, F % 32 == 0.
+ *   soc_ffn_split_packed_bytes / soc_ffn_split_pack_f32: split and lay out both weights ONCE (opaque image `packed`);
+ *   re-pack after the weights change.  Every pointer 16-byte aligned.
+ */
+size_t soc_ffn_split_packed_bytes(int C, int F);
+int soc_ffn_split_pack_f32(const float* w1, const float* w2, void* packed, int C, int F, void* stream);
+int soc_ffn_split_f32(const float* x, const void* packed, const float* b1, const float* b2, const float* residual,
+                      float* out, long M, int C, int F, void* stream);
 
 /*
  * K21 -- Video-Swin patch embedding: the (1,4,4) / stride (1,4,4) convolution + LayerNorm(C) in one pass.  Replaces

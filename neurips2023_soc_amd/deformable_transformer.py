@@ -32,7 +32,7 @@ class DeformableTransformerEncoderLayer(nn.Module):
         a, _, _ = self.self_attn(src, reference_points, src, spatial_shapes, level_start_index, padding_mask,
                                  pad_flag=pad_flag, return_sampling=False, query_pos=pos)
         src = _add_norm(src, a, self.norm1)
-        return _add_norm(src, fused.apply(self.linear2, linear_relu(src, self.linear1)), self.norm2)
+        return _add_norm(src, fused.ffn_relu(src, self.linear1, self.linear2), self.norm2)     # K22 + remainder
 
 
 class DeformableTransformerEncoder(nn.Module):

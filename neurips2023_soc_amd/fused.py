@@ -23,6 +23,29 @@ def is_small(x: torch.Tensor) -> bool:
             and x.numel() // K <= hot_ops.SMALL_LINEAR_MAX_ROWS)
 
 
+def ffn_relu(x: torch.Tensor, lin1: nn.Linear, lin2: nn.Linear) -> torch.Tensor:
+    """lin2(relu(lin1(x))) -- the deformable encoder's feed-forward block (reference models/deformable_transformer.py:
+    253-263).  K22 keeps the hidden layer in registers; a launch streams both weight matrices once per 32 768 rows (8 waves
+    x 16 rows on each of the 256 CUs), so whole multiples of that go to K22 and a short remainder (5 792 of the 38 560
+    rows at the BASELINE config: 374 + 120 us instead of 630) to the two-GEMM path."""
+    C = x.shape[-1]
+    rows = x.numel() // C
+    if hot_ops.ffn_split_supported(x, lin1.weight, lin2.weight) and lin1.bias is not None and lin2.bias is not None \
+            and rows >= 4096:
+        unit = 32768
+        full = (rows // unit) * unit
+        if rows - full >= (3 * unit) // 5 or full == 0:
+            full = rows                                   # the last pass is filled well enough (or it is the only one)
+        x2 = x.reshape(rows, C)
+        if full == rows:
+            return hot_ops.ffn_split(x2, lin1.weight, lin1.bias, lin2.weight, lin2.bias).view(x.shape)
+        out = torch.empty_like(x2)
+        out[:full] = hot_ops.ffn_split(x2[:full], lin1.weight, lin1.bias, lin2.weight, lin2.bias)
+        out[full:] = apply(lin2, linear_relu(x2[full:], lin1))
+        return out.view(x.shape)
+    return apply(lin2, linear_relu(x, lin1))
+
+
 def ws_dense_ok(x: torch.Tensor, weight: torch.Tensor) -> bool:
     """K13b's step-by-step form (K = 384 / 512, no LayerNorm in front) for a plain linear layer on a pixel-sized, already
     normalised input: Video-Swin stage 2 qkv / proj / fc1 (53 / 26 / 71 us against the library's 74 / 30 and K20's 75-80,

@@ -1200,3 +1200,33 @@ def test_patch_embed_module_uses_fused_kernel_and_matches_library_path(ops):
         want = torch.nn.functional.layer_norm(f.permute(0, 2, 3, 4, 1), (96,), pe.norm.weight.double().cpu(),
                                               pe.norm.bias.double().cpu(), pe.norm.eps)
     assert got.shape == want.shape and maxdiff(got, want) < 2e-5
+
+
+@pytest.mark.parametrize("M,F", [(38560, 2048), (1000, 512), (17, 64), (4099, 2048)])
+def test_ffn_split_vs_f64(ops, M, F):
+    """K22 (linear1 + ReLU + linear2 in one launch, hidden layer in registers, bf16 matrix cores with the exact split)
+    against f64 and against the f32 library path: f32-grade error, residual epilogue, bit-repeatable, repack on update."""
+    g = torch.Generator().manual_seed(M + F)
+    x = (torch.randn(M, 256, generator=g) * 1.2).cuda()
+    w1 = (torch.randn(F, 256, generator=g) / 16).cuda()
+    b1 = (torch.randn(F, generator=g) * 0.1).cuda()
+    w2 = (torch.randn(256, F, generator=g) / F ** 0.5).cuda()
+    b2 = (torch.randn(256, generator=g) * 0.1).cuda()
+    res = torch.randn(M, 256, generator=g).cuda()
+    assert ops.ffn_split_supported(x, w1, w2)
+    got = ops.ffn_split(x, w1, b1, w2, b2)
+    assert torch.equal(got, ops.ffn_split(x, w1, b1, w2, b2))
+    want = torch.nn.functional.linear(torch.nn.functional.linear(x.double(), w1.double(), b1.double()).relu(), w2.double(),
+                                      b2.double())
+    lib = torch.nn.functional.linear(torch.nn.functional.linear(x, w1, b1).relu(), w2, b2)
+    scale = float(want.abs().max())
+    e_k22, e_lib = float((got.double() - want).abs().max()), float((lib.double() - want).abs().max())
+    print(f"K22 {M}x{F}: split {e_k22 / scale:.2e}  library f32 {e_lib / scale:.2e}")
+    assert e_k22 < 1e-5 * scale and e_k22 <= 1.5 * e_lib + 2e-7 * scale, (e_k22, e_lib)
+    got_r = ops.ffn_split(x, w1, b1, w2, b2, residual=res)
+    assert float((got_r.double() - (want + res.double())).abs().max()) < 1e-5 * max(scale, float(res.abs().max()))
+    w2.mul_(0.5)                                                    # in-place update: the cached image must be rebuilt
+    half = ops.ffn_split(x, w1, b1, w2, b2)
+    want_h = torch.nn.functional.linear(torch.nn.functional.linear(x.double(), w1.double(), b1.double()).relu(), w2.double(),
+                                        b2.double())
+    assert float((half.double() - want_h).abs().max()) < 1e-5 * scale

@@ -91,3 +91,20 @@ def test_k13b_follows_the_same_rules(k13b_asm):
     assert len(counts) == len(bodies) and all(int(v) == 256 for _, v in counts), counts[:3]
     spills = re.findall(r"\.name:\s+_Z\w*ws_linear_split_kernel\w*\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)", k13b_asm)
     assert spills and all(int(v) == 0 for v in spills), spills
+
+
+@pytest.fixture(scope="module")
+def k22_asm(tmp_path_factory):
+    return _asm(tmp_path_factory, "ffn_split.hip")
+
+
+def test_k22_follows_the_same_rules(k22_asm):
+    bodies = list(_kernel_bodies(k22_asm, "ffn_split_kernel"))
+    assert len(bodies) == 1
+    name, body = bodies[0]
+    assert "v_mfma_f32_16x16x32_bf16" in body and "global_load_lds_dwordx4" in body and "s_barrier" in body
+    bad = [ln.strip() for ln in body.splitlines()
+           if re.search(r"\bv_pk_(fma|mul|add)_f32\b", ln) and re.search(r"[ ,]s\[\d+:\d+\]", ln)]
+    assert not bad, bad[:4]
+    counts = re.findall(r"\.name:\s+(_Z\w*ffn_split_kernel\w*)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)", k22_asm)
+    assert counts and all(int(v) == 256 for _, v in counts), counts
