@@ -49,7 +49,9 @@ python3 bench.py --no-cpu-baseline --backbone video-swin-b --height 720 --width 
 python3 tools/k1_probe.py > $P/k1_probe_time.txt 2>&1
 python3 tools/k2_probe.py 50 plain > $P/k2_probe_time.txt 2>&1
 ./tools/experiments/_build/pk_mfma_probe 40 > $P/pk_mfma_probe.txt 2>&1
-python3 tools/experiments/k20_vs_dynmask.py 300 none k20 k20_s0 k1 > $P/k4_beside_kernels.txt 2>&1
+python3 tools/experiments/k20_vs_dynmask.py 300 none k20 k20_s0 k1 k13 > $P/k4_beside_kernels.txt 2>&1
+python3 tools/experiments/k22_time.py > $P/k22_time.txt 2>&1
+python3 tools/experiments/k13b_time.py > $P/k13b_time.txt 2>&1
 SOAK_TRACE=1 python3 tools/experiments/soak_sites.py 6000 2> /dev/null | tail -1 > $P/soak_trace.json
 # keep the merge small
 find $P -name "*kernel_trace.csv" -size +8M -delete
