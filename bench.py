@@ -462,6 +462,20 @@ def main():
             if split13:
                 blocks["ws_linear"].update(arithmetic=issued, bf16_issued_tflops=6.0 * ach, bf16_peak=PEAK_BF16_MFMA_TFLOPS,
                                            bf16_frac=6.0 * ach / PEAK_BF16_MFMA_TFLOPS)
+        k22 = prof.get("ffn_split")
+        if k22 and k22["ms"] > 0:       # launches of ~0.4 ms: per-launch event pairs of the instrumented pass are accurate here
+            ach = k22["work"] / (k22["ms"] * 1e-3) / 1e12
+            blocks["ffn_split"] = {
+                "kernel": f"soc_ffn_split_f32 ({int(k22['launches'] / a.steps)} launches of a forward: linear1 + ReLU + linear2 of "
+                          "the encoder, hidden layer in registers)", "bound": "mfma",
+                "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
+                "traffic": traffic.get("ffn_split") if default_cfg else None,
+                "traffic_unit": f"HBM bytes per clip, rocprofv3 PMC, {traffic_file}",
+                "algorithmic_flop_per_clip": k22["work"] / a.steps, "avg_launch_us": 1e3 * k22["ms"] / k22["launches"],
+                "ms_per_clip": k22["ms"] / a.steps, "arithmetic": issued, "bf16_issued_tflops": 6.0 * ach,
+                "bf16_peak": PEAK_BF16_MFMA_TFLOPS, "bf16_frac": 6.0 * ach / PEAK_BF16_MFMA_TFLOPS,
+                "measured": "HIP-event pairs around each launch in the instrumented eager pass right after the timed region; "
+                            "algorithmic FLOPs = 4 M F C for the rows K22 takes (whole rounds of 32 768 rows)"}
         if blocks:      # the roofline object is the kernel with the largest share of a clip; the other one follows
             order = sorted(blocks, key=lambda n: -blocks[n]["ms_per_clip"])
             line["roofline"] = blocks[order[0]]
