@@ -18,6 +18,14 @@ from . import postprocessing as P
 from .nested_tensor import NestedTensor
 
 
+# Stream-capture error mode.  The drivers decode and upload the NEXT clip on a background thread (clip_io.VideoClipCache)
+# while this thread captures a graph: in HIP's default "global" mode a hipMalloc / hipHostMalloc issued by ANY thread during
+# the capture invalidates it (hipErrorStreamCaptureInvalidated -- seen as a rare failure of the Ref-YouTube-VOS driver test in
+# the first session on a fresh box, when the allocator pools are still cold).  Only this thread's calls matter for the
+# capture, so the check is thread-local.
+CAPTURE_MODE = "thread_local"
+
+
 class ClipGraph:
     def __init__(self, model, T: int, H: int, W: int, L: int, device, warmup: int = 2):
         self.model, self.T, self.H, self.W, self.L = model, T, H, W, L
@@ -40,7 +48,7 @@ class ClipGraph:
                 self._forward()
         torch.cuda.current_stream(self.device).wait_stream(side)
         torch.cuda.synchronize(self.device)
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, capture_error_mode=CAPTURE_MODE):
             self.out = self._forward()
 
     def _forward(self):
@@ -120,7 +128,7 @@ class PipelinedClipGraph:
 
         def capture(body):
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
                 body()
             return g
 
