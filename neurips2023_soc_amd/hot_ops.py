@@ -995,7 +995,9 @@ def ffn_split(x: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor, residua
         packed = torch.empty(lib.soc_ffn_split_packed_bytes(C_, F_), dtype=torch.uint8, device=x.device)
         _lib.check(lib.soc_ffn_split_pack_f32(_f32c(w1).data_ptr(), _f32c(w2).data_ptr(), packed.data_ptr(), C_, F_, _stream()),
                    "soc_ffn_split_pack_f32")
-        ent = (key, packed)
+        if len(_ffn_cache) > 256:
+            _ffn_cache.clear()
+        ent = (key, packed, (w1, w2))                 # the keyed tensors stay alive: their addresses cannot be reused
         _ffn_cache[(w1.data_ptr(), w2.data_ptr())] = ent
     out = torch.empty_like(x)
     if residual is not None:
