@@ -40,7 +40,7 @@ def ffn_relu(x: torch.Tensor, lin1: nn.Linear, lin2: nn.Linear) -> torch.Tensor:
         if full == rows:
             return hot_ops.ffn_split(x2, lin1.weight, lin1.bias, lin2.weight, lin2.bias).view(x.shape)
         out = torch.empty_like(x2)
-        out[:full] = hot_ops.ffn_split(x2[:full], lin1.weight, lin1.bias, lin2.weight, lin2.bias)
+        hot_ops.ffn_split(x2[:full], lin1.weight, lin1.bias, lin2.weight, lin2.bias, out=out[:full])
         out[full:] = apply(lin2, linear_relu(x2[full:], lin1))
         return out.view(x.shape)
     return apply(lin2, linear_relu(x, lin1))

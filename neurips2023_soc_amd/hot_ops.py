@@ -981,7 +981,8 @@ def ffn_split_supported(x: Tensor, w1: Tensor, w2: Tensor) -> bool:
             and w1.dtype == torch.float32 and w2.dtype == torch.float32)
 
 
-def ffn_split(x: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor, residual: Optional[Tensor] = None) -> Tensor:
+def ffn_split(x: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor, residual: Optional[Tensor] = None,
+              out: Optional[Tensor] = None) -> Tensor:
     """K22: ReLU(x @ w1.T + b1) @ w2.T + b2 (+ residual) in one launch, the hidden layer in registers.  The packed weight
     image is cached per (weights, versions) and rebuilt after an in-place update."""
     _need_gpu(x, w1, b1, w2, b2, residual)
@@ -999,7 +1000,10 @@ def ffn_split(x: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor, residua
             _ffn_cache.clear()
         ent = (key, packed, (w1, w2))                 # the keyed tensors stay alive: their addresses cannot be reused
         _ffn_cache[(w1.data_ptr(), w2.data_ptr())] = ent
-    out = torch.empty_like(x)
+    if out is None:
+        out = torch.empty_like(x)
+    elif out.shape != x.shape or out.dtype != torch.float32 or not out.is_contiguous() or out.device != x.device:
+        raise _lib.SocHipError("ffn_split: `out` must be a contiguous float32 tensor of the input's shape on its device")
     if residual is not None:
         residual = _f32c(residual)
         if residual.shape != x.shape:
