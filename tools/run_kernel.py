@@ -1,5 +1,5 @@
 """Launch one hot kernel repeatedly at a BASELINE-config geometry (for rocprofv3 --pmc passes).
-usage: python tools/run_kernel.py {k1s0|k1s1|k1s2|k1s3|msda|vlf|dyn|k20ffn|k20qkv1|k20fc1s2} [reps]
+usage: python tools/run_kernel.py {k1s0|k1s1|k1s2|k1s3|msda|vlf|dyn|k20ffn|k20qkv1|k20fc1s2|k13qkv0|k13fc1s0|k13qkv2|k22} [reps]
 (SOC_MATMUL=f32 in the environment keeps K1 on the f32-input MFMA form: the ablation partner of the default split form)"""
 import sys
 
@@ -45,6 +45,20 @@ elif which.startswith("k20"):
     ln = ((torch.rand(K, generator=g) + 0.5).to(dev), torch.randn(K, generator=g).to(dev), 1e-5) if use_ln else None
     stats = hot_ops.row_stats(x, 1e-5) if use_ln else None
     fn = lambda: hot_ops.linear_split(x, wt, b, ln=ln, act=act, stats=stats)  # noqa: E731
+elif which.startswith("k13"):
+    # K13b at three of its call sites: stage-0 qkv (LayerNorm in front), stage-0 fc1 + GELU, stage-2 qkv (step-by-step form)
+    M, N, K, act, use_ln = {"k13qkv0": (115200, 288, 96, "none", True), "k13fc1s0": (115200, 384, 96, "gelu", True),
+                            "k13qkv2": (7360, 1152, 384, "none", False)}[which]
+    x = torch.randn(M, K, generator=g).to(dev)
+    wt = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
+    b = torch.randn(N, generator=g).to(dev)
+    ln = ((torch.rand(K, generator=g) + 0.5).to(dev), torch.randn(K, generator=g).to(dev), 1e-5) if use_ln else None
+    fn = lambda: hot_ops.ws_linear(x, wt, b, ln, None, act)  # noqa: E731
+elif which == "k22":
+    x = torch.randn(32768, 256, generator=g).to(dev)
+    w1, b1 = (torch.randn(2048, 256, generator=g) / 16).to(dev), torch.randn(2048, generator=g).to(dev)
+    w2, b2 = (torch.randn(256, 2048, generator=g) / 45).to(dev), torch.randn(256, generator=g).to(dev)
+    fn = lambda: hot_ops.ffn_split(x, w1, b1, w2, b2)  # noqa: E731
 elif which.startswith("ln"):
     rows, C = {"ln0": (115200, 96), "ln1": (28800, 192), "lnenc": (38560, 256), "ln2": (7360, 384)}[which]
     x = torch.randn(rows, C, generator=g).to(dev)
