@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SOC_HIP_ABI_VERSION 10
+#define SOC_HIP_ABI_VERSION 11
 
 #define SOC_OK 0
 #define SOC_EINVAL (-1)       /* null pointer / non-positive dimension */
@@ -248,6 +248,38 @@ size_t soc_ffn_split_packed_bytes(int C, int F);
 int soc_ffn_split_pack_f32(const float* w1, const float* w2, void* packed, int C, int F, void* stream);
 int soc_ffn_split_f32(const float* x, const void* packed, const float* b1, const float* b2, const float* residual,
                       float* out, long M, int C, int F, void* stream);
+
+/*
+ * K23 -- a two-layer perceptron block in one launch, on the bf16 matrix cores (exact three-way operand split, f32-grade
+ * results -- see soc_linear_split_f32):
+ *     out = LN2(act(LN(x) W1^T + b1) W2^T + b2 + residual),   act 1 = ReLU, 2 = exact (erf) GELU;  LN, LN2, residual optional.
+ * Replaces  x + mlp(norm2(x))  of SwinTransformerBlock3D.forward_part2 (models/video_swin_transformer.py:262-272 with
+ * Mlp.forward :24-37: norm2, fc1, nn.GELU, fc2, the residual add) and, as K22 does, linear1 -> ReLU -> linear2 of
+ * DeformableTransformerEncoderLayer.forward_ffn (models/deformable_transformer.py:253-263) with the residual add and norm2
+ * behind it (post_gamma / post_beta: `src = norm2(src + dropout3(src2))`, :261-262).  The [M, F] hidden tensor is
+ * never written.  Every row is taken: whole rounds of the chip stream both weight matrices once per 8 (C > 96) or 16
+ * (C <= 96) row tiles of 16 per CU; a short last round, or a short input altogether, is cut over `nfs` hidden ranges whose
+ * partial sums a second kernel adds in a fixed order (deterministic).
+ *   x [M, C], w1 [F, C], b1 [F], w2 [C, F], b2 [C], ln_gamma / ln_beta [C] or both NULL, residual [M, C] or NULL,
+ *   post_gamma / post_beta [C] or both NULL, out [M, C]; C in {96, 128, 192, 256}, F % 32 == 0; every pointer 16-byte aligned.
+ *   soc_mlp_split_packed_bytes / soc_mlp_split_pack_f32: split and lay out both weights ONCE (opaque image `packed`);
+ *   re-pack after the weights change.  soc_mlp_split_workspace_bytes: scratch for the partial sums (0 when none are needed).
+ *   soc_mlp_split_plan: the (workgroup rows, hidden ranges) cut chosen for M rows taken as ONE launch.
+ *   soc_mlp_split_variant_f32: one launch with an explicit cut (workspace: nfs * M * C floats when nfs > 1); `variant` 0 is
+ *   the shipped kernel, other values exist in diagnostic builds only (SOC_K23_VARIANTS) and return SOC_EUNSUPPORTED otherwise.
+ */
+size_t soc_mlp_split_packed_bytes(int C, int F);
+int soc_mlp_split_pack_f32(const float* w1, const float* w2, void* packed, int C, int F, void* stream);
+size_t soc_mlp_split_workspace_bytes(long M, int C, int F);
+int soc_mlp_split_plan(long M, int C, int F, int* nrg, int* nfs);
+int soc_mlp_split_f32(const float* x, const void* packed, const float* b1, const float* b2, const float* ln_gamma,
+                      const float* ln_beta, float ln_eps, const float* residual, const float* post_gamma,
+                      const float* post_beta, float post_eps, float* out, float* workspace, size_t workspace_bytes, long M,
+                      int C, int F, int act, void* stream);
+int soc_mlp_split_variant_f32(const float* x, const void* packed, const float* b1, const float* b2, const float* ln_gamma,
+                              const float* ln_beta, float ln_eps, const float* residual, const float* post_gamma,
+                              const float* post_beta, float post_eps, float* out, float* workspace, long M, int C, int F,
+                              int act, int nrg, int nfs, int variant, void* stream);
 
 /*
  * K21 -- Video-Swin patch embedding: the (1,4,4) / stride (1,4,4) convolution + LayerNorm(C) in one pass.  Replaces

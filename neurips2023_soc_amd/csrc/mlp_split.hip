@@ -1,0 +1,616 @@
+// K23: a two-layer perceptron block in one kernel, on the bf16 matrix cores (exact three-way split) -- the generalisation of
+// K22 (ffn_split.hip) to the widths, activations and LayerNorm prologue of the Video-Swin MLP.
+//
+//   out[M, C] = act(LN(x)[M, C] . W1[F, C]^T + b1) . W2[C, F]^T + b2 (+ residual)                  (f32 in, f32 out)
+//
+// Replaces  x + mlp(norm2(x))  = norm2 -> fc1 -> GELU -> fc2 -> residual of SwinTransformerBlock3D.forward_part2
+// (reference models/video_swin_transformer.py:24-37, 262-272) and linear1 -> ReLU -> linear2 of the deformable encoder's
+// forward_ffn (models/deformable_transformer.py:253-263).  The [M, F] hidden tensor (177 MB per block at Video-Swin stage 0,
+// 316 MB per encoder layer) never exists.
+//
+// Data flow (K22's, see ffn_split.hip for the operand-layout argument):
+//   * a wave owns RT 16-row tiles of x and keeps them, normalised and split, as bf16 MFMA fragments (K = C);
+//   * the hidden layer is produced 32 columns (one chunk) at a time, H^T[32 x 16] = W1_chunk . x^T, + b1, activation; the two
+//     accumulator tiles ARE the B operand of the second product once split (the packed image of W2 carries the k-permutation);
+//   * out^T[C x 16] += W2_chunk . H_chunk^T over the chunks; + b2 (+ residual), 16-B stores.
+// New here:
+//   * the weight stream is a RING of NSLOT LDS slots filled by LDS-DMA up to NSLOT - 1 blocks ahead, handed over with a COUNTED
+//     vmcnt wait (only the block needed next must have landed) -- K22 had one block in flight and sat at the barrier for it;
+//   * weight fragments are read one group ahead of the MFMAs that consume them;
+//   * optional stagger: waves 4..7 run one block behind waves 0..3, so that the activation / split VALU phase of one wave of a
+//     SIMD sits beside the MFMAs of its partner (MI355X_MICROARCH.md, "Two waves per SIMD", item 9);
+//   * every row is taken: a workgroup owns a balanced contiguous share of the row tiles and deals the tiles of a part-filled
+//     pass round-robin over its waves (one per SIMD first), and for few rows the hidden dimension is split over `nfs`
+//     workgroup columns that write partial sums (deterministic: a reduce kernel adds them in a fixed order);
+//   * LayerNorm prologue as K13b (two-pass, the row lives in the four lanes that share it), exact-erf GELU.
+// Co-residence rule: all 256 VGPRs claimed, waves retire behind a barrier, packed f32 code has VGPR
+// operands only (tests/test_isa_rules.py).
+#include "soc_common.h"
+#include "split_math.h"
+#include <atomic>
+#include <type_traits>
+
+namespace {
+
+using namespace soc_split;
+constexpr int THREADS = 512;
+
+template <int C>
+struct Geo {
+    static constexpr int KS = C / 32;                                   // k-steps of the first product
+    static constexpr int OT = C / 16;                                   // output tiles of the second product
+    static constexpr int BLK_U4 = OT * 3 * 64;                          // 16-B pieces of a weight block (W1: 2 KS groups, W2: OT)
+    static constexpr int PIECES = (BLK_U4 + THREADS - 1) / THREADS;     // LDS-DMA instructions per thread and block
+    static constexpr int BLKP_U4 = PIECES * THREADS;                    // a block in the image / a ring slot (whole DMA rounds)
+    static_assert(2 * KS == OT, "both block kinds hold the same number of fragment groups");
+};
+
+template <int N>
+__device__ __forceinline__ void handoff() {        // my part of the next block has landed; everyone is done with this one
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+// DBG (diagnostics only) bit 0: no LDS-DMA inside the block loop, bit 1: no MFMA work (stream ceiling), bit 2: no fragment
+// reads after a block's first group, bit 3: no activation.  STAG: waves 4..7 run one block behind.  PF: fragment groups read ahead.
+template <int C, int ACT, bool HAS_LN, int RT, int NSLOT, int STAG, int PF, int DBG>
+__global__ __launch_bounds__(THREADS, 2) void mlp_split_kernel(
+    const float* __restrict__ x, const u32x4* __restrict__ img, const float* __restrict__ b1, const float* __restrict__ b2,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, const float* __restrict__ res,
+    const float* __restrict__ gamma2, const float* __restrict__ beta2, float eps2, float* __restrict__ out, long M, int F,
+    int nrg, int nfs) {
+    using G = Geo<C>;
+    constexpr int KS = G::KS, OT = G::OT, P = G::PIECES, BLKP = G::BLKP_U4;
+    constexpr int D = NSLOT - 1 - STAG;                                 // blocks in flight ahead of the one being consumed
+    static_assert(D >= 1 && (D - 1) * P < 64, "ring depth");
+    extern __shared__ __attribute__((aligned(16))) u32x4 lds[];
+    u32x4* slots = lds;
+    float* gs = reinterpret_cast<float*>(lds + NSLOT * BLKP);           // gamma [C], beta [C], then this range's b1
+    float* bs = gs + C;
+    float* b1s = bs + C;
+    asm volatile("v_mov_b32 v255, 0" ::: "v255");                       // own the CU
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, kq = lane >> 4;
+    const int fs = blockIdx.x % nfs, g = blockIdx.x / nfs;              // blocks b and b + 8 share an XCD: with nfs | 8 an XCD
+    const int NC = F / 32;                                              // streams one hidden range only
+    const int c0 = (int)((long)fs * NC / nfs), c1 = (int)((long)(fs + 1) * NC / nfs);
+    const int nb = 2 * (c1 - c0);
+    const long ntiles = (M + 15) >> 4;
+    const long t0 = (long)g * ntiles / nrg, t1 = (long)(g + 1) * ntiles / nrg;
+    float* o = out + (nfs > 1 ? (long)fs * M * C : 0);
+    for (int i = tid; i < (c1 - c0) * 32; i += THREADS) b1s[i] = b1[c0 * 32 + i];
+    if (HAS_LN)
+        for (int i = tid; i < C; i += THREADS) { gs[i] = gamma[i]; bs[i] = beta[i]; }
+    // block `blk` of this hidden range -> ring slot `slot`: wave-uniform base + 16 B per lane.  The LDS-DMA is issued from
+    // inline assembly on purpose: while the compiler knows of an LDS-DMA in flight it turns every LDS wait of the loop into
+    // lgkmcnt(0) (fragment reads could not run ahead of the MFMAs) and would pair its own vmcnt(0) with LDS reads; the ring's
+    // waits are the counted ones in handoff().  m0 is touched by these statements only (tests/test_isa_rules.py).
+    const char* ibase = reinterpret_cast<const char*>(img + (long)c0 * 2 * BLKP);
+    const unsigned voff = (unsigned)tid * 16u;
+    const unsigned lds_slots = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)slots + (unsigned)wave * 1024u;
+    auto dma = [&](int blk, int slot) {
+        const char* src = ibase + (long)blk * (BLKP * 16);
+        const unsigned dst = lds_slots + (unsigned)slot * (BLKP * 16);
+#pragma unroll
+        for (int u = 0; u < P; ++u)
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                         ::"s"(dst + u * (THREADS * 16)), "v"(voff), "s"(src + u * (THREADS * 16)) : "memory");
+    };
+    auto next_slot = [](int s) { return s + 1 == NSLOT ? 0 : s + 1; };
+    __syncthreads();
+    // One pass = up to 8 RT row tiles through the whole hidden range.  NRT (compile time) = this wave's tiles in the pass:
+    // the accumulator updates are straight-line code for every count, a wave without tiles only feeds the ring.
+    auto pass = [&](auto nrt_c, auto late_c, long pt) {
+        constexpr int NRT = decltype(nrt_c)::value;
+        constexpr bool LATE = decltype(late_c)::value;
+        constexpr int NX = NRT > 0 ? NRT : 1;
+        bf16x8 xb[NX][KS][3];
+        {
+            float4 xn[NX][KS][2];
+#pragma unroll
+            for (int rt = 0; rt < NRT; ++rt) {
+                const long m = min((pt + 8 * rt + wave) * 16 + r, M - 1);
+                const float4* xp = reinterpret_cast<const float4*>(x + m * C + 8 * kq);
+#pragma unroll
+                for (int s = 0; s < KS; ++s) { xn[rt][s][0] = xp[8 * s]; xn[rt][s][1] = xp[8 * s + 1]; }
+            }
+            int ps = 0;
+#pragma unroll
+            for (int b = 0; b < D; ++b)
+                if (b < nb) { dma(b, ps); ps = next_slot(ps); }
+#pragma unroll
+            for (int rt = 0; rt < NRT; ++rt) {
+                float v[KS][8];
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    v[s][0] = xn[rt][s][0].x; v[s][1] = xn[rt][s][0].y; v[s][2] = xn[rt][s][0].z; v[s][3] = xn[rt][s][0].w;
+                    v[s][4] = xn[rt][s][1].x; v[s][5] = xn[rt][s][1].y; v[s][6] = xn[rt][s][1].z; v[s][7] = xn[rt][s][1].w;
+                }
+                if (HAS_LN) {   // as nn.LayerNorm: two-pass mean / variance over the row, which lives in lanes (r, kq = 0..3)
+                    const float inv_c = in_vgpr(1.0f / C), eps_v = in_vgpr(eps);
+                    float sm = 0.f;
+#pragma unroll
+                    for (int s = 0; s < KS; ++s)
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) sm += v[s][i];
+                    sm += __shfl_xor(sm, 16);
+                    sm += __shfl_xor(sm, 32);
+                    const float mean = sm * inv_c;
+                    float q = 0.f;
+#pragma unroll
+                    for (int s = 0; s < KS; ++s)
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) { v[s][i] -= mean; q = fmaf(v[s][i], v[s][i], q); }
+                    q += __shfl_xor(q, 16);
+                    q += __shfl_xor(q, 32);
+                    const float rstd = rsqrtf(fmaf(q, inv_c, eps_v));
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) {
+                        const float4* gp = reinterpret_cast<const float4*>(gs + 32 * s + 8 * kq);
+                        const float4* ep = reinterpret_cast<const float4*>(bs + 32 * s + 8 * kq);
+                        const float4 ga = gp[0], gb = gp[1], ea = ep[0], eb = ep[1];
+                        const float gg[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
+                        const float bb[8] = {ea.x, ea.y, ea.z, ea.w, eb.x, eb.y, eb.z, eb.w};
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) v[s][i] = fmaf(v[s][i] * rstd, gg[i], bb[i]);
+                    }
+                }
+#pragma unroll
+                for (int s = 0; s < KS; ++s) split8(v[s], xb[rt][s][0], xb[rt][s][1], xb[rt][s][2]);
+            }
+        }
+        f32x4 acc2[NX][OT];
+#pragma unroll
+        for (int rt = 0; rt < NX; ++rt)
+#pragma unroll
+            for (int ot = 0; ot < OT; ++ot) acc2[rt][ot] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 acc1[NX][2];          // a chunk of the hidden layer between its two blocks: H^T tiles j = 0, 1, bias included
+        // ---- the two kinds of block.  Fragment groups are read PF groups ahead of the MFMAs that consume them.
+        auto frag = [&](bf16x8 (&wf)[3], const u32x4* wl, int gi) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) wf[pl] = __builtin_bit_cast(bf16x8, wl[(gi * 3 + pl) * 64]);
+        };
+        // W1 block `blk` (even) in slot `sl`: hidden columns [16 blk, 16 blk + 32) of this range; groups (j, s), j = hidden tile
+        auto first = [&](int blk, int sl) {
+            if ((DBG & 2) || NRT == 0) return;
+            // the accumulators start from b1 (lane (r, kq) holds hidden columns 4 kq .. + 3 of each tile)
+            const f32x4* bp = reinterpret_cast<const f32x4*>(b1s + 16 * blk + 4 * kq);
+            const f32x4 bq0 = bp[0], bq1 = bp[4];
+            const u32x4* wl = slots + sl * BLKP + lane;
+#pragma unroll
+            for (int rt = 0; rt < NRT; ++rt) { acc1[rt][0] = bq0; acc1[rt][1] = bq1; }
+            constexpr int NG = 2 * KS;
+            bf16x8 wf[PF + 1][3];
+#pragma unroll
+            for (int q = 0; q < PF; ++q) frag(wf[q], wl, q);
+#pragma unroll
+            for (int gi = 0; gi < NG; ++gi) {
+                if (gi + PF < NG && !((DBG & 4) && gi > 0)) frag(wf[(gi + PF) % (PF + 1)], wl, gi + PF);
+                const int j = gi / KS, s = gi % KS;
+                const int cur = (DBG & 4) ? 0 : gi % (PF + 1);
+#pragma unroll
+                for (int rt = 0; rt < NRT; ++rt) mfma6(acc1[rt][j], wf[cur], xb[rt][s][0], xb[rt][s][1], xb[rt][s][2]);
+                // the reads go out in front of this group's MFMAs; PF groups ahead, not all of them
+                if (gi + PF < NG && !(DBG & 4)) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 6 * NRT, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        // W2 block in slot `sl`: activation and split of the chunk (vector ALU: with the stagger it runs beside the partner
+        // wave's first product), then every output tile gets the chunk's 32 hidden columns
+        auto second = [&](int sl) {
+            if ((DBG & 2) || NRT == 0) return;
+            const u32x4* wl = slots + sl * BLKP + lane;
+            bf16x8 wf[PF + 1][3];
+#pragma unroll
+            for (int q = 0; q < PF; ++q) frag(wf[q], wl, q);
+            bf16x8 hb[NX][3];
+#pragma unroll
+            for (int rt = 0; rt < NRT; ++rt) {
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = acc1[rt][i >> 2][i & 3];
+                if (DBG & 8) {
+                } else if (ACT == 1) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
+                } else {
+                    const GeluK gk = gelu_k();
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = gelu_erf(v[i], gk);
+                }
+                split8(v, hb[rt][0], hb[rt][1], hb[rt][2]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ot = 0; ot < OT; ++ot) {
+                if (ot + PF < OT && !((DBG & 4) && ot > 0)) frag(wf[(ot + PF) % (PF + 1)], wl, ot + PF);
+                const int cur = (DBG & 4) ? 0 : ot % (PF + 1);
+#pragma unroll
+                for (int rt = 0; rt < NRT; ++rt) mfma6(acc2[rt][ot], wf[cur], hb[rt][0], hb[rt][1], hb[rt][2]);
+                if (ot + PF < OT && !(DBG & 4)) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 6 * NRT, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        if (nb >= D) handoff<(D - 1) * P>(); else handoff<0>();         // block 0 has landed
+        // time step t: waves 0..3 work on block t; with the stagger waves 4..7 work on block t - 1 (its slot: `pslot`)
+        int slot = 0, pslot = 0, dslot = D % NSLOT;
+        for (int blk = 0; blk < nb; blk += 2) {
+            bool more = blk + D < nb;
+            if (!(DBG & 1) && more) { dma(blk + D, dslot); dslot = next_slot(dslot); }
+            if (!LATE) first(blk, slot);
+            else if (blk > 0) second(pslot);
+            if (more) handoff<(D - 1) * P>(); else handoff<0>();        // the W2 block has landed
+            pslot = slot;
+            slot = next_slot(slot);
+            more = blk + 1 + D < nb;
+            if (!(DBG & 1) && more) { dma(blk + 1 + D, dslot); dslot = next_slot(dslot); }
+            if (!LATE) second(slot);
+            else first(blk, pslot);
+            if (blk + 2 < nb) {
+                if (more) handoff<(D - 1) * P>(); else handoff<0>();    // the next W1 block has landed
+            }
+            pslot = slot;
+            slot = next_slot(slot);
+        }
+        if (LATE) second(pslot);
+        // ---- lane (r, kq) holds out[m][16 ot + 4 kq .. + 3] of its tiles.  b2 and the residual are added LAST, to the finished
+        // sum of products (starting the accumulators from them would round every product at the residual's magnitude); the
+        // loads of a tile go out together
+#pragma unroll
+        for (int rt = 0; rt < NRT; ++rt) {
+            const long m = (pt + 8 * rt + wave) * 16 + r;
+            if (m < M) {
+                long mo = m * C + 4 * kq;
+                asm volatile("" : "+v"(mo));       // worked out here, not carried through the block loop
+                if (nfs == 1) {
+                    f32x4 bq[OT];
+#pragma unroll
+                    for (int ot = 0; ot < OT; ++ot) bq[ot] = *reinterpret_cast<const f32x4*>(b2 + 16 * ot + 4 * kq);
+                    if (res) {
+                        f32x4 rr[OT];
+#pragma unroll
+                        for (int ot = 0; ot < OT; ++ot) rr[ot] = *reinterpret_cast<const f32x4*>(res + mo + 16 * ot);
+#pragma unroll
+                        for (int ot = 0; ot < OT; ++ot) acc2[rt][ot] = (acc2[rt][ot] + bq[ot]) + rr[ot];
+                    } else {
+#pragma unroll
+                        for (int ot = 0; ot < OT; ++ot) acc2[rt][ot] += bq[ot];
+                    }
+                }
+                if (nfs == 1 && gamma2) {
+                    // LayerNorm behind the block (the encoder's norm2): the row lives in lanes (r, kq = 0..3), two-pass
+                    const float inv_c = in_vgpr(1.0f / C), eps_v = in_vgpr(eps2);
+                    float sm = 0.f;
+#pragma unroll
+                    for (int ot = 0; ot < OT; ++ot) sm += (acc2[rt][ot][0] + acc2[rt][ot][1]) + (acc2[rt][ot][2] + acc2[rt][ot][3]);
+                    sm += __shfl_xor(sm, 16);
+                    sm += __shfl_xor(sm, 32);
+                    const float mean = sm * inv_c;
+                    float q = 0.f;
+#pragma unroll
+                    for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { acc2[rt][ot][i] -= mean; q = fmaf(acc2[rt][ot][i], acc2[rt][ot][i], q); }
+                    q += __shfl_xor(q, 16);
+                    q += __shfl_xor(q, 32);
+                    const float rstd = rsqrtf(fmaf(q, inv_c, eps_v));
+#pragma unroll
+                    for (int ot = 0; ot < OT; ++ot) {
+                        const f32x4 g2 = *reinterpret_cast<const f32x4*>(gamma2 + 16 * ot + 4 * kq);
+                        const f32x4 e2 = *reinterpret_cast<const f32x4*>(beta2 + 16 * ot + 4 * kq);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc2[rt][ot][i] = fmaf(acc2[rt][ot][i] * rstd, g2[i], e2[i]);
+                    }
+                }
+#pragma unroll
+                for (int ot = 0; ot < OT; ++ot) *reinterpret_cast<f32x4*>(o + mo + 16 * ot) = acc2[rt][ot];
+            }
+        }
+    };
+    const bool late = STAG && wave >= 4;
+    for (long pt = t0; pt < t1; pt += 8 * RT) {
+        if (pt != t0) handoff<0>();                 // nobody still reads the slots the next pass's prologue refills
+        // this wave's row tiles: pt + 8 rt + wave (a part-filled pass leaves the second tile of a wave empty first)
+        const int nrt = (RT == 2 && pt + 8 + wave < t1) ? 2 : (pt + wave < t1 ? 1 : 0);
+        if (STAG && late) {
+            if (RT == 2 && nrt == 2) pass(std::integral_constant<int, RT>{}, std::integral_constant<bool, STAG != 0>{}, pt);
+            else if (nrt == 1) pass(std::integral_constant<int, 1>{}, std::integral_constant<bool, STAG != 0>{}, pt);
+            else pass(std::integral_constant<int, 0>{}, std::integral_constant<bool, STAG != 0>{}, pt);
+        } else {
+            if (RT == 2 && nrt == 2) pass(std::integral_constant<int, RT>{}, std::false_type{}, pt);
+            else if (nrt == 1) pass(std::integral_constant<int, 1>{}, std::false_type{}, pt);
+            else pass(std::integral_constant<int, 0>{}, std::false_type{}, pt);
+        }
+    }
+    __syncthreads();        // the waves retire together
+}
+
+// out = [LayerNorm](sum over the hidden ranges (fixed order) + b2 (+ residual)); a wave per row, a float4 per lane
+__global__ __launch_bounds__(256) void mlp_reduce_kernel(const float* __restrict__ part, int nfs, const float* __restrict__ b2,
+                                                         const float* __restrict__ res, const float* __restrict__ gamma2,
+                                                         const float* __restrict__ beta2, float eps2, float* __restrict__ out,
+                                                         long M, int C) {
+    const int lane = threadIdx.x & 63;
+    const bool on = lane < C / 4;
+    const long n4 = M * C / 4;
+    for (long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6); m < M; m += (long)gridDim.x * 4) {
+        const long i = m * (C / 4) + lane;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (on) {
+            a = reinterpret_cast<const float4*>(part)[i];
+            for (int f = 1; f < nfs; ++f) {
+                const float4 p = reinterpret_cast<const float4*>(part)[(long)f * n4 + i];
+                a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w;
+            }
+            const float4 bq = *reinterpret_cast<const float4*>(b2 + 4 * lane);
+            a.x += bq.x; a.y += bq.y; a.z += bq.z; a.w += bq.w;
+            if (res) {
+                const float4 rr = reinterpret_cast<const float4*>(res)[i];
+                a.x += rr.x; a.y += rr.y; a.z += rr.z; a.w += rr.w;
+            }
+        }
+        if (gamma2) {
+            float sm = (a.x + a.y) + (a.z + a.w);
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) sm += __shfl_xor(sm, d);
+            const float mean = sm / C;
+            if (on) { a.x -= mean; a.y -= mean; a.z -= mean; a.w -= mean; }
+            float q = a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) q += __shfl_xor(q, d);
+            const float rstd = rsqrtf(q / C + eps2);
+            if (on) {
+                const float4 g2 = *reinterpret_cast<const float4*>(gamma2 + 4 * lane);
+                const float4 e2 = *reinterpret_cast<const float4*>(beta2 + 4 * lane);
+                a.x = fmaf(a.x * rstd, g2.x, e2.x); a.y = fmaf(a.y * rstd, g2.y, e2.y);
+                a.z = fmaf(a.z * rstd, g2.z, e2.z); a.w = fmaf(a.w * rstd, g2.w, e2.w);
+            }
+        }
+        if (on) reinterpret_cast<float4*>(out)[i] = a;
+    }
+}
+
+// item = (chunk hc, block kind, group, lane): one 16-B piece per plane = 8 weights split three ways
+template <int C>
+__global__ __launch_bounds__(256) void mlp_pack_kernel(const float* __restrict__ w1, const float* __restrict__ w2,
+                                                       u32x4* __restrict__ img, int F) {
+    using G = Geo<C>;
+    constexpr int KS = G::KS, OT = G::OT;
+    const long total = (long)(F / 32) * 2 * OT * 64;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int lane = (int)(idx & 63);
+        long rest = idx >> 6;
+        const int sub = (int)(rest % OT);                              // W1: (j, s) = (sub / KS, sub % KS); W2: output tile
+        rest /= OT;
+        const int kind = (int)(rest & 1), hc = (int)(rest >> 1);
+        const int n = lane & 15, kq = lane >> 4;
+        float v[8];
+        if (kind == 0) {
+            const int j = sub / KS, s = sub % KS;
+            const float* src = w1 + (long)(32 * hc + 16 * j + n) * C + 32 * s + 8 * kq;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = src[i];
+        } else {
+            // k order of a lane = the order the two hidden tiles of a chunk sit in the accumulators: 4 kq + i, 16 + 4 kq + i
+            const float* src = w2 + (long)(16 * sub + n) * F + 32 * hc + 4 * kq;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { v[i] = src[i]; v[4 + i] = src[16 + i]; }
+        }
+        bf16x8 h0, h1, h2;
+        split8(v, h0, h1, h2);
+        u32x4* dst = img + (long)(hc * 2 + kind) * G::BLKP_U4 + (sub * 3) * 64 + lane;
+        dst[0] = __builtin_bit_cast(u32x4, h0);
+        dst[64] = __builtin_bit_cast(u32x4, h1);
+        dst[128] = __builtin_bit_cast(u32x4, h2);
+    }
+}
+
+int num_cus() {
+    const int dev = soc_current_device();
+    int v = 0;
+    if (dev >= 0 && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) return v;
+    return 256;
+}
+
+constexpr int rows_per_wave(int C) { return C <= 96 ? 2 : 1; }       // RT: x fragments + output accumulators must fit 256 VGPRs
+
+template <int C>
+size_t lds_bytes(int nslot, int F, int nfs) {
+    const int nc = (F / 32 + nfs - 1) / nfs;
+    return (size_t)nslot * Geo<C>::BLKP_U4 * 16 + 8 * C + (size_t)nc * 128;
+}
+
+struct Args {
+    const float *x, *b1, *b2, *gamma, *beta, *res, *gamma2, *beta2;
+    float eps2;
+    const u32x4* img;
+    float eps;
+    float* out;
+    long M;
+    int F, nrg, nfs;
+    hipStream_t st;
+};
+
+template <int C, int ACT, bool HAS_LN, int NSLOT, int STAG, int PF, int DBG>
+int launch(const Args& a) {
+    constexpr int RT = rows_per_wave(C);
+    const void* fn = reinterpret_cast<const void*>(mlp_split_kernel<C, ACT, HAS_LN, RT, NSLOT, STAG, PF, DBG>);
+    const size_t lds = lds_bytes<C>(NSLOT, a.F, a.nfs);
+    if (lds > 160 * 1024) return SOC_EUNSUPPORTED;
+    static std::atomic<bool> attr_set[SOC_MAX_DEVICES];
+    const int dev = soc_current_device();
+    if (dev < 0) return SOC_ELAUNCH;
+    if (!attr_set[dev].load(std::memory_order_acquire)) {
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return SOC_ELAUNCH;
+        attr_set[dev].store(true, std::memory_order_release);
+    }
+    hipLaunchKernelGGL((mlp_split_kernel<C, ACT, HAS_LN, RT, NSLOT, STAG, PF, DBG>), dim3((unsigned)(a.nrg * a.nfs)), dim3(THREADS),
+                       lds, a.st, a.x, a.img, a.b1, a.b2, a.gamma, a.beta, a.eps, a.res, a.gamma2, a.beta2, a.eps2, a.out, a.M, a.F, a.nrg,
+                       a.nfs);
+    return soc_check_launch();
+}
+
+// variant = NSLOT + 8 * STAG + 16 * DBG + 256 * (PF - 1); 0 = the shipped choice for the width
+template <int C, int ACT, bool HAS_LN>
+int launch_variant(const Args& a, int variant) {
+    constexpr int NS_MAX = (160 * 1024 - 8 * C - 4096) / (Geo<C>::BLKP_U4 * 16);    // ring slots that fit beside a 1024-wide b1 range
+    constexpr int NS_DEF = NS_MAX >= 4 ? 4 : NS_MAX;
+    static_assert(NS_DEF >= 3, "three slots at least");
+    if (variant == 0) return launch<C, ACT, HAS_LN, NS_DEF, 0, 1, 0>(a);
+#ifdef SOC_K23_VARIANTS         // diagnostic build (tools/experiments/k23_time.py)
+#define V(NS, ST, PFD, DB) case NS + 8 * ST + 16 * DB + 256 * (PFD - 1): return launch<C, ACT, HAS_LN, NS, ST, PFD, DB>(a);
+    switch (variant) {
+        V(2, 0, 1, 0) V(3, 0, 1, 0) V(3, 1, 1, 0) V(3, 0, 2, 0) V(3, 1, 2, 0)
+        V(3, 0, 1, 1) V(3, 0, 1, 2) V(3, 0, 1, 4) V(3, 0, 1, 8) V(3, 0, 1, 12) V(3, 0, 1, 13) V(3, 1, 1, 13) V(3, 1, 1, 1)
+        default: break;
+    }
+#undef V
+#endif
+    return SOC_EUNSUPPORTED;
+}
+
+template <int C>
+int launch_c(const Args& a, int act, int variant) {
+#ifdef SOC_K23_VARIANTS         // the diagnostic build instantiates the two forms the model uses only
+    if (act == 1 && !a.gamma) return launch_variant<C, 1, false>(a, variant);
+    if (act == 2 && a.gamma) return launch_variant<C, 2, true>(a, variant);
+#else
+    if (act == 1) return a.gamma ? launch_variant<C, 1, true>(a, variant) : launch_variant<C, 1, false>(a, variant);
+    if (act == 2) return a.gamma ? launch_variant<C, 2, true>(a, variant) : launch_variant<C, 2, false>(a, variant);
+#endif
+    return SOC_EUNSUPPORTED;
+}
+
+bool width_ok(int C) { return C == 96 || C == 128 || C == 192 || C == 256; }
+
+template <int C> size_t packed_bytes(int F) { return (size_t)(F / 32) * 2 * Geo<C>::BLKP_U4 * 16; }
+
+}  // namespace
+
+extern "C" size_t soc_mlp_split_packed_bytes(int C, int F) {
+    if (!width_ok(C) || F <= 0 || F % 32 != 0) return 0;
+    switch (C) {
+        case 96: return packed_bytes<96>(F);
+        case 128: return packed_bytes<128>(F);
+        case 192: return packed_bytes<192>(F);
+        default: return packed_bytes<256>(F);
+    }
+}
+
+extern "C" int soc_mlp_split_pack_f32(const float* w1, const float* w2, void* packed, int C, int F, void* stream) {
+    if (!w1 || !w2 || !packed) return SOC_EINVAL;
+    if (!width_ok(C) || F <= 0 || F % 32 != 0) return SOC_EUNSUPPORTED;
+    const long total = (long)(F / 32) * 2 * (C / 16) * 64;
+    const int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+    u32x4* img = reinterpret_cast<u32x4*>(packed);
+    hipStream_t st = (hipStream_t)stream;
+    switch (C) {
+        case 96: hipLaunchKernelGGL(mlp_pack_kernel<96>, dim3(blocks), dim3(256), 0, st, w1, w2, img, F); break;
+        case 128: hipLaunchKernelGGL(mlp_pack_kernel<128>, dim3(blocks), dim3(256), 0, st, w1, w2, img, F); break;
+        case 192: hipLaunchKernelGGL(mlp_pack_kernel<192>, dim3(blocks), dim3(256), 0, st, w1, w2, img, F); break;
+        default: hipLaunchKernelGGL(mlp_pack_kernel<256>, dim3(blocks), dim3(256), 0, st, w1, w2, img, F); break;
+    }
+    return soc_check_launch();
+}
+
+// How a launch is cut: `nrg` workgroup rows over the row tiles x `nfs` hidden ranges.  Many rows: one hidden range, a
+// workgroup per CU.  Few rows (less than half a pass of every CU): the hidden dimension is split so that nrg * nfs fills the
+// chip; nfs is a power of two <= 8 (an XCD then streams one range only).
+static void plan_rows(long M, int C, int F, int cus, int* nrg_out, int* nfs_out) {
+    const long ntiles = (M + 15) >> 4;
+    const int per_pass = 8 * rows_per_wave(C);
+    const long groups = (ntiles + per_pass - 1) / per_pass;             // workgroup passes if every pass were full
+    int nfs = 1;
+    while (nfs < 8 && groups * nfs * 2 <= cus && (F / 32) % (nfs * 2) == 0) nfs *= 2;
+    long nrg = groups < cus / nfs ? groups : cus / nfs;
+    if (nrg < 1) nrg = 1;
+    *nrg_out = (int)nrg;
+    *nfs_out = nfs;
+}
+
+// A whole call: rows that fill whole rounds of the chip (every CU one full pass) run with one hidden range; a last round that
+// would be less than 60 % filled is cut off and run as its own launch over split hidden ranges (a round streams both
+// weight matrices into every CU whatever its fill).  Returns the row where the tail starts (M: no tail).
+static long tail_start(long M, int C, int cus) {
+    const long ntiles = (M + 15) >> 4;
+    const long per_round = (long)cus * 8 * rows_per_wave(C);
+    const long full = ntiles / per_round, rem = ntiles - full * per_round;
+    if (full >= 1 && rem > 0 && rem * 5 < per_round * 3) return full * per_round * 16;
+    return M;
+}
+
+extern "C" int soc_mlp_split_plan(long M, int C, int F, int* nrg_out, int* nfs_out) {
+    if (!width_ok(C) || F <= 0 || F % 32 != 0 || M <= 0 || !nrg_out || !nfs_out) return SOC_EUNSUPPORTED;
+    plan_rows(M, C, F, num_cus(), nrg_out, nfs_out);
+    return SOC_OK;
+}
+
+extern "C" size_t soc_mlp_split_workspace_bytes(long M, int C, int F) {
+    if (!width_ok(C) || F <= 0 || F % 32 != 0 || M <= 0) return 0;
+    const int cus = num_cus();
+    const long m0 = tail_start(M, C, cus);
+    int nrg = 0, nfs = 0;
+    plan_rows(m0 < M ? M - m0 : M, C, F, cus, &nrg, &nfs);
+    return nfs == 1 ? 0 : (size_t)nfs * (m0 < M ? M - m0 : M) * C * sizeof(float);
+}
+
+extern "C" int soc_mlp_split_variant_f32(const float* x, const void* packed, const float* b1, const float* b2,
+                                         const float* ln_gamma, const float* ln_beta, float ln_eps, const float* residual,
+                                         const float* post_gamma, const float* post_beta, float post_eps, float* out,
+                                         float* workspace, long M, int C, int F, int act, int nrg, int nfs, int variant,
+                                         void* stream) {
+    if (M < 0 || F <= 0) return SOC_EINVAL;
+    if (M == 0) return SOC_OK;
+    if (!x || !packed || !b1 || !b2 || !out || (ln_gamma == nullptr) != (ln_beta == nullptr) ||
+        (post_gamma == nullptr) != (post_beta == nullptr))
+        return SOC_EINVAL;
+    if (!width_ok(C) || F % 32 != 0 || (act != 1 && act != 2)) return SOC_EUNSUPPORTED;
+    if ((((uintptr_t)x | (uintptr_t)packed | (uintptr_t)b1 | (uintptr_t)b2 | (uintptr_t)residual | (uintptr_t)out |
+          (uintptr_t)ln_gamma | (uintptr_t)ln_beta | (uintptr_t)post_gamma | (uintptr_t)post_beta | (uintptr_t)workspace) & 15) != 0)
+        return SOC_EUNSUPPORTED;
+    if (nrg <= 0 || nfs <= 0 || nfs > F / 32 || nrg > (M + 15) / 16) return SOC_EINVAL;
+    if (nfs > 1 && !workspace) return SOC_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    Args a{x, b1, b2, ln_gamma, ln_beta, nfs > 1 ? nullptr : residual, nfs > 1 ? nullptr : post_gamma,
+           nfs > 1 ? nullptr : post_beta, post_eps, reinterpret_cast<const u32x4*>(packed), ln_eps,
+           nfs > 1 ? workspace : out, M, F, nrg, nfs, st};
+    int rc;
+    switch (C) {
+        case 96: rc = launch_c<96>(a, act, variant); break;
+        case 128: rc = launch_c<128>(a, act, variant); break;
+        case 192: rc = launch_c<192>(a, act, variant); break;
+        default: rc = launch_c<256>(a, act, variant); break;
+    }
+    if (rc != SOC_OK || nfs == 1) return rc;
+    const int blocks = (int)((M + 3) / 4 > 8192 ? 8192 : (M + 3) / 4);
+    hipLaunchKernelGGL(mlp_reduce_kernel, dim3(blocks), dim3(256), 0, st, workspace, nfs, b2, residual, post_gamma, post_beta,
+                       post_eps, out, M, C);
+    return soc_check_launch();
+}
+
+extern "C" int soc_mlp_split_f32(const float* x, const void* packed, const float* b1, const float* b2, const float* ln_gamma,
+                                 const float* ln_beta, float ln_eps, const float* residual, const float* post_gamma,
+                                 const float* post_beta, float post_eps, float* out, float* workspace, size_t workspace_bytes,
+                                 long M, int C, int F, int act, void* stream) {
+    if (M < 0 || F <= 0) return SOC_EINVAL;
+    if (M == 0) return SOC_OK;
+    if (!width_ok(C) || F % 32 != 0) return SOC_EUNSUPPORTED;
+    if (workspace_bytes < soc_mlp_split_workspace_bytes(M, C, F)) return SOC_EWORKSPACE;
+    const int cus = num_cus();
+    const long m0 = tail_start(M, C, cus);
+    int nrg = 0, nfs = 0;
+    if (m0 < M) {       // whole rounds first, then the tail over split hidden ranges
+        const int rc = soc_mlp_split_variant_f32(x, packed, b1, b2, ln_gamma, ln_beta, ln_eps, residual, post_gamma, post_beta,
+                                                 post_eps, out, nullptr, m0, C, F, act, cus, 1, 0, stream);
+        if (rc != SOC_OK) return rc;
+        plan_rows(M - m0, C, F, cus, &nrg, &nfs);
+        return soc_mlp_split_variant_f32(x + m0 * C, packed, b1, b2, ln_gamma, ln_beta, ln_eps,
+                                         residual ? residual + m0 * C : nullptr, post_gamma, post_beta, post_eps, out + m0 * C,
+                                         workspace, M - m0, C, F, act, nrg, nfs, 0, stream);
+    }
+    plan_rows(M, C, F, cus, &nrg, &nfs);
+    return soc_mlp_split_variant_f32(x, packed, b1, b2, ln_gamma, ln_beta, ln_eps, residual, post_gamma, post_beta, post_eps, out,
+                                     workspace, M, C, F, act, nrg, nfs, 0, stream);
+}

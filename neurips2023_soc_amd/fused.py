@@ -46,6 +46,13 @@ def ffn_relu(x: torch.Tensor, lin1: nn.Linear, lin2: nn.Linear) -> torch.Tensor:
     return apply(lin2, linear_relu(x, lin1))
 
 
+def mlp_ok(x: torch.Tensor, lin1: nn.Linear, lin2: nn.Linear) -> bool:
+    """K23 takes the whole two-layer block lin2(act(lin1(LN(x)))) (+ residual, + LayerNorm behind it): pixel-sized inputs of
+    width 96 / 128 / 192 / 256 (Video-Swin stages 0-1, the deformable encoder's feed-forward block)."""
+    return (lin1.bias is not None and lin2.bias is not None and x.numel() // x.shape[-1] >= 4096
+            and hot_ops.mlp_split_supported(x, lin1.weight, lin2.weight))
+
+
 def ws_dense_ok(x: torch.Tensor, weight: torch.Tensor) -> bool:
     """K13b's step-by-step form (K = 384 / 512, no LayerNorm in front) for a plain linear layer on a pixel-sized, already
     normalised input: Video-Swin stage 2 qkv / proj / fc1 (53 / 26 / 71 us against the library's 74 / 30 and K20's 75-80,

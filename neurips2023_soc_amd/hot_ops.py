@@ -1015,6 +1015,95 @@ def ffn_split(x: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor, residua
     return out
 
 
+MLP_SPLIT_C = (96, 128, 192, 256)       # model widths K23 is built for
+_MLP_ACT = {"relu": 1, "gelu": 2}
+_mlp_cache = {}
+
+
+def mlp_split_supported(x: Tensor, w1: Tensor, w2: Tensor) -> bool:
+    """K23 takes act(LN(x) w1^T + b1) w2^T + b2 (+ residual): CUDA fp32, model width 96 / 128 / 192 / 256, hidden width a
+    multiple of 32, split arithmetic on (SOC_SPLIT_OFF=mlp switches it off)."""
+    Cw = x.shape[-1]
+    return (x.is_cuda and x.dtype == torch.float32 and split_enabled() and "mlp" not in _SPLIT_OFF and Cw in MLP_SPLIT_C
+            and tuple(w1.shape[1:]) == (Cw,) and tuple(w2.shape) == (Cw, w1.shape[0]) and w1.shape[0] % 32 == 0
+            and w1.dtype == torch.float32 and w2.dtype == torch.float32)
+
+
+def _mlp_packed(w1: Tensor, w2: Tensor) -> Tensor:
+    """The K23 weight image of (w1, w2): built once, rebuilt after an in-place update; the keyed tensors stay alive with it."""
+    lib = _lib.load()
+    F_, C_ = w1.shape
+    ident = (w1.data_ptr(), w2.data_ptr())
+    key = ident + (w1._version, w2._version, F_, C_, w1.device.index, tuple(w1.stride()), tuple(w2.stride()))
+    ent = _mlp_cache.get(ident)
+    if ent is None or ent[0] != key:
+        packed = torch.empty(lib.soc_mlp_split_packed_bytes(C_, F_), dtype=torch.uint8, device=w1.device)
+        w1c, w2c = _f32c(w1.detach()), _f32c(w2.detach())
+        _lib.check(lib.soc_mlp_split_pack_f32(w1c.data_ptr(), w2c.data_ptr(), packed.data_ptr(), C_, F_, _stream()),
+                   "soc_mlp_split_pack_f32")
+        ent = (key, packed, (w1, w2))
+        _mlp_cache[ident] = ent
+    return ent[1]
+
+
+def mlp_split(x: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor, act: str = "gelu",
+              ln: Optional[Tuple[Tensor, Tensor, float]] = None, residual: Optional[Tensor] = None,
+              out: Optional[Tensor] = None, cut: Optional[Tuple[int, int]] = None, variant: int = 0,
+              post_ln: Optional[Tuple[Tensor, Tensor, float]] = None) -> Tensor:
+    """K23: LN2(act(LN(x) @ w1.T + b1) @ w2.T + b2 + residual) in one launch, the hidden layer in registers; ln / post_ln =
+    (gamma, beta, eps) or None, act "relu" | "gelu".  `cut` = (workgroup rows, hidden ranges) forces one launch with that decomposition
+    (tests, probes); by default the library plans whole rounds + a split tail."""
+    _need_gpu(x, w1, b1, w2, b2, residual, *(ln[:2] if ln else ()), *(post_ln[:2] if post_ln else ()))
+    lib = _lib.load()
+    x = _f32c(x)
+    F_, C_ = w1.shape
+    M = x.numel() // C_
+    packed = _mlp_packed(w1, w2)
+    g2 = be2 = None
+    eps2 = 0.0
+    if post_ln is not None:
+        g2, be2, eps2 = _f32c(post_ln[0]), _f32c(post_ln[1]), float(post_ln[2])
+    if out is None:
+        out = torch.empty_like(x)
+    elif out.shape != x.shape or out.dtype != torch.float32 or not out.is_contiguous() or out.device != x.device:
+        raise _lib.SocHipError("mlp_split: `out` must be a contiguous float32 tensor of the input's shape on its device")
+    if residual is not None:
+        residual = _f32c(residual)
+        if residual.shape != x.shape:
+            raise _lib.SocHipError("mlp_split: residual shape differs from the input's")
+    g = be = None
+    eps = 0.0
+    if ln is not None:
+        g, be, eps = _f32c(ln[0]), _f32c(ln[1]), float(ln[2])
+    ptr = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
+    b1c, b2c = _f32c(b1), _f32c(b2)
+    if cut is None:
+        nbytes = lib.soc_mlp_split_workspace_bytes(M, C_, F_)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
+        with _timed("mlp_split", 4.0 * M * F_ * C_):
+            rc = lib.soc_mlp_split_f32(x.data_ptr(), packed.data_ptr(), b1c.data_ptr(), b2c.data_ptr(), ptr(g), ptr(be), eps,
+                                       ptr(residual), ptr(g2), ptr(be2), eps2, out.data_ptr(), ptr(ws), nbytes, M, C_, F_,
+                                       _MLP_ACT[act], _stream())
+        _lib.check(rc, "soc_mlp_split_f32")
+        return out
+    nrg, nfs = cut
+    ws = torch.empty(nfs * M * C_, dtype=torch.float32, device=x.device) if nfs > 1 else None
+    with _timed("mlp_split", 4.0 * M * F_ * C_):
+        rc = lib.soc_mlp_split_variant_f32(x.data_ptr(), packed.data_ptr(), b1c.data_ptr(), b2c.data_ptr(), ptr(g), ptr(be), eps,
+                                           ptr(residual), ptr(g2), ptr(be2), eps2, out.data_ptr(), ptr(ws), M, C_, F_,
+                                           _MLP_ACT[act], int(nrg), int(nfs), int(variant), _stream())
+    _lib.check(rc, "soc_mlp_split_variant_f32")
+    return out
+
+
+def mlp_split_plan(M: int, C_: int, F_: int) -> Tuple[int, int]:
+    """(workgroup rows, hidden ranges) K23 would cut M rows into as ONE launch."""
+    lib = _lib.load()
+    nrg, nfs = C.c_int(0), C.c_int(0)
+    _lib.check(lib.soc_mlp_split_plan(M, C_, F_, C.byref(nrg), C.byref(nfs)), "soc_mlp_split_plan")
+    return nrg.value, nfs.value
+
+
 def linear_split_supported(x: Tensor, weight: Tensor, ln: bool = False) -> bool:
     N, K = weight.shape
     return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.shape[-1] == K

@@ -135,6 +135,11 @@ class BasicLayer(nn.Module):
                 o = hot_ops.window_attention3d(qkv, a.qkv.bias, a.relative_position_bias_table, a.num_heads,
                                                a.window_size, blk.shift_size)
                 x = hot_ops.ws_linear(o, a.proj.weight, a.proj.bias, residual=x)
+                if fused.mlp_ok(x, blk.mlp.fc1, blk.mlp.fc2):
+                    # K23: norm2 + fc1 + GELU + fc2 + residual in one launch, the hidden layer never leaves the registers
+                    x = hot_ops.mlp_split(x, blk.mlp.fc1.weight, blk.mlp.fc1.bias, blk.mlp.fc2.weight, blk.mlp.fc2.bias, "gelu",
+                                          ln=(blk.norm2.weight, blk.norm2.bias, blk.norm2.eps), residual=x)
+                    continue
                 h = hot_ops.ws_linear(x, blk.mlp.fc1.weight, blk.mlp.fc1.bias,
                                       ln=(blk.norm2.weight, blk.norm2.bias, blk.norm2.eps), act="gelu")
                 if hot_ops.ws_linear_supported(h, blk.mlp.fc2.weight, False):

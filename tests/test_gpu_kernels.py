@@ -1235,3 +1235,93 @@ def test_ffn_split_vs_f64(ops, M, F):
     want_h = torch.nn.functional.linear(torch.nn.functional.linear(x.double(), w1.double(), b1.double()).relu(), w2.double(),
                                         b2.double())
     assert float((half.double() - want_h).abs().max()) < 1e-5 * scale
+
+
+def _mlp_case(M, Cw, F, act, ln, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = (torch.randn(M, Cw, generator=g) * 1.2).cuda()
+    w1 = (torch.randn(F, Cw, generator=g) / Cw ** 0.5).cuda()
+    b1 = (torch.randn(F, generator=g) * 0.1).cuda()
+    w2 = (torch.randn(Cw, F, generator=g) / F ** 0.5).cuda()
+    b2 = (torch.randn(Cw, generator=g) * 0.1).cuda()
+    lnp = ((torch.rand(Cw, generator=g) + 0.5).cuda(), (torch.randn(Cw, generator=g) * 0.1).cuda(), 1e-5) if ln else None
+    return x, w1, b1, w2, b2, lnp
+
+
+def _mlp_f64(x, w1, b1, w2, b2, act, lnp, res=None):
+    xd = x.double()
+    if lnp is not None:
+        xd = torch.nn.functional.layer_norm(xd, (x.shape[-1],), lnp[0].double(), lnp[1].double(), lnp[2])
+    h = torch.nn.functional.linear(xd, w1.double(), b1.double())
+    h = h.relu() if act == "relu" else torch.nn.functional.gelu(h)
+    y = torch.nn.functional.linear(h, w2.double(), b2.double())
+    return y if res is None else y + res.double()
+
+
+def _mlp_f32(x, w1, b1, w2, b2, act, lnp):
+    xn = x if lnp is None else torch.nn.functional.layer_norm(x, (x.shape[-1],), lnp[0], lnp[1], lnp[2])
+    h = torch.nn.functional.linear(xn, w1, b1)
+    h = h.relu() if act == "relu" else torch.nn.functional.gelu(h)
+    return torch.nn.functional.linear(h, w2, b2)
+
+
+@pytest.mark.parametrize("M,Cw,F,act,ln", [
+    (115200, 96, 384, "gelu", True),        # Video-Swin-T stage 0 at the BASELINE config: norm2 + fc1 + GELU + fc2 + residual
+    (28800, 192, 768, "gelu", True),        # stage 1
+    (115200, 128, 512, "gelu", True),       # Swin-B stage 0
+    (28800, 256, 1024, "gelu", True),       # Swin-B stage 1
+    (38560, 256, 2048, "relu", False),      # the deformable encoder's feed-forward block: whole round + tail over 4 hidden ranges
+    (4099, 256, 2048, "relu", False), (17, 256, 2048, "relu", False), (1000, 192, 768, "gelu", True), (33, 96, 384, "relu", True),
+    (5000, 96, 64, "gelu", False)])
+def test_mlp_split_vs_f64(ops, M, Cw, F, act, ln):
+    """K23 (LayerNorm + linear + activation + linear + residual in one launch, hidden layer in registers, bf16 matrix cores with
+    the exact split) against f64 and against the f32 library path: f32-grade error, every row taken (whole rounds + split
+    tail), bit-repeatable, repack after an in-place weight update."""
+    x, w1, b1, w2, b2, lnp = _mlp_case(M, Cw, F, act, ln, M + F + Cw)
+    assert ops.mlp_split_supported(x, w1, w2)
+    got = ops.mlp_split(x, w1, b1, w2, b2, act, lnp)
+    assert torch.equal(got, ops.mlp_split(x, w1, b1, w2, b2, act, lnp))
+    want = _mlp_f64(x, w1, b1, w2, b2, act, lnp)
+    lib = _mlp_f32(x, w1, b1, w2, b2, act, lnp)
+    scale = float(want.abs().max())
+    e_k, e_lib = float((got.double() - want).abs().max()), float((lib.double() - want).abs().max())
+    print(f"K23 {M}x{Cw}x{F} {act}: split {e_k / scale:.2e}  library f32 {e_lib / scale:.2e}")
+    assert e_k < 1e-5 * scale and e_k <= 1.5 * e_lib + 3e-7 * scale, (e_k, e_lib)
+    got_r = ops.mlp_split(x, w1, b1, w2, b2, act, lnp, residual=x)           # the Swin form: x + mlp(norm2(x))
+    assert float((got_r.double() - (want + x.double())).abs().max()) < 1e-5 * max(scale, float(x.abs().max()))
+    w2.mul_(0.5)                                                            # in-place update: the cached image must be rebuilt
+    half = ops.mlp_split(x, w1, b1, w2, b2, act, lnp)
+    assert float((half.double() - _mlp_f64(x, w1, b1, w2, b2, act, lnp)).abs().max()) < 1e-5 * scale
+
+
+@pytest.mark.parametrize("M,Cw,F,cut", [(5792, 256, 2048, (46, 4)), (5792, 256, 2048, (91, 2)), (5792, 256, 2048, (32, 8)),
+                                         (5792, 256, 2048, (200, 1)), (777, 96, 384, (3, 4)), (777, 192, 768, (49, 3)),
+                                         (4099, 128, 512, (7, 2))])
+def test_mlp_split_cuts_agree(ops, M, Cw, F, cut):
+    """Every (workgroup rows, hidden ranges) decomposition gives the result of the plain one to summation-order noise, the
+    split ones deterministically (fixed reduction order), and rows past the last tile are never written."""
+    x, w1, b1, w2, b2, lnp = _mlp_case(M, Cw, F, "gelu", True, 7 * M + Cw)
+    want = _mlp_f64(x, w1, b1, w2, b2, "gelu", lnp, x)
+    scale = float(want.abs().max())
+    buf = torch.full((M + 64, Cw), 12345.0, device="cuda")
+    got = ops.mlp_split(x, w1, b1, w2, b2, "gelu", lnp, residual=x, out=buf[:M], cut=cut)
+    assert float((got.double() - want).abs().max()) < 1e-5 * scale
+    assert torch.equal(got.clone(), ops.mlp_split(x, w1, b1, w2, b2, "gelu", lnp, residual=x, cut=cut))
+    assert bool((buf[M:] == 12345.0).all())
+
+
+@pytest.mark.parametrize("M,cut", [(38560, None), (5792, (46, 4)), (5792, (100, 1)), (17, None)])
+def test_mlp_split_post_layernorm(ops, M, cut):
+    """The encoder form of K23: norm2(src + linear2(relu(linear1(src)))) in one launch (reference
+    models/deformable_transformer.py:253-263), LayerNorm applied by the block kernel's epilogue or, for split hidden ranges,
+    by the reduce kernel."""
+    x, w1, b1, w2, b2, _ = _mlp_case(M, 256, 2048, "relu", False, M)
+    g = torch.Generator().manual_seed(3)
+    gam, bet = (torch.rand(256, generator=g) + 0.5).cuda(), (torch.randn(256, generator=g) * 0.1).cuda()
+    got = ops.mlp_split(x, w1, b1, w2, b2, "relu", residual=x, post_ln=(gam, bet, 1e-5), cut=cut)
+    want = torch.nn.functional.layer_norm(_mlp_f64(x, w1, b1, w2, b2, "relu", None, x), (256,), gam.double(), bet.double(), 1e-5)
+    lib = torch.nn.functional.layer_norm(_mlp_f32(x, w1, b1, w2, b2, "relu", None) + x, (256,), gam, bet, 1e-5)
+    e_k, e_lib = float((got.double() - want).abs().max()), float((lib.double() - want).abs().max())
+    print(f"K23 + norm2, M = {M}: split {e_k:.2e}  library f32 {e_lib:.2e}")
+    assert e_k < 2e-5 and e_k <= 1.5 * e_lib + 1e-6, (e_k, e_lib)
+    assert torch.equal(got, ops.mlp_split(x, w1, b1, w2, b2, "relu", residual=x, post_ln=(gam, bet, 1e-5), cut=cut))
