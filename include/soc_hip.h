@@ -257,11 +257,11 @@ int soc_ffn_split_f32(const float* x, const void* packed, const float* b1, const
  * Mlp.forward :24-37: norm2, fc1, nn.GELU, fc2, the residual add) and, as K22 does, linear1 -> ReLU -> linear2 of
  * DeformableTransformerEncoderLayer.forward_ffn (models/deformable_transformer.py:253-263) with the residual add and norm2
  * behind it (post_gamma / post_beta: `src = norm2(src + dropout3(src2))`, :261-262).  The [M, F] hidden tensor is
- * never written.  Every row is taken: whole rounds of the chip stream both weight matrices once per 8 (C > 96) or 16
- * (C <= 96) row tiles of 16 per CU; a short last round, or a short input altogether, is cut over `nfs` hidden ranges whose
+ * never written.  Every row is taken: whole rounds of the chip stream both weight matrices once per 16 (C <= 96), 8
+ * (C <= 256) or 4 (C = 384) row tiles of 16 per CU; a short last round, or a short input altogether, is cut over `nfs` hidden ranges whose
  * partial sums a second kernel adds in a fixed order (deterministic).
  *   x [M, C], w1 [F, C], b1 [F], w2 [C, F], b2 [C], ln_gamma / ln_beta [C] or both NULL, residual [M, C] or NULL,
- *   post_gamma / post_beta [C] or both NULL, out [M, C]; C in {96, 128, 192, 256}, F % 32 == 0; every pointer 16-byte aligned.
+ *   post_gamma / post_beta [C] or both NULL, out [M, C]; C in {96, 128, 192, 256, 384}, F % 32 == 0; every pointer 16-byte aligned.
  *   soc_mlp_split_packed_bytes / soc_mlp_split_pack_f32: split and lay out both weights ONCE (opaque image `packed`);
  *   re-pack after the weights change.  soc_mlp_split_workspace_bytes: scratch for the partial sums (0 when none are needed).
  *   soc_mlp_split_plan: the (workgroup rows, hidden ranges) cut chosen for M rows taken as ONE launch.

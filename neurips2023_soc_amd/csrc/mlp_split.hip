@@ -33,15 +33,14 @@
 namespace {
 
 using namespace soc_split;
-constexpr int THREADS = 512;
+constexpr int MAX_THREADS = 512;       // the image pads a block to whole DMA rounds of 512 threads (256-thread forms take two)
 
 template <int C>
 struct Geo {
     static constexpr int KS = C / 32;                                   // k-steps of the first product
     static constexpr int OT = C / 16;                                   // output tiles of the second product
     static constexpr int BLK_U4 = OT * 3 * 64;                          // 16-B pieces of a weight block (W1: 2 KS groups, W2: OT)
-    static constexpr int PIECES = (BLK_U4 + THREADS - 1) / THREADS;     // LDS-DMA instructions per thread and block
-    static constexpr int BLKP_U4 = PIECES * THREADS;                    // a block in the image / a ring slot (whole DMA rounds)
+    static constexpr int BLKP_U4 = (BLK_U4 + MAX_THREADS - 1) / MAX_THREADS * MAX_THREADS;     // a block in the image / a ring slot
     static_assert(2 * KS == OT, "both block kinds hold the same number of fragment groups");
 };
 
@@ -51,30 +50,36 @@ __device__ __forceinline__ void handoff() {        // my part of the next block 
 }
 
 // DBG (diagnostics only) bit 0: no LDS-DMA inside the block loop, bit 1: no MFMA work (stream ceiling), bit 2: no fragment
-// reads after a block's first group, bit 3: no activation.  STAG: waves 4..7 run one block behind.  PF: fragment groups read ahead.
-template <int C, int ACT, bool HAS_LN, int RT, int NSLOT, int STAG, int PF, int DBG>
-__global__ __launch_bounds__(THREADS, 2) void mlp_split_kernel(
+// reads after a piece's first group, bit 3: no activation.  PF: fragment groups read ahead.
+// NW waves per workgroup: 8 (two per SIMD, 256 registers each) or 4 (one per SIMD, 512 registers: wider rows or more row tiles
+// per wave, so that a weight fragment read from LDS feeds more MFMAs).  RT row tiles per wave.
+template <int C, int ACT, bool HAS_LN, int NW, int RT, int NSLOT, int SB, int PF, int DBG>
+__global__ __launch_bounds__(NW * 64, NW / 4) void mlp_split_kernel(
     const float* __restrict__ x, const u32x4* __restrict__ img, const float* __restrict__ b1, const float* __restrict__ b2,
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps, const float* __restrict__ res,
     const float* __restrict__ gamma2, const float* __restrict__ beta2, float eps2, float* __restrict__ out, long M, int F,
     int nrg, int nfs) {
     using G = Geo<C>;
-    constexpr int KS = G::KS, OT = G::OT, P = G::PIECES, BLKP = G::BLKP_U4;
-    constexpr int D = NSLOT - 1 - STAG;                                 // blocks in flight ahead of the one being consumed
+    constexpr int THREADS = NW * 64;
+    // a block travels in SB ring pieces (a piece = a slot = one DMA round set): P LDS-DMA instructions per thread and piece
+    constexpr int KS = G::KS, OT = G::OT, BLKP = G::BLKP_U4, SLOT = BLKP / SB, P = SLOT / THREADS;
+    static_assert(OT % SB == 0 && SLOT % THREADS == 0 && (SB == 1 || BLKP == G::BLK_U4), "pieces are whole fragment groups");
+    constexpr int D = NSLOT - 1;                                        // pieces in flight ahead of the one being consumed
     static_assert(D >= 1 && (D - 1) * P < 64, "ring depth");
     extern __shared__ __attribute__((aligned(16))) u32x4 lds[];
     u32x4* slots = lds;
-    float* gs = reinterpret_cast<float*>(lds + NSLOT * BLKP);           // gamma [C], beta [C], then this range's b1
+    float* gs = reinterpret_cast<float*>(lds + NSLOT * SLOT);           // gamma [C], beta [C], then this range's b1
     float* bs = gs + C;
     float* b1s = bs + C;
     asm volatile("v_mov_b32 v255, 0" ::: "v255");                       // own the CU
+    if (NW == 4) asm volatile("v_accvgpr_write_b32 a255, 0" ::: "a255");   // one wave per SIMD: the whole 512-entry file
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, kq = lane >> 4;
     const int fs = blockIdx.x % nfs, g = blockIdx.x / nfs;              // blocks b and b + 8 share an XCD: with nfs | 8 an XCD
     const int NC = F / 32;                                              // streams one hidden range only
     const int c0 = (int)((long)fs * NC / nfs), c1 = (int)((long)(fs + 1) * NC / nfs);
-    const int nb = 2 * (c1 - c0);
+    const int nb = 2 * (c1 - c0), nq = nb * SB;                         // blocks / ring pieces of this range
     const long ntiles = (M + 15) >> 4;
     const long t0 = (long)g * ntiles / nrg, t1 = (long)(g + 1) * ntiles / nrg;
     float* o = out + (nfs > 1 ? (long)fs * M * C : 0);
@@ -88,9 +93,9 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_split_kernel(
     const char* ibase = reinterpret_cast<const char*>(img + (long)c0 * 2 * BLKP);
     const unsigned voff = (unsigned)tid * 16u;
     const unsigned lds_slots = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)slots + (unsigned)wave * 1024u;
-    auto dma = [&](int blk, int slot) {
-        const char* src = ibase + (long)blk * (BLKP * 16);
-        const unsigned dst = lds_slots + (unsigned)slot * (BLKP * 16);
+    auto dma = [&](int piece, int slot) {
+        const char* src = ibase + (long)piece * (SLOT * 16);
+        const unsigned dst = lds_slots + (unsigned)slot * (SLOT * 16);
 #pragma unroll
         for (int u = 0; u < P; ++u)
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
@@ -100,16 +105,15 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_split_kernel(
     __syncthreads();
     // One pass = up to 8 RT row tiles through the whole hidden range.  NRT (compile time) = this wave's tiles in the pass:
     // the accumulator updates are straight-line code for every count, a wave without tiles only feeds the ring.
-    auto pass = [&](auto nrt_c, auto late_c, long pt) {
+    auto pass = [&](auto nrt_c, long pt) {
         constexpr int NRT = decltype(nrt_c)::value;
-        constexpr bool LATE = decltype(late_c)::value;
         constexpr int NX = NRT > 0 ? NRT : 1;
         bf16x8 xb[NX][KS][3];
         {
             float4 xn[NX][KS][2];
 #pragma unroll
             for (int rt = 0; rt < NRT; ++rt) {
-                const long m = min((pt + 8 * rt + wave) * 16 + r, M - 1);
+                const long m = min((pt + NW * rt + wave) * 16 + r, M - 1);
                 const float4* xp = reinterpret_cast<const float4*>(x + m * C + 8 * kq);
 #pragma unroll
                 for (int s = 0; s < KS; ++s) { xn[rt][s][0] = xp[8 * s]; xn[rt][s][1] = xp[8 * s + 1]; }
@@ -117,7 +121,7 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_split_kernel(
             int ps = 0;
 #pragma unroll
             for (int b = 0; b < D; ++b)
-                if (b < nb) { dma(b, ps); ps = next_slot(ps); }
+                if (b < nq) { dma(b, ps); ps = next_slot(ps); }
 #pragma unroll
             for (int rt = 0; rt < NRT; ++rt) {
                 float v[KS][8];
@@ -165,102 +169,115 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_split_kernel(
 #pragma unroll
             for (int ot = 0; ot < OT; ++ot) acc2[rt][ot] = (f32x4){0.f, 0.f, 0.f, 0.f};
         f32x4 acc1[NX][2];          // a chunk of the hidden layer between its two blocks: H^T tiles j = 0, 1, bias included
-        // ---- the two kinds of block.  Fragment groups are read PF groups ahead of the MFMAs that consume them.
+        bf16x8 hb[NX][3];           // ... and once activated and split: the B operand of the second product
+        // ---- the two kinds of block, one ring piece (1 / SB of a block: NGS fragment groups) at a time.  Fragment groups are
+        // read PF groups ahead of the MFMAs that consume them.
+        constexpr int NGS = OT / SB;
         auto frag = [&](bf16x8 (&wf)[3], const u32x4* wl, int gi) {
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) wf[pl] = __builtin_bit_cast(bf16x8, wl[(gi * 3 + pl) * 64]);
         };
-        // W1 block `blk` (even) in slot `sl`: hidden columns [16 blk, 16 blk + 32) of this range; groups (j, s), j = hidden tile
-        auto first = [&](int blk, int sl) {
+        // piece `sb` of W1 block `blk` (even) in slot `sl`: hidden columns [16 blk, 16 blk + 32) of this range; fragment groups
+        // (j, s) = (g / KS, g % KS), j = hidden tile
+        auto first = [&](int blk, auto sb_c, int sl) {
+            constexpr int sb = decltype(sb_c)::value;
             if ((DBG & 2) || NRT == 0) return;
-            // the accumulators start from b1 (lane (r, kq) holds hidden columns 4 kq .. + 3 of each tile)
-            const f32x4* bp = reinterpret_cast<const f32x4*>(b1s + 16 * blk + 4 * kq);
-            const f32x4 bq0 = bp[0], bq1 = bp[4];
-            const u32x4* wl = slots + sl * BLKP + lane;
+            const u32x4* wl = slots + sl * SLOT + lane;
+            if (sb == 0) {      // the accumulators start from b1 (lane (r, kq) holds hidden columns 4 kq .. + 3 of each tile)
+                const f32x4* bp = reinterpret_cast<const f32x4*>(b1s + 16 * blk + 4 * kq);
+                const f32x4 bq0 = bp[0], bq1 = bp[4];
 #pragma unroll
-            for (int rt = 0; rt < NRT; ++rt) { acc1[rt][0] = bq0; acc1[rt][1] = bq1; }
-            constexpr int NG = 2 * KS;
+                for (int rt = 0; rt < NRT; ++rt) { acc1[rt][0] = bq0; acc1[rt][1] = bq1; }
+            }
             bf16x8 wf[PF + 1][3];
 #pragma unroll
             for (int q = 0; q < PF; ++q) frag(wf[q], wl, q);
 #pragma unroll
-            for (int gi = 0; gi < NG; ++gi) {
-                if (gi + PF < NG && !((DBG & 4) && gi > 0)) frag(wf[(gi + PF) % (PF + 1)], wl, gi + PF);
-                const int j = gi / KS, s = gi % KS;
+            for (int gi = 0; gi < NGS; ++gi) {
+                if (gi + PF < NGS && !((DBG & 4) && gi > 0)) frag(wf[(gi + PF) % (PF + 1)], wl, gi + PF);
+                const int g = sb * NGS + gi, j = g / KS, s = g % KS;
                 const int cur = (DBG & 4) ? 0 : gi % (PF + 1);
 #pragma unroll
                 for (int rt = 0; rt < NRT; ++rt) mfma6(acc1[rt][j], wf[cur], xb[rt][s][0], xb[rt][s][1], xb[rt][s][2]);
                 // the reads go out in front of this group's MFMAs; PF groups ahead, not all of them
-                if (gi + PF < NG && !(DBG & 4)) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                if (gi + PF < NGS && !(DBG & 4)) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 6 * NRT, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
-        // W2 block in slot `sl`: activation and split of the chunk (vector ALU: with the stagger it runs beside the partner
-        // wave's first product), then every output tile gets the chunk's 32 hidden columns
-        auto second = [&](int sl) {
+        // piece `sb` of a W2 block in slot `sl`: (activation and split of the chunk first), then its output tiles get the
+        // chunk's 32 hidden columns
+        auto second = [&](auto sb_c, int sl) {
+            constexpr int sb = decltype(sb_c)::value;
             if ((DBG & 2) || NRT == 0) return;
-            const u32x4* wl = slots + sl * BLKP + lane;
+            const u32x4* wl = slots + sl * SLOT + lane;
             bf16x8 wf[PF + 1][3];
 #pragma unroll
             for (int q = 0; q < PF; ++q) frag(wf[q], wl, q);
-            bf16x8 hb[NX][3];
+            if (sb == 0) {
 #pragma unroll
-            for (int rt = 0; rt < NRT; ++rt) {
-                float v[8];
+                for (int rt = 0; rt < NRT; ++rt) {
+                    float v[8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = acc1[rt][i >> 2][i & 3];
-                if (DBG & 8) {
-                } else if (ACT == 1) {
+                    for (int i = 0; i < 8; ++i) v[i] = acc1[rt][i >> 2][i & 3];
+                    if (DBG & 8) {
+                    } else if (ACT == 1) {
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
-                } else {
-                    const GeluK gk = gelu_k();
+                        for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
+                    } else {
+                        const GeluK gk = gelu_k();
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) v[i] = gelu_erf(v[i], gk);
+                        for (int i = 0; i < 8; ++i) v[i] = gelu_erf(v[i], gk);
+                    }
+                    split8(v, hb[rt][0], hb[rt][1], hb[rt][2]);
                 }
-                split8(v, hb[rt][0], hb[rt][1], hb[rt][2]);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int ot = 0; ot < OT; ++ot) {
-                if (ot + PF < OT && !((DBG & 4) && ot > 0)) frag(wf[(ot + PF) % (PF + 1)], wl, ot + PF);
-                const int cur = (DBG & 4) ? 0 : ot % (PF + 1);
+            for (int gi = 0; gi < NGS; ++gi) {
+                if (gi + PF < NGS && !((DBG & 4) && gi > 0)) frag(wf[(gi + PF) % (PF + 1)], wl, gi + PF);
+                const int ot = sb * NGS + gi;
+                const int cur = (DBG & 4) ? 0 : gi % (PF + 1);
 #pragma unroll
                 for (int rt = 0; rt < NRT; ++rt) mfma6(acc2[rt][ot], wf[cur], hb[rt][0], hb[rt][1], hb[rt][2]);
-                if (ot + PF < OT && !(DBG & 4)) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                if (gi + PF < NGS && !(DBG & 4)) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 6 * NRT, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
-        if (nb >= D) handoff<(D - 1) * P>(); else handoff<0>();         // block 0 has landed
-        // time step t: waves 0..3 work on block t; with the stagger waves 4..7 work on block t - 1 (its slot: `pslot`)
-        int slot = 0, pslot = 0, dslot = D % NSLOT;
-        for (int blk = 0; blk < nb; blk += 2) {
-            bool more = blk + D < nb;
-            if (!(DBG & 1) && more) { dma(blk + D, dslot); dslot = next_slot(dslot); }
-            if (!LATE) first(blk, slot);
-            else if (blk > 0) second(pslot);
-            if (more) handoff<(D - 1) * P>(); else handoff<0>();        // the W2 block has landed
-            pslot = slot;
-            slot = next_slot(slot);
-            more = blk + 1 + D < nb;
-            if (!(DBG & 1) && more) { dma(blk + 1 + D, dslot); dslot = next_slot(dslot); }
-            if (!LATE) second(slot);
-            else first(blk, pslot);
-            if (blk + 2 < nb) {
-                if (more) handoff<(D - 1) * P>(); else handoff<0>();    // the next W1 block has landed
+        if (nq >= D) handoff<(D - 1) * P>(); else handoff<0>();         // piece 0 has landed
+        int slot = 0, dslot = D % NSLOT, q = 0;                         // the slot being consumed / the slot the next DMA fills
+        // one ring step: the piece D ahead goes out, this piece is consumed, the next one is waited for
+        auto step = [&](auto&& work) {
+            const bool more = q + D < nq;
+            if (!(DBG & 1) && more) { dma(q + D, dslot); dslot = next_slot(dslot); }
+            work(slot);
+            if (q + 1 < nq) {
+                if (more) handoff<(D - 1) * P>(); else handoff<0>();
             }
-            pslot = slot;
             slot = next_slot(slot);
+            ++q;
+        };
+        for (int blk = 0; blk < nb; blk += 2) {
+            step([&](int sl) { first(blk, std::integral_constant<int, 0>{}, sl); });
+            if constexpr (SB >= 2) step([&](int sl) { first(blk, std::integral_constant<int, 1>{}, sl); });
+            if constexpr (SB >= 4) {
+                step([&](int sl) { first(blk, std::integral_constant<int, 2>{}, sl); });
+                step([&](int sl) { first(blk, std::integral_constant<int, 3>{}, sl); });
+            }
+            step([&](int sl) { second(std::integral_constant<int, 0>{}, sl); });
+            if constexpr (SB >= 2) step([&](int sl) { second(std::integral_constant<int, 1>{}, sl); });
+            if constexpr (SB >= 4) {
+                step([&](int sl) { second(std::integral_constant<int, 2>{}, sl); });
+                step([&](int sl) { second(std::integral_constant<int, 3>{}, sl); });
+            }
         }
-        if (LATE) second(pslot);
         // ---- lane (r, kq) holds out[m][16 ot + 4 kq .. + 3] of its tiles.  b2 and the residual are added LAST, to the finished
         // sum of products (starting the accumulators from them would round every product at the residual's magnitude); the
         // loads of a tile go out together
 #pragma unroll
         for (int rt = 0; rt < NRT; ++rt) {
-            const long m = (pt + 8 * rt + wave) * 16 + r;
+            const long m = (pt + NW * rt + wave) * 16 + r;
             if (m < M) {
                 long mo = m * C + 4 * kq;
                 asm volatile("" : "+v"(mo));       // worked out here, not carried through the block loop
@@ -309,66 +326,79 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_split_kernel(
             }
         }
     };
-    const bool late = STAG && wave >= 4;
-    for (long pt = t0; pt < t1; pt += 8 * RT) {
+    for (long pt = t0; pt < t1; pt += NW * RT) {
         if (pt != t0) handoff<0>();                 // nobody still reads the slots the next pass's prologue refills
-        // this wave's row tiles: pt + 8 rt + wave (a part-filled pass leaves the second tile of a wave empty first)
-        const int nrt = (RT == 2 && pt + 8 + wave < t1) ? 2 : (pt + wave < t1 ? 1 : 0);
-        if (STAG && late) {
-            if (RT == 2 && nrt == 2) pass(std::integral_constant<int, RT>{}, std::integral_constant<bool, STAG != 0>{}, pt);
-            else if (nrt == 1) pass(std::integral_constant<int, 1>{}, std::integral_constant<bool, STAG != 0>{}, pt);
-            else pass(std::integral_constant<int, 0>{}, std::integral_constant<bool, STAG != 0>{}, pt);
-        } else {
-            if (RT == 2 && nrt == 2) pass(std::integral_constant<int, RT>{}, std::false_type{}, pt);
-            else if (nrt == 1) pass(std::integral_constant<int, 1>{}, std::false_type{}, pt);
-            else pass(std::integral_constant<int, 0>{}, std::false_type{}, pt);
-        }
+        // this wave's row tiles: pt + NW rt + wave (a part-filled pass leaves the later tiles of a wave empty first)
+        int nrt = 0;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+            if (pt + NW * rt + wave < t1) nrt = rt + 1;
+        if (RT >= 4 && nrt == 4) pass(std::integral_constant<int, RT >= 4 ? 4 : 0>{}, pt);
+        else if (RT >= 3 && nrt == 3) pass(std::integral_constant<int, RT >= 3 ? 3 : 0>{}, pt);
+        else if (RT >= 2 && nrt == 2) pass(std::integral_constant<int, RT >= 2 ? 2 : 0>{}, pt);
+        else if (nrt == 1) pass(std::integral_constant<int, 1>{}, pt);
+        else pass(std::integral_constant<int, 0>{}, pt);
     }
     __syncthreads();        // the waves retire together
 }
 
-// out = [LayerNorm](sum over the hidden ranges (fixed order) + b2 (+ residual)); a wave per row, a float4 per lane
+// out = [LayerNorm](sum over the hidden ranges (fixed order) + b2 (+ residual)); a wave per row, up to two float4 per lane
 __global__ __launch_bounds__(256) void mlp_reduce_kernel(const float* __restrict__ part, int nfs, const float* __restrict__ b2,
                                                          const float* __restrict__ res, const float* __restrict__ gamma2,
                                                          const float* __restrict__ beta2, float eps2, float* __restrict__ out,
                                                          long M, int C) {
     const int lane = threadIdx.x & 63;
-    const bool on = lane < C / 4;
     const long n4 = M * C / 4;
     for (long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6); m < M; m += (long)gridDim.x * 4) {
-        const long i = m * (C / 4) + lane;
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (on) {
-            a = reinterpret_cast<const float4*>(part)[i];
-            for (int f = 1; f < nfs; ++f) {
-                const float4 p = reinterpret_cast<const float4*>(part)[(long)f * n4 + i];
-                a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w;
-            }
-            const float4 bq = *reinterpret_cast<const float4*>(b2 + 4 * lane);
-            a.x += bq.x; a.y += bq.y; a.z += bq.z; a.w += bq.w;
-            if (res) {
-                const float4 rr = reinterpret_cast<const float4*>(res)[i];
-                a.x += rr.x; a.y += rr.y; a.z += rr.z; a.w += rr.w;
+        float4 a[2];
+        bool on[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int c4 = lane + 64 * h;
+            on[h] = c4 < C / 4;
+            a[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (on[h]) {
+                const long i = m * (C / 4) + c4;
+                a[h] = reinterpret_cast<const float4*>(part)[i];
+                for (int f = 1; f < nfs; ++f) {
+                    const float4 p = reinterpret_cast<const float4*>(part)[(long)f * n4 + i];
+                    a[h].x += p.x; a[h].y += p.y; a[h].z += p.z; a[h].w += p.w;
+                }
+                const float4 bq = *reinterpret_cast<const float4*>(b2 + 4 * c4);
+                a[h].x += bq.x; a[h].y += bq.y; a[h].z += bq.z; a[h].w += bq.w;
+                if (res) {
+                    const float4 rr = reinterpret_cast<const float4*>(res)[i];
+                    a[h].x += rr.x; a[h].y += rr.y; a[h].z += rr.z; a[h].w += rr.w;
+                }
             }
         }
         if (gamma2) {
-            float sm = (a.x + a.y) + (a.z + a.w);
+            float sm = ((a[0].x + a[0].y) + (a[0].z + a[0].w)) + ((a[1].x + a[1].y) + (a[1].z + a[1].w));
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) sm += __shfl_xor(sm, d);
             const float mean = sm / C;
-            if (on) { a.x -= mean; a.y -= mean; a.z -= mean; a.w -= mean; }
-            float q = a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
+            float q = 0.f;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                if (on[h]) {
+                    a[h].x -= mean; a[h].y -= mean; a[h].z -= mean; a[h].w -= mean;
+                    q += a[h].x * a[h].x + a[h].y * a[h].y + a[h].z * a[h].z + a[h].w * a[h].w;
+                }
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) q += __shfl_xor(q, d);
             const float rstd = rsqrtf(q / C + eps2);
-            if (on) {
-                const float4 g2 = *reinterpret_cast<const float4*>(gamma2 + 4 * lane);
-                const float4 e2 = *reinterpret_cast<const float4*>(beta2 + 4 * lane);
-                a.x = fmaf(a.x * rstd, g2.x, e2.x); a.y = fmaf(a.y * rstd, g2.y, e2.y);
-                a.z = fmaf(a.z * rstd, g2.z, e2.z); a.w = fmaf(a.w * rstd, g2.w, e2.w);
-            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                if (on[h]) {
+                    const float4 g2 = *reinterpret_cast<const float4*>(gamma2 + 4 * (lane + 64 * h));
+                    const float4 e2 = *reinterpret_cast<const float4*>(beta2 + 4 * (lane + 64 * h));
+                    a[h].x = fmaf(a[h].x * rstd, g2.x, e2.x); a[h].y = fmaf(a[h].y * rstd, g2.y, e2.y);
+                    a[h].z = fmaf(a[h].z * rstd, g2.z, e2.z); a[h].w = fmaf(a[h].w * rstd, g2.w, e2.w);
+                }
         }
-        if (on) reinterpret_cast<float4*>(out)[i] = a;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            if (on[h]) reinterpret_cast<float4*>(out)[m * (C / 4) + lane + 64 * h] = a[h];
     }
 }
 
@@ -414,12 +444,17 @@ int num_cus() {
     return 256;
 }
 
-constexpr int rows_per_wave(int C) { return C <= 96 ? 2 : 1; }       // RT: x fragments + output accumulators must fit 256 VGPRs
+// The shipped form of a width: waves per workgroup and row tiles per wave.  256-register waves (NW = 8) hold the x fragments
+// (3 C / 8 registers per tile) and the output accumulators (C / 4 per tile) of RT tiles up to C = 256; C = 384 needs the 512
+// registers of a one-wave-per-SIMD workgroup.
+constexpr int form_nw(int C) { return C > 256 ? 4 : 8; }
+constexpr int form_rt(int C) { return C <= 96 ? 2 : 1; }
+constexpr int tiles_per_pass(int C) { return form_nw(C) * form_rt(C); }
 
 template <int C>
-size_t lds_bytes(int nslot, int F, int nfs) {
+size_t lds_bytes(int nslot, int sb, int F, int nfs) {
     const int nc = (F / 32 + nfs - 1) / nfs;
-    return (size_t)nslot * Geo<C>::BLKP_U4 * 16 + 8 * C + (size_t)nc * 128;
+    return (size_t)nslot * (Geo<C>::BLKP_U4 / sb) * 16 + 8 * C + (size_t)nc * 128;
 }
 
 struct Args {
@@ -433,11 +468,10 @@ struct Args {
     hipStream_t st;
 };
 
-template <int C, int ACT, bool HAS_LN, int NSLOT, int STAG, int PF, int DBG>
+template <int C, int ACT, bool HAS_LN, int NW, int RT, int NSLOT, int SB, int PF, int DBG>
 int launch(const Args& a) {
-    constexpr int RT = rows_per_wave(C);
-    const void* fn = reinterpret_cast<const void*>(mlp_split_kernel<C, ACT, HAS_LN, RT, NSLOT, STAG, PF, DBG>);
-    const size_t lds = lds_bytes<C>(NSLOT, a.F, a.nfs);
+    const void* fn = reinterpret_cast<const void*>(mlp_split_kernel<C, ACT, HAS_LN, NW, RT, NSLOT, SB, PF, DBG>);
+    const size_t lds = lds_bytes<C>(NSLOT, SB, a.F, a.nfs);
     if (lds > 160 * 1024) return SOC_EUNSUPPORTED;
     static std::atomic<bool> attr_set[SOC_MAX_DEVICES];
     const int dev = soc_current_device();
@@ -446,24 +480,42 @@ int launch(const Args& a) {
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return SOC_ELAUNCH;
         attr_set[dev].store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL((mlp_split_kernel<C, ACT, HAS_LN, RT, NSLOT, STAG, PF, DBG>), dim3((unsigned)(a.nrg * a.nfs)), dim3(THREADS),
-                       lds, a.st, a.x, a.img, a.b1, a.b2, a.gamma, a.beta, a.eps, a.res, a.gamma2, a.beta2, a.eps2, a.out, a.M, a.F, a.nrg,
-                       a.nfs);
+    hipLaunchKernelGGL((mlp_split_kernel<C, ACT, HAS_LN, NW, RT, NSLOT, SB, PF, DBG>), dim3((unsigned)(a.nrg * a.nfs)),
+                       dim3(NW * 64), lds, a.st, a.x, a.img, a.b1, a.b2, a.gamma, a.beta, a.eps, a.res, a.gamma2, a.beta2, a.eps2,
+                       a.out, a.M, a.F, a.nrg, a.nfs);
     return soc_check_launch();
 }
 
-// variant = NSLOT + 8 * STAG + 16 * DBG + 256 * (PF - 1); 0 = the shipped choice for the width
+// The ring of a width: a block of C <= 256 is one piece, three or four slots; the 72-KB blocks of C = 384 travel as halves (36 KB)
+// through four slots -- two whole-block slots would leave one block in flight, too little to cover the L2 latency.
+constexpr int form_sb(int C) { return C > 256 ? 2 : 1; }
+template <int C>
+constexpr int form_ns() {
+    constexpr int ns = (160 * 1024 - 8 * C - 4096) / (Geo<C>::BLKP_U4 / form_sb(C) * 16);     // slots beside a 1024-wide b1 range
+    return ns >= 4 ? 4 : ns;
+}
+
+// variant = NSLOT + 8 * log2(SB) + 32 * DBG + 512 * (PF - 1) + 1024 * form (1: 4 waves x 1 tile, 2: 4 x 2, 3: 4 x 4, 4: 8 x 1,
+// 5: 8 x 2); 0 = the shipped choice for the width
 template <int C, int ACT, bool HAS_LN>
 int launch_variant(const Args& a, int variant) {
-    constexpr int NS_MAX = (160 * 1024 - 8 * C - 4096) / (Geo<C>::BLKP_U4 * 16);    // ring slots that fit beside a 1024-wide b1 range
-    constexpr int NS_DEF = NS_MAX >= 4 ? 4 : NS_MAX;
-    static_assert(NS_DEF >= 3, "three slots at least");
-    if (variant == 0) return launch<C, ACT, HAS_LN, NS_DEF, 0, 1, 0>(a);
+    static_assert(form_ns<C>() >= 3, "three slots at least");
+    if (variant == 0) return launch<C, ACT, HAS_LN, form_nw(C), form_rt(C), form_ns<C>(), form_sb(C), 1, 0>(a);
 #ifdef SOC_K23_VARIANTS         // diagnostic build (tools/experiments/k23_time.py)
-#define V(NS, ST, PFD, DB) case NS + 8 * ST + 16 * DB + 256 * (PFD - 1): return launch<C, ACT, HAS_LN, NS, ST, PFD, DB>(a);
+#define V(FORM, NW_, RT_, NS, LSB, PFD, DB)                                                                      \
+    case NS + 8 * LSB + 32 * DB + 512 * (PFD - 1) + 1024 * FORM:                                                 \
+        if constexpr ((size_t)NS * (Geo<C>::BLKP_U4 >> LSB) * 16 + 8 * C + 4096 <= 160 * 1024 &&                 \
+                      (Geo<C>::OT >> LSB) >= 1 && (LSB == 0 || Geo<C>::BLKP_U4 == Geo<C>::BLK_U4) &&             \
+                      (Geo<C>::BLKP_U4 >> LSB) % (NW_ * 64) == 0 &&                                              \
+                      (3 * C / 8 + C / 4) * RT_ + 40 <= (NW_ == 8 ? 256 : 512))                                  \
+            return launch<C, ACT, HAS_LN, NW_, RT_, NS, (1 << LSB), PFD, DB>(a);                                 \
+        else break;
+    constexpr int NW0 = form_nw(C), RT0 = form_rt(C);
     switch (variant) {
-        V(2, 0, 1, 0) V(3, 0, 1, 0) V(3, 1, 1, 0) V(3, 0, 2, 0) V(3, 1, 2, 0)
-        V(3, 0, 1, 1) V(3, 0, 1, 2) V(3, 0, 1, 4) V(3, 0, 1, 8) V(3, 0, 1, 12) V(3, 0, 1, 13) V(3, 1, 1, 13) V(3, 1, 1, 1)
+        V(0, NW0, RT0, 2, 0, 1, 0) V(0, NW0, RT0, 3, 0, 1, 0) V(0, NW0, RT0, 4, 1, 1, 0) V(0, NW0, RT0, 3, 1, 1, 0)
+        V(0, NW0, RT0, 4, 1, 2, 0) V(0, NW0, RT0, 6, 2, 1, 0) V(0, NW0, RT0, 7, 2, 1, 0)
+        V(0, NW0, RT0, 3, 0, 1, 1) V(0, NW0, RT0, 3, 0, 1, 2) V(0, NW0, RT0, 3, 0, 1, 13) V(0, NW0, RT0, 4, 1, 1, 1)
+        V(0, NW0, RT0, 4, 1, 1, 2) V(0, NW0, RT0, 4, 1, 1, 13)
         default: break;
     }
 #undef V
@@ -473,7 +525,7 @@ int launch_variant(const Args& a, int variant) {
 
 template <int C>
 int launch_c(const Args& a, int act, int variant) {
-#ifdef SOC_K23_VARIANTS         // the diagnostic build instantiates the two forms the model uses only
+#ifdef SOC_K23_VARIANTS         // the diagnostic build instantiates the forms the model uses only
     if (act == 1 && !a.gamma) return launch_variant<C, 1, false>(a, variant);
     if (act == 2 && a.gamma) return launch_variant<C, 2, true>(a, variant);
 #else
@@ -483,7 +535,7 @@ int launch_c(const Args& a, int act, int variant) {
     return SOC_EUNSUPPORTED;
 }
 
-bool width_ok(int C) { return C == 96 || C == 128 || C == 192 || C == 256; }
+bool width_ok(int C) { return C == 96 || C == 128 || C == 192 || C == 256 || C == 384; }
 
 template <int C> size_t packed_bytes(int F) { return (size_t)(F / 32) * 2 * Geo<C>::BLKP_U4 * 16; }
 
@@ -495,7 +547,8 @@ extern "C" size_t soc_mlp_split_packed_bytes(int C, int F) {
         case 96: return packed_bytes<96>(F);
         case 128: return packed_bytes<128>(F);
         case 192: return packed_bytes<192>(F);
-        default: return packed_bytes<256>(F);
+        case 256: return packed_bytes<256>(F);
+        default: return packed_bytes<384>(F);
     }
 }
 
@@ -510,7 +563,8 @@ extern "C" int soc_mlp_split_pack_f32(const float* w1, const float* w2, void* pa
         case 96: hipLaunchKernelGGL(mlp_pack_kernel<96>, dim3(blocks), dim3(256), 0, st, w1, w2, img, F); break;
         case 128: hipLaunchKernelGGL(mlp_pack_kernel<128>, dim3(blocks), dim3(256), 0, st, w1, w2, img, F); break;
         case 192: hipLaunchKernelGGL(mlp_pack_kernel<192>, dim3(blocks), dim3(256), 0, st, w1, w2, img, F); break;
-        default: hipLaunchKernelGGL(mlp_pack_kernel<256>, dim3(blocks), dim3(256), 0, st, w1, w2, img, F); break;
+        case 256: hipLaunchKernelGGL(mlp_pack_kernel<256>, dim3(blocks), dim3(256), 0, st, w1, w2, img, F); break;
+        default: hipLaunchKernelGGL(mlp_pack_kernel<384>, dim3(blocks), dim3(256), 0, st, w1, w2, img, F); break;
     }
     return soc_check_launch();
 }
@@ -520,7 +574,7 @@ extern "C" int soc_mlp_split_pack_f32(const float* w1, const float* w2, void* pa
 // chip; nfs is a power of two <= 8 (an XCD then streams one range only).
 static void plan_rows(long M, int C, int F, int cus, int* nrg_out, int* nfs_out) {
     const long ntiles = (M + 15) >> 4;
-    const int per_pass = 8 * rows_per_wave(C);
+    const int per_pass = tiles_per_pass(C);
     const long groups = (ntiles + per_pass - 1) / per_pass;             // workgroup passes if every pass were full
     int nfs = 1;
     while (nfs < 8 && groups * nfs * 2 <= cus && (F / 32) % (nfs * 2) == 0) nfs *= 2;
@@ -535,7 +589,7 @@ static void plan_rows(long M, int C, int F, int cus, int* nrg_out, int* nfs_out)
 // weight matrices into every CU whatever its fill).  Returns the row where the tail starts (M: no tail).
 static long tail_start(long M, int C, int cus) {
     const long ntiles = (M + 15) >> 4;
-    const long per_round = (long)cus * 8 * rows_per_wave(C);
+    const long per_round = (long)cus * tiles_per_pass(C);
     const long full = ntiles / per_round, rem = ntiles - full * per_round;
     if (full >= 1 && rem > 0 && rem * 5 < per_round * 3) return full * per_round * 16;
     return M;
@@ -581,7 +635,8 @@ extern "C" int soc_mlp_split_variant_f32(const float* x, const void* packed, con
         case 96: rc = launch_c<96>(a, act, variant); break;
         case 128: rc = launch_c<128>(a, act, variant); break;
         case 192: rc = launch_c<192>(a, act, variant); break;
-        default: rc = launch_c<256>(a, act, variant); break;
+        case 256: rc = launch_c<256>(a, act, variant); break;
+        default: rc = launch_c<384>(a, act, variant); break;
     }
     if (rc != SOC_OK || nfs == 1) return rc;
     const int blocks = (int)((M + 3) / 4 > 8192 ? 8192 : (M + 3) / 4);

@@ -1015,13 +1015,13 @@ def ffn_split(x: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor, residua
     return out
 
 
-MLP_SPLIT_C = (96, 128, 192, 256)       # model widths K23 is built for
+MLP_SPLIT_C = (96, 128, 192, 256, 384)  # model widths K23 is built for
 _MLP_ACT = {"relu": 1, "gelu": 2}
 _mlp_cache = {}
 
 
 def mlp_split_supported(x: Tensor, w1: Tensor, w2: Tensor) -> bool:
-    """K23 takes act(LN(x) w1^T + b1) w2^T + b2 (+ residual): CUDA fp32, model width 96 / 128 / 192 / 256, hidden width a
+    """K23 takes act(LN(x) w1^T + b1) w2^T + b2 (+ residual): CUDA fp32, model width 96 / 128 / 192 / 256 / 384, hidden width a
     multiple of 32, split arithmetic on (SOC_SPLIT_OFF=mlp switches it off)."""
     Cw = x.shape[-1]
     return (x.is_cuda and x.dtype == torch.float32 and split_enabled() and "mlp" not in _SPLIT_OFF and Cw in MLP_SPLIT_C

@@ -55,15 +55,17 @@ class WindowAttention3D(nn.Module):
         self.proj = nn.Linear(dim, dim)
         nn.init.trunc_normal_(self.relative_position_bias_table, std=0.02)
 
-    def forward(self, x: torch.Tensor, shift: Sequence[int]) -> torch.Tensor:
-        """x [B,D,H,W,C] (after norm1, un-padded) -> attention branch output [B,D,H,W,C]."""
+    def forward(self, x: torch.Tensor, shift: Sequence[int], residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """x [B,D,H,W,C] (after norm1, un-padded) -> attention branch output [B,D,H,W,C] (+ residual: the block's
+        shortcut, added in the projection's epilogue where K13b runs it)."""
         ws = fused.ws_dense_ok(x, self.qkv.weight)              # stage 2: K13b instead of the library GEMMs
         qkv = hot_ops.ws_linear(x, self.qkv.weight, self.qkv.bias) if ws else self.qkv(x)
         attn = hot_ops.window_attention3d(qkv, self.qkv.bias, self.relative_position_bias_table,
                                           self.num_heads, self.window_size, shift)
         if ws and fused.ws_dense_ok(attn, self.proj.weight):
-            return hot_ops.ws_linear(attn, self.proj.weight, self.proj.bias)
-        return self.proj(attn)
+            return hot_ops.ws_linear(attn, self.proj.weight, self.proj.bias, residual=residual)
+        out = self.proj(attn)
+        return out if residual is None else out + residual
 
 
 class Mlp(nn.Module):
@@ -148,6 +150,18 @@ class BasicLayer(nn.Module):
                     x = x + blk.mlp.fc2(h)
             return x
         _, h = hot_ops.add_layernorm(x, None, blocks[0].norm1.weight, blocks[0].norm1.bias, blocks[0].norm1.eps)
+        if fused.mlp_ok(x, blocks[0].mlp.fc1, blocks[0].mlp.fc2):
+            # stage 2 (C = 384): the shortcut rides in the projection's epilogue, norm2 + fc1 + GELU + fc2 + shortcut are one K23
+            # launch; one LayerNorm pass per block is left (norm1 of the next block)
+            for i, blk in enumerate(blocks):
+                x = blk.attn(h, blk.shift_size, residual=x)
+                m = blk.mlp
+                x = hot_ops.mlp_split(x, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias, "gelu",
+                                      ln=(blk.norm2.weight, blk.norm2.bias, blk.norm2.eps), residual=x)
+                if i + 1 < len(blocks):
+                    nxt = blocks[i + 1].norm1
+                    _, h = hot_ops.add_layernorm(x, None, nxt.weight, nxt.bias, nxt.eps)
+            return x
         for i, blk in enumerate(blocks):
             a = blk.attn(h, blk.shift_size)
             x, h = hot_ops.add_layernorm(x, a, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)

@@ -1271,6 +1271,8 @@ def _mlp_f32(x, w1, b1, w2, b2, act, lnp):
     (115200, 128, 512, "gelu", True),       # Swin-B stage 0
     (28800, 256, 1024, "gelu", True),       # Swin-B stage 1
     (38560, 256, 2048, "relu", False),      # the deformable encoder's feed-forward block: whole round + tail over 4 hidden ranges
+    (7360, 384, 1536, "gelu", True),        # stage 2: four waves of 512 registers, two hidden ranges, half-block ring pieces
+    (29440, 384, 1536, "gelu", True),       # ... at 720p
     (4099, 256, 2048, "relu", False), (17, 256, 2048, "relu", False), (1000, 192, 768, "gelu", True), (33, 96, 384, "relu", True),
     (5000, 96, 64, "gelu", False)])
 def test_mlp_split_vs_f64(ops, M, Cw, F, act, ln):
@@ -1296,7 +1298,8 @@ def test_mlp_split_vs_f64(ops, M, Cw, F, act, ln):
 
 @pytest.mark.parametrize("M,Cw,F,cut", [(5792, 256, 2048, (46, 4)), (5792, 256, 2048, (91, 2)), (5792, 256, 2048, (32, 8)),
                                          (5792, 256, 2048, (200, 1)), (777, 96, 384, (3, 4)), (777, 192, 768, (49, 3)),
-                                         (4099, 128, 512, (7, 2))])
+                                         (4099, 128, 512, (7, 2)), (7360, 384, 1536, (115, 1)), (7360, 384, 1536, (58, 4)),
+                                         (1000, 384, 1536, (16, 3))])
 def test_mlp_split_cuts_agree(ops, M, Cw, F, cut):
     """Every (workgroup rows, hidden ranges) decomposition gives the result of the plain one to summation-order noise, the
     split ones deterministically (fixed reduction order), and rows past the last tile are never written."""

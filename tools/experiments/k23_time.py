@@ -104,45 +104,20 @@ def case(name, M, Cw, F, act, ln, res, cuts, variants):
             torch.cuda.synchronize()
             err = (out.double() - ref).abs().max().item() / scale
             us = t(run, 10 if quick else 20)
-            dbg = (v >> 4) & 15
-            tag = f"  NS={v & 7} STAG={(v >> 3) & 1} PF={(v >> 8) + 1}" + ("" if not dbg else "  [wrong on purpose:" + "".join(
+            dbg = (v >> 5) & 15
+            tag = f"  NS={v & 7} SB={1 << ((v >> 3) & 3)} PF={((v >> 9) & 1) + 1}" + ("" if not dbg else "  [wrong on purpose:" + "".join(
                 n for b, n in ((1, " no DMA in loop"), (2, " no MFMA"), (4, " no fragment reads"), (8, " no activation")) if dbg & b) + "]")
             print(f"{name} M={M} C={Cw} F={F} cut ({nrg},{nfs}) variant {v:3d}: {us:7.1f} us  {fl / us / 1e6:6.1f} TFLOP/s  "
                   f"max err / max|ref| {err:.2e}{tag}", flush=True)
     return x, w1, b1, w2, b2, gam, bet, r, ref, scale
 
 
-V = [0, 2, 3, 3 + 8, 3 + 256, 3 + 8 + 256, 3 + 16, 3 + 32, 3 + 64, 3 + 128, 3 + 192, 3 + 208, 3 + 8 + 208, 3 + 8 + 16]
-if quick:
-    V = [0, 3 + 8, 3 + 256, 3 + 8 + 256]
-# the encoder's feed-forward block: one full round, the whole level, the tail over split hidden ranges
-x, w1, b1, w2, b2, *_ = case("enc", 32768, 256, 2048, "relu", False, True, [(256, 1)], V)
-print(f"   K22 (ffn_split.hip) on the same rows: {t(lambda: hot_ops.ffn_split(x, w1, b1, w2, b2)):.1f} us", flush=True)
-case("enc.tail", 5792, 256, 2048, "relu", False, True, [None, (64, 4)], [0, 3 + 8, 3 + 8 + 256])
-# Video-Swin stages 0 / 1: norm2 + fc1 + GELU + fc2 + residual
-x, w1, b1, w2, b2, gam, bet, r, ref, scale = case("s0", 115200, 96, 384, "gelu", True, True, [(256, 1)], V)
-lnp = (gam, bet, 1e-5)
-two = t(lambda: hot_ops.ws_linear(hot_ops.ws_linear(x, w1, b1, lnp, None, "gelu"), w2, b2, None, r, "none"))
-print(f"   K13b fc1 + GELU, K13b fc2 + residual on the same rows: {two:.1f} us", flush=True)
-x, w1, b1, w2, b2, gam, bet, r, ref, scale = case("s1", 28800, 192, 768, "gelu", True, True, [None], V)
-lnp = (gam, bet, 1e-5)
-two = t(lambda: fused.linear(hot_ops.ws_linear(x, w1, b1, lnp, None, "gelu"), w2, b2, residual=r))
-print(f"   K13b fc1 + GELU, library fc2 + add on the same rows: {two:.1f} us", flush=True)
-case("s0.swinb", 115200, 128, 512, "gelu", True, True, [(256, 1)], [0])
-# the production entry (whole rounds + tail) against f64
-for (M, Cw, F, act, ln) in [(38560, 256, 2048, "relu", False), (4099, 256, 2048, "relu", False), (17, 256, 2048, "relu", False),
-                            (115200, 96, 384, "gelu", True), (28800, 192, 768, "gelu", True), (1000, 192, 768, "gelu", True)]:
-    x = torch.randn(M, Cw, generator=g).cuda()
-    w1 = (torch.randn(F, Cw, generator=g) / Cw ** 0.5).cuda(); b1 = torch.randn(F, generator=g).cuda()
-    w2 = (torch.randn(Cw, F, generator=g) / F ** 0.5).cuda(); b2 = torch.randn(Cw, generator=g).cuda()
-    lnp = ((torch.rand(Cw, generator=g) + 0.5).cuda(), (torch.randn(Cw, generator=g) * 0.1).cuda(), 1e-5) if ln else None
-    xd = x.double()
-    if ln:
-        xd = torch.nn.functional.layer_norm(xd, (Cw,), lnp[0].double(), lnp[1].double(), 1e-5)
-    h = xd @ w1.double().t() + b1.double()
-    h = torch.relu(h) if act == "relu" else torch.nn.functional.gelu(h)
-    ref = h @ w2.double().t() + b2.double() + x.double()
-    out = hot_ops.mlp_split(x, w1, b1, w2, b2, act, lnp, x)
-    err = (out.double() - ref).abs().max().item() / ref.abs().max().item()
-    us = t(lambda: hot_ops.mlp_split(x, w1, b1, w2, b2, act, lnp, x), 10)
-    print(f"production entry M={M} C={Cw} F={F} {act}: {us:.1f} us ({4.0 * M * F * Cw / us / 1e6:.1f} TFLOP/s), err {err:.2e}", flush=True)
+def vr(ns=3, lsb=0, pf=1, dbg=0):
+    return ns + 8 * lsb + 32 * dbg + 512 * (pf - 1)
+
+
+V = [0, vr(3, 1), vr(4, 1, pf=2), vr(6, 2), vr(7, 2), vr(4, 1, dbg=1), vr(4, 1, dbg=2), vr(4, 1, dbg=13)]
+x, w1, b1, w2, b2, gam, bet, r, ref, scale = case("s2", 7360, 384, 1536, "gelu", True, True, [None, (115, 1)], V)
+case("s2", 7360, 384, 1536, "gelu", True, True, [(58, 4), (230, 1), (77, 3)], [0])
+two = t(lambda: fused.linear(hot_ops.ws_linear(torch.nn.functional.layer_norm(x, (384,), gam, bet), w1, b1, None, None, "gelu"), w2, b2, residual=r))
+print(f"   LayerNorm, K13b fc1 + GELU, library fc2 + add on the same rows: {two:.1f} us", flush=True)
