@@ -29,6 +29,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32-input MFMA peak
 PEAK_HBM_GBS = 8000.0          # HBM3E spec
+HBM_ACHIEVABLE_GBS = 6300.0    # MI355X_MICROARCH.md: measured float4 copy rate (79 % of spec): what a streaming kernel can reach
 PEAK_BF16_MFMA_TFLOPS = 2500.0 # MI355X_MICROARCH.md: dense bf16 MFMA peak (spec; the clock held on random data is lower)
 WEIGHT_SEED = 2023
 
@@ -48,6 +49,12 @@ def parse():
                     help="one clip per graph replay (ClipGraph) instead of the software-pipelined PipelinedClipGraph")
     ap.add_argument("--no-stream", action="store_true",
                     help="skip the second, H2D-inclusive timed pass (stream_ms_per_step)")
+    ap.add_argument("--stub", action="store_true",
+                    help="CPU / gloo dry run of the rank loop with a stub clip step (no model, no kernels): what the 2-rank "
+                         "CPU test drives; the line it prints carries \"stub\": true and is not a measurement")
+    ap.add_argument("--all-passes", action="store_true",
+                    help="N > 1: also run the streamed and the f32-only passes (by default a rank of a multi-GPU run does the "
+                         "headline pass only: one graph capture per rank)")
     ap.add_argument("--no-f32-pass", action="store_true",
                     help="skip the extra timed pass with every GEMM on the f32 MFMA path (SOC_MATMUL=f32 arithmetic)")
     return ap.parse_args()
@@ -102,14 +109,64 @@ def _cpu_topology():
     return max(len(cores), 1), model
 
 
+def headline(a, world, timed, workload, launch):
+    """The contract's keys of the JSON line, from what the measured rank loop returned (shared by the stub dry run)."""
+    dt = timed["seconds"]
+    T, H, Wd = a.frames, a.height, a.width
+    return {
+        "metric": "clips/s (T=8, 360x640, Video-Swin-T)" if (a.backbone, T, H, Wd) == ("video-swin-t", 8, 360, 640)
+                  else f"clips/s (T={T}, {H}x{Wd}, {a.backbone})",
+        "value": world * a.steps / dt, "unit": "clips/s", "n_gpus": world, "ranks_seen": timed["ranks_seen"],
+        "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "seconds_per_rank": timed.get("seconds_per_rank"),
+        "config": {"workload": workload, "clips_per_rank": a.steps,
+                   "parallelism": f"clip-parallel x{world}, one result all_gather", "launch": launch}}
+
+
+def stub_main(a, CP):
+    """`--stub`: the rank loop of this file -- warm-up, the RCCL / gloo warm-up gather, timed_sharded_run, the world and
+    ranks_seen check, the JSON line -- on CPU tensors with a stub step (record i of rank r = f(r, i)).  No model, no GPU."""
+    rank, local_rank, world = CP.init_rank("cpu", expect_world=a.gpus)
+    CP.pin_rank_cpus(rank, world)
+    R = 8
+    results = torch.zeros(a.steps, R)
+
+    def run_steps(n, out):
+        for i in range(n):
+            out[i % out.shape[0]] = torch.tensor([float(rank), float(i), float(rank * 1000 + i)] + [1.0] * (R - 3))
+
+    run_steps(a.warmup, results)
+    if dist.is_initialized():
+        CP.gather_results(results)
+    results.zero_()
+    timed = CP.timed_sharded_run(lambda out: run_steps(a.steps, out), results, None)
+    g = timed["gathered"]
+    assert g.shape[0] == world == a.gpus and timed["ranks_seen"] == list(range(world)), timed["ranks_seen"]
+    ok = all(g[r, i, 2].item() == r * 1000 + i for r in range(world) for i in range(a.steps))
+    if rank == 0:
+        line = headline(a, world, timed, "stub step (no model): dry run of the rank loop", "stub")
+        line.update(stub=True, records_ok=bool(ok))
+        print(json.dumps(line), flush=True)
+    if dist.is_initialized():
+        dist.destroy_process_group()
+    return 0 if ok else 1
+
+
 def main():
     a = parse()
     from neurips2023_soc_amd import clip_parallel as CP
+    CP.rank_environment()           # before anything touches the GPU: the same process environment in both launch modes
     if a.gpus > 1 and not CP.launched_as_rank():
         # fan out BEFORE any GPU call in this process; the parent never execs, it waits and relays the exit code
         return CP.spawn_ranks(a.gpus, [sys.executable, os.path.abspath(__file__), *sys.argv[1:]])
+    if a.stub:
+        return stub_main(a, CP)
     assert torch.cuda.is_available(), "bench.py measures the HIP path; it needs an MI355X"
     rank, local_rank, world = CP.init_rank("cuda", expect_world=a.gpus)   # "nccl" is RCCL on ROCm
+    CP.pin_rank_cpus(rank, world)   # N ranks share the box's CPU quota: each keeps to its share (captures, launches)
+    if world > 1 and not a.all_passes:
+        a.no_stream = a.no_f32_pass = True      # one graph capture per rank; the extra passes are single-GPU diagnostics
     dev = torch.device("cuda", local_rank)
     use_dist = dist.is_initialized()
 
@@ -263,101 +320,80 @@ def main():
         finally:
             hot_ops.MATMUL_MODE = "split"
 
-    # K1 (the roofline kernel): replay the 12 launches of ONE forward back to back between one event pair
+    # The dominant kernel families: replay the launches of ONE forward back to back between one HIP-event pair on the launch
+    # stream (per-launch event pairs add host / queue latency to 30-400 us kernels), with the forward's own tensors.  Every
+    # launch carries its algorithmic FLOPs and algorithmic HBM bytes, so that it can be priced against the ceiling that
+    # binds IT (matrix cores or HBM) -- see ceiling() below.
     K1_REPS = 20
-    hot_ops.record_window_attention_calls(True)
-    step(0)
-    k1_calls = hot_ops.record_window_attention_calls(False)
-    torch.cuda.synchronize()
-    k1_ms_per_forward, k1_per_launch_us = 0.0, []
-    if k1_calls:
-        def replay(calls, reps):
-            torch.cuda._sleep(40_000_000)        # head start for the host so the launches queue back to back
-            s_ev, e_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s_ev.record()
-            for _ in range(reps):
-                for c in calls:
-                    hot_ops.window_attention3d(*c)
-            e_ev.record()
-            torch.cuda.synchronize()
-            return s_ev.elapsed_time(e_ev) / reps
-        replay(k1_calls, 3)
-        k1_ms_per_forward = replay(k1_calls, K1_REPS)
-        k1_per_launch_us = [round(1e3 * replay([c], K1_REPS), 1) for c in k1_calls]
-    del k1_calls[:]
 
-    # K20 (the kernel with the largest share of a clip): the same back-to-back replay of one forward's launches
-    hot_ops.record_linear_split_calls(True)
-    step(0)
-    k20_calls = hot_ops.record_linear_split_calls(False)
-    torch.cuda.synchronize()
-    k20_ms_per_forward, k20_flop, k20_shapes = 0.0, 0.0, []
-    if k20_calls:
-        def replay20(calls, reps):
-            torch.cuda._sleep(40_000_000)
-            s_ev, e_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s_ev.record()
-            for _ in range(reps):
-                for c in calls:
-                    hot_ops.linear_split(**c)
-            e_ev.record()
-            torch.cuda.synchronize()
-            return s_ev.elapsed_time(e_ev) / reps
-        replay20(k20_calls, 3)
-        k20_ms_per_forward = replay20(k20_calls, K1_REPS)
-        seen = {}
-        for c in k20_calls:
-            Nn, Kk = c["weight"].shape
-            Mm = c["x"].numel() // Kk
-            k20_flop += 2.0 * Mm * Nn * Kk
-            seen.setdefault((Mm, Nn, Kk), []).append(c)
-        for (Mm, Nn, Kk), cs in seen.items():
-            us = 1e3 * replay20(cs[:1], K1_REPS)
-            k20_shapes.append({"M": Mm, "N": Nn, "K": Kk, "launches": len(cs), "us": round(us, 1),
-                               "tflops": round(2.0 * Mm * Nn * Kk / us / 1e6, 1)})
-    del k20_calls[:]
+    def replay_calls(fn, calls, reps, star=False):
+        torch.cuda._sleep(40_000_000)        # head start for the host so the launches queue back to back
+        s_ev, e_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s_ev.record()
+        for _ in range(reps):
+            for c in calls:
+                fn(*c) if star else fn(**c)
+        e_ev.record()
+        torch.cuda.synchronize()
+        return s_ev.elapsed_time(e_ev) / reps
 
-    # K13 / K13b (weight-stationary linear layers): the same replay
-    hot_ops.record_ws_linear_calls(True)
-    step(0)
-    k13_calls = hot_ops.record_ws_linear_calls(False)
-    torch.cuda.synchronize()
-    k13_ms_per_forward, k13_flop, k13_shapes = 0.0, 0.0, []
-    if k13_calls:
-        def replay13(calls, reps):
-            torch.cuda._sleep(40_000_000)
-            s_ev, e_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s_ev.record()
-            for _ in range(reps):
-                for c in calls:
-                    hot_ops.ws_linear(**c)
-            e_ev.record()
-            torch.cuda.synchronize()
-            return s_ev.elapsed_time(e_ev) / reps
-        replay13(k13_calls, 3)
-        k13_ms_per_forward = replay13(k13_calls, K1_REPS)
-        seen13 = {}
-        for c in k13_calls:
-            Nn, Kk = c["weight"].shape
-            Mm = c["x"].numel() // Kk
-            k13_flop += 2.0 * Mm * Nn * Kk
-            seen13.setdefault((Mm, Nn, Kk, c["ln"] is not None, c["act"], c["residual"] is not None), []).append(c)
-        for (Mm, Nn, Kk, has_ln, act_, has_res), cs in seen13.items():
-            us = 1e3 * replay13(cs[:1], K1_REPS)
-            k13_shapes.append({"M": Mm, "N": Nn, "K": Kk, "ln": has_ln, "act": act_, "residual": has_res,
-                               "launches": len(cs), "us": round(us, 1), "tflops": round(2.0 * Mm * Nn * Kk / us / 1e6, 1)})
-    del k13_calls[:]
+    def k1_cost(c):
+        qkv, _, _, n_heads, window, shift = c
+        B_, D_, H_, W_, C3 = qkv.shape
+        Cc = C3 // 3
+        win, _ = hot_ops.clamp_window((D_, H_, W_), window, shift)
+        n_win = B_ * -(-D_ // win[0]) * -(-H_ // win[1]) * -(-W_ // win[2])
+        n_tok = win[0] * win[1] * win[2]
+        return (4.0 * n_tok * n_tok * (Cc // n_heads) * n_win * n_heads, 4.0 * qkv.numel() * 4 / 3,
+                (tuple(qkv.shape), n_heads, tuple(shift) != (0, 0, 0)))
+
+    def linear_cost(c):
+        Nn, Kk = c["weight"].shape
+        Mm = c["x"].numel() // Kk
+        extra = sum(1 for k in ("residual", "mul") if c.get(k) is not None) * Mm * Nn + (Mm * Kk if c.get("add") is not None else 0)
+        return (2.0 * Mm * Nn * Kk, 4.0 * (Mm * Kk + Mm * Nn + Nn * Kk + extra),
+                (Mm, Nn, Kk, c.get("ln") is not None, c.get("act", "none"), c.get("residual") is not None))
+
+    def mlp_cost(c):
+        Ff, Cc = c["w1"].shape
+        Mm = c["x"].numel() // Cc
+        return (4.0 * Mm * Ff * Cc, 4.0 * (Mm * Cc * (2 + (c["residual"] is not None)) + 2 * Ff * Cc),
+                (Mm, Cc, Ff, c["act"], c["ln"] is not None, c["post_ln"] is not None))
+
+    families = {}
+    for fam, rec, fn, cost, star in (
+            ("win_attn3d", hot_ops.record_window_attention_calls, hot_ops.window_attention3d, k1_cost, True),
+            ("linear_split", hot_ops.record_linear_split_calls, hot_ops.linear_split, linear_cost, False),
+            ("ws_linear", hot_ops.record_ws_linear_calls, hot_ops.ws_linear, linear_cost, False),
+            ("mlp_split", hot_ops.record_mlp_split_calls, hot_ops.mlp_split, mlp_cost, False)):
+        rec(True)
+        step(0)
+        calls = rec(False)
+        torch.cuda.synchronize()
+        if not calls:
+            continue
+        replay_calls(fn, calls, 3, star)
+        ms = replay_calls(fn, calls, K1_REPS, star)
+        shapes, seen = [], {}
+        for c in calls:
+            seen.setdefault(cost(c)[2], []).append(c)
+        for key, cs in seen.items():
+            fl, by, _ = cost(cs[0])
+            us = 1e3 * replay_calls(fn, cs[:1], K1_REPS, star)
+            shapes.append({"shape": list(key), "launches": len(cs), "us": round(us, 1), "flop": fl, "bytes": by})
+        families[fam] = {"ms": ms, "launches": len(calls), "shapes": shapes}
+        del calls[:]
 
     assert gathered.shape[0] == world == a.gpus and timed["ranks_seen"] == list(range(world)), timed["ranks_seen"]
 
     if rank == 0:
         line = {
-            "metric": "clips/s (T=8, 360x640, Video-Swin-T)" if (a.backbone, T, H, Wd) == ("video-swin-t", 8, 360, 640)
-                      else f"clips/s (T={T}, {H}x{Wd}, {a.backbone})",
-            "value": world * a.steps / dt, "unit": "clips/s", "n_gpus": world, "ranks_seen": timed["ranks_seen"],
-            "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            **headline(a, world, timed,
+                       f"SOC eval forward + query selection, {a.backbone}, T={T}, {H}x{Wd}, B=1, L={L} tokens, random "
+                       f"deterministic weights (seed {WEIGHT_SEED})",
+                       "eager" if graph is None else (
+                           "hipGraph replay, software-pipelined: tail of clip i beside the head of clip i+1"
+                           if pipelined else "hipGraph replay (one graph per clip geometry)")),
             "matmul": ("f32 in / f32 out / f32 accumulation everywhere; pixel-sized linear layers (soc_linear_split_f32) run "
                        "on the bf16 matrix cores with every operand split EXACTLY into three bf16 terms (6 of 9 products, "
                        "dropped terms <= 2^-23 |a b|): error vs f64 no larger than the f32 library GEMM's "
@@ -374,17 +410,11 @@ def main():
                           "(clip_io.DoubleBufferedH2D); 22 MB per clip at 360x640",
                 "stream_record0_max_abs_diff_vs_resident": float((stream["records"][0] - timed_records[0]).abs().max())}
                if stream is not None else {}),
-            "config": {"workload": f"SOC eval forward + query selection, {a.backbone}, T={T}, {H}x{Wd}, B=1, "
-                                   f"L={L} tokens, random deterministic weights (seed {WEIGHT_SEED})",
-                       "clips_per_rank": a.steps, "parallelism": f"clip-parallel x{world}, one result all_gather",
-                       "launch": "eager" if graph is None else (
-                           "hipGraph replay, software-pipelined: tail of clip i beside the head of clip i+1"
-                           if pipelined else "hipGraph replay (one graph per clip geometry)")},
         }
         # HBM bytes per clip from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE collected
         # separately and corrected as MI355X_MICROARCH.md prescribes): profiles/r01_hbm_traffic_pmc.json
         traffic, traffic_file = {}, None
-        for name in ("r03_hbm_traffic_pmc.json", "r02_hbm_traffic_pmc.json", "r01_hbm_traffic_pmc.json"):
+        for name in ("r04_hbm_traffic_pmc.json", "r03_hbm_traffic_pmc.json", "r02_hbm_traffic_pmc.json", "r01_hbm_traffic_pmc.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as f:
                     traffic = {k: v["hbm_total"] for k, v in json.load(f)["per_clip_bytes"].items()}
@@ -393,90 +423,64 @@ def main():
             except (OSError, KeyError, ValueError):
                 continue
         default_cfg = (a.backbone, T, H, Wd) == ("video-swin-t", 8, 360, 640)
-        split_k1 = hot_ops.k1_split_enabled()
-        issued = ("the products run on the bf16 matrix cores, six bf16 MFMA products per f32 product (exact three-way operand "
-                  "split); `achieved` counts the ALGORITHMIC f32 FLOPs once and is priced against the f32-input MFMA peak, the "
-                  "rate the f32 form of the same kernel is bound by; bf16_* prices the issued bf16 MFMA FLOPs against the bf16 peak")
+        split_on = {"win_attn3d": hot_ops.k1_split_enabled(), "linear_split": hot_ops.split_enabled(),
+                    "ws_linear": hot_ops.k13_split_enabled(), "mlp_split": True}
+        desc = {"win_attn3d": "soc_win_attn3d_f32 (K1, 3-D shifted-window attention)",
+                "linear_split": "soc_linear_split_f32 (K20, tiled linear layers)",
+                "ws_linear": "soc_ws_linear_f32 (K13 / K13b, weight-stationary linear layers)",
+                "mlp_split": "soc_mlp_split_f32 (K23: LayerNorm + linear + activation + linear + residual (+ LayerNorm) in one "
+                             "launch, hidden layer in registers -- the Video-Swin MLPs of stages 0-2 and the encoder's feed-forward "
+                             "blocks)"}
+        stats_rows = {"win_attn3d": "win_attn3d_split_kernel<false|true>", "linear_split": "linear_split_kernel<...>",
+                      "ws_linear": "ws_linear_split_kernel<...> (+ ws_linear_kernel<...>)",
+                      "mlp_split": "mlp_split_kernel<...> (+ mlp_reduce_kernel)"}
+
+        def ceiling(fam, shapes):
+            """Time the launches cannot beat: per launch max(FLOPs / matrix-core peak, algorithmic bytes / achievable HBM
+            rate).  The matrix-core peak of a kernel that runs its f32 products as six bf16 MFMAs (exact three-way operand
+            split) is the dense bf16 peak / 6 = 417 TFLOP/s in algorithmic f32 FLOPs; of the f32-input MFMA forms 157.3."""
+            mf = (PEAK_BF16_MFMA_TFLOPS / 6.0 if split_on[fam] else PEAK_F32_MFMA_TFLOPS) * 1e12
+            t_m = sum(sh["launches"] * sh["flop"] / mf for sh in shapes)
+            t_h = sum(sh["launches"] * sh["bytes"] / (HBM_ACHIEVABLE_GBS * 1e9) for sh in shapes)
+            t_c = sum(sh["launches"] * max(sh["flop"] / mf, sh["bytes"] / (HBM_ACHIEVABLE_GBS * 1e9)) for sh in shapes)
+            return t_c, t_m, t_h, mf / 1e12
+
         blocks = {}
-        k1 = prof.get("win_attn3d")
-        if k1 and k1_ms_per_forward > 0:
-            flop_per_clip = k1["work"] / a.steps
-            ach = flop_per_clip / (k1_ms_per_forward * 1e-3) / 1e12
-            blocks["win_attn3d"] = {
-                "kernel": "soc_win_attn3d_f32 (all 12 launches of a forward)", "bound": "mfma",
-                "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
-                "traffic": traffic.get("win_attn3d") if default_cfg else None,
-                "traffic_unit": f"HBM bytes per clip (12 launches), rocprofv3 PMC, {traffic_file}",
-                "algorithmic_flop_per_clip": flop_per_clip,
-                "avg_launch_us": 1e3 * k1_ms_per_forward / max(len(k1_per_launch_us), 1),
-                "ms_per_clip": k1_ms_per_forward,
-                "per_launch_us": k1_per_launch_us,
-                "measured": f"HIP events on the launch stream around {K1_REPS} back-to-back replays of the {len(k1_per_launch_us)} "
-                            "K1 launches of one forward (the forward's own qkv / bias tensors), right after the timed region",
-                "per_launch_event_pairs_ms_per_clip": k1["ms"] / a.steps,
-                "source": "profiles/r03_bench_kernel_stats.csv rows win_attn3d_split_kernel<false|true> "
-                          "(rocprofv3 --kernel-trace --stats of this command): TotalDurationNs / clips"}
-            if split_k1:        # 6 products; 400 x 400 issued for 392 x 392 (query and key tiles of 16)
-                bf = 6.0 * ach * (400.0 * 400.0) / (392.0 * 392.0)
-                blocks["win_attn3d"].update(arithmetic=issued, bf16_issued_tflops=bf, bf16_peak=PEAK_BF16_MFMA_TFLOPS,
-                                            bf16_frac=bf / PEAK_BF16_MFMA_TFLOPS)
-        k20 = prof.get("linear_split")
-        if k20 and k20_ms_per_forward > 0:
-            ach = k20_flop / (k20_ms_per_forward * 1e-3) / 1e12
-            n20 = sum(sh["launches"] for sh in k20_shapes)
-            blocks["linear_split"] = {
-                "kernel": f"soc_linear_split_f32 (all {n20} launches of a forward)", "bound": "mfma",
-                "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
-                "traffic": traffic.get("linear_split") if default_cfg else None,
-                "traffic_unit": f"HBM bytes per clip ({n20} launches), rocprofv3 PMC, {traffic_file}",
-                "algorithmic_flop_per_clip": k20_flop, "avg_launch_us": 1e3 * k20_ms_per_forward / max(n20, 1),
-                "ms_per_clip": k20_ms_per_forward, "per_shape": k20_shapes,
-                "arithmetic": issued, "bf16_issued_tflops": 6.0 * ach, "bf16_peak": PEAK_BF16_MFMA_TFLOPS,
-                "bf16_frac": 6.0 * ach / PEAK_BF16_MFMA_TFLOPS,
-                "measured": f"HIP events on the launch stream around {K1_REPS} back-to-back replays of the K20 launches of one "
-                            "forward (the forward's own activations, weights and row statistics), right after the timed region; "
-                            "algorithmic FLOPs = sum of 2 M N K",
-                "per_launch_event_pairs_ms_per_clip": k20["ms"] / a.steps,
-                "source": "profiles/r03_bench_kernel_stats.csv rows linear_split_kernel<...>: TotalDurationNs / clips"}
-        k13 = prof.get("ws_linear")
-        if k13 and k13_ms_per_forward > 0:
-            ach = k13_flop / (k13_ms_per_forward * 1e-3) / 1e12
-            n13 = sum(sh["launches"] for sh in k13_shapes)
-            split13 = hot_ops.k13_split_enabled()
-            blocks["ws_linear"] = {
-                "kernel": f"soc_ws_linear_f32 (all {n13} launches of a forward; K13b on the bf16 matrix cores where it covers "
-                          "the width)" if split13 else f"soc_ws_linear_f32 (all {n13} launches of a forward, f32 MFMA)",
-                "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": ach / PEAK_F32_MFMA_TFLOPS,
-                "traffic": traffic.get("ws_linear") if default_cfg else None,
-                "traffic_unit": f"HBM bytes per clip ({n13} launches), rocprofv3 PMC, {traffic_file}",
-                "algorithmic_flop_per_clip": k13_flop, "avg_launch_us": 1e3 * k13_ms_per_forward / max(n13, 1),
-                "ms_per_clip": k13_ms_per_forward, "per_shape": k13_shapes,
-                "measured": f"HIP events on the launch stream around {K1_REPS} back-to-back replays of the K13 launches of one "
-                            "forward (the forward's own activations and weights), right after the timed region; algorithmic "
-                            "FLOPs = sum of 2 M N K.  The stage-0 layers (K = 96) sit on the HBM side of their roofline "
-                            "(177-221 MB per launch), the wider ones on the matrix-core side",
-                "per_launch_event_pairs_ms_per_clip": k13["ms"] / a.steps,
-                "source": "profiles/r03_bench_kernel_stats.csv rows ws_linear_split_kernel<...> (+ ws_linear_kernel<...>): "
-                          "TotalDurationNs / clips"}
-            if split13:
-                blocks["ws_linear"].update(arithmetic=issued, bf16_issued_tflops=6.0 * ach, bf16_peak=PEAK_BF16_MFMA_TFLOPS,
-                                           bf16_frac=6.0 * ach / PEAK_BF16_MFMA_TFLOPS)
-        k22 = prof.get("ffn_split")
-        if k22 and k22["ms"] > 0:       # launches of ~0.4 ms: per-launch event pairs of the instrumented pass are accurate here
-            ach = k22["work"] / (k22["ms"] * 1e-3) / 1e12
-            blocks["ffn_split"] = {
-                "kernel": f"soc_ffn_split_f32 ({int(k22['launches'] / a.steps)} launches of a forward: linear1 + ReLU + linear2 of "
-                          "the encoder, hidden layer in registers)", "bound": "mfma",
-                "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
-                "traffic": traffic.get("ffn_split") if default_cfg else None,
-                "traffic_unit": f"HBM bytes per clip, rocprofv3 PMC, {traffic_file}",
-                "algorithmic_flop_per_clip": k22["work"] / a.steps, "avg_launch_us": 1e3 * k22["ms"] / k22["launches"],
-                "ms_per_clip": k22["ms"] / a.steps, "arithmetic": issued, "bf16_issued_tflops": 6.0 * ach,
-                "bf16_peak": PEAK_BF16_MFMA_TFLOPS, "bf16_frac": 6.0 * ach / PEAK_BF16_MFMA_TFLOPS,
-                "measured": "HIP-event pairs around each launch in the instrumented eager pass right after the timed region; "
-                            "algorithmic FLOPs = 4 M F C for the rows K22 takes (whole rounds of 32 768 rows)"}
-        if blocks:      # the roofline object is the kernel with the largest share of a clip; the other one follows
+        for fam, f in families.items():
+            flop = sum(sh["launches"] * sh["flop"] for sh in f["shapes"])
+            byts = sum(sh["launches"] * sh["bytes"] for sh in f["shapes"])
+            t_c, t_m, t_h, mf = ceiling(fam, f["shapes"])
+            sec = f["ms"] * 1e-3
+            mfma_bound = t_m >= t_h
+            ach = flop / sec / 1e12 if mfma_bound else byts / sec / 1e9
+            for sh in f["shapes"]:
+                sh["tflops"] = round(sh["flop"] / sh["us"] / 1e6, 1)
+                sh["gbs"] = round(sh["bytes"] / sh["us"] / 1e3, 1)
+                sh["frac_of_ceiling"] = round(max(sh["flop"] / (mf * 1e12), sh["bytes"] / (HBM_ACHIEVABLE_GBS * 1e9)) / (sh["us"] * 1e-6), 3)
+            blocks[fam] = {
+                "kernel": f"{desc[fam]}: all {f['launches']} launches of a forward",
+                "bound": "mfma" if mfma_bound else "hbm",
+                "achieved": ach, "peak": mf if mfma_bound else PEAK_HBM_GBS, "unit": "TFLOP/s" if mfma_bound else "GB/s",
+                "frac": ach / (mf if mfma_bound else PEAK_HBM_GBS),
+                "frac_of_ceiling": t_c / sec,
+                "ceiling": "per launch max(algorithmic FLOPs / matrix-core peak, algorithmic bytes / 6.3 TB/s achievable HBM rate), "
+                           "summed over the launches, divided by the measured time; the matrix-core peak is "
+                           + ("the dense bf16 MFMA peak / 6 = 417 TFLOP/s of algorithmic f32 FLOPs: every f32 product runs as six "
+                              "bf16 MFMA products (exact three-way operand split)" if split_on[fam] else
+                              "the f32-input MFMA peak, 157.3 TFLOP/s"),
+                "ceiling_ms_per_clip": 1e3 * t_c, "mfma_ms_at_peak": 1e3 * t_m, "hbm_ms_at_6_3_TBs": 1e3 * t_h,
+                "vs_f32_mfma_peak": flop / sec / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                "algorithmic_tflops": flop / sec / 1e12, "algorithmic_gbs": byts / sec / 1e9,
+                "traffic": traffic.get(fam) if default_cfg else None,
+                "traffic_unit": f"HBM bytes per clip ({f['launches']} launches), rocprofv3 PMC, {traffic_file}",
+                "algorithmic_flop_per_clip": flop, "algorithmic_bytes_per_clip": byts,
+                "avg_launch_us": 1e3 * f["ms"] / f["launches"], "ms_per_clip": f["ms"], "per_shape": f["shapes"],
+                "measured": f"HIP events on the launch stream around {K1_REPS} back-to-back replays of this family's launches of one "
+                            "forward (the forward's own activations and weights), right after the timed region",
+                "per_launch_event_pairs_ms_per_clip": prof[fam]["ms"] / a.steps if fam in prof else None,
+                "source": f"profiles/r04_bench_kernel_stats.csv rows {stats_rows[fam]} (rocprofv3 --kernel-trace --stats of this "
+                          "command): TotalDurationNs / clips"}
+        if blocks:      # the roofline object is the kernel family with the largest share of a clip; the others follow
             order = sorted(blocks, key=lambda n: -blocks[n]["ms_per_clip"])
             line["roofline"] = blocks[order[0]]
             for n in order[1:]:
@@ -565,6 +569,22 @@ def main():
                                               "forwards, median, at 8 threads and at the CPU count the cgroup quota grants"}
             d = (timed_records[0][1 + T * Q:].view(T, hm, wm) - P.select_trajectory(ref)[1]).abs().max().item()
             line.setdefault("parity", {})["timed_path_mask_logit_max_abs_diff_vs_cpu_oracle"] = d
+            # the other clips of the pool have no reference golden: one oracle forward each checks their timed records too
+            # (selected query, its mask logits within the north_star tolerance, flips only inside fp32 noise of zero)
+            others = []
+            torch.set_num_threads(best[0])
+            for i in range(1, min(n_pool, a.steps, 4)):
+                ref_i = O.soc_forward(sd, clips_cpu[i], ids_cpu, ones, (H, Wd), backbone=a.backbone, text_encoder=enc)
+                q_ref, m_ref = P.select_trajectory(ref_i)[:2]
+                q_i, _, m_i = CP.unpack_record(timed_records[i], T, Q, hm, wm)
+                flip_i = (m_i > 0) != (m_ref > 0)
+                others.append({"record": i, "selected_query": q_i, "selected_query_oracle": int(q_ref),
+                               "mask_logit_max_abs_diff": float((m_i - m_ref).abs().max()),
+                               "thresholded_mask_flips": int(flip_i.sum()),
+                               "max_abs_oracle_logit_at_flips": float(m_ref[flip_i].abs().max()) if bool(flip_i.any()) else 0.0})
+                assert q_i == int(q_ref) and others[-1]["mask_logit_max_abs_diff"] < 1e-3 \
+                    and others[-1]["max_abs_oracle_logit_at_flips"] < 1e-4, others[-1]
+            line["parity"]["timed_path_other_records_vs_cpu_oracle"] = others
             got = step(0)
             torch.cuda.synchronize()
             d = (got["pred_masks"].cpu() - ref["pred_masks"]).abs().max().item()

@@ -68,6 +68,60 @@ def free_port() -> int:
         return s.getsockname()[1]
 
 
+def rank_environment() -> None:
+    """Process environment every rank needs, whichever way it was started (spawn_ranks or torch.distributed.run): the host
+    driver of this pool only supports dmabuf IPC, and RCCL's / torch's cross-process GPU buffer sharing fails with
+    `hipIpcGetMemHandle: invalid argument` without HSA_ENABLE_IPC_MODE_LEGACY=0.  The HIP runtime reads the variable when it
+    initialises, so this runs first thing in main(), before any GPU call; an explicit setting by the caller wins."""
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+
+def granted_cpus(cgroup_root: str = "/sys/fs/cgroup") -> int:
+    """CPUs this process may actually use: the cgroup CPU quota (v2 cpu.max, v1 cfs quota / period) rounded up, capped by
+    the affinity mask."""
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        with open(os.path.join(cgroup_root, "cpu.max")) as f:
+            q, per = f.read().split()[:2]
+            if q != "max":
+                quota = -(-int(q) // int(per))
+    except (OSError, ValueError):
+        try:
+            with open(os.path.join(cgroup_root, "cpu", "cpu.cfs_quota_us")) as f:
+                q = int(f.read())
+            with open(os.path.join(cgroup_root, "cpu", "cpu.cfs_period_us")) as f:
+                per = int(f.read())
+            if q > 0:
+                quota = -(-q // per)
+        except (OSError, ValueError):
+            pass
+    return max(1, min(avail, quota) if quota else avail)
+
+
+def rank_cpu_share(rank: int, world: int, allowed: Sequence[int], granted: int) -> List[int]:
+    """The CPUs rank `rank` of `world` keeps to: `granted // world` of them (at least one), consecutive in the sorted
+    affinity mask, disjoint between ranks while the mask is long enough.  Eight ranks behind a 16-CPU quota get two CPUs
+    each instead of eight capture threads and eight intra-op pools competing for the sixteen."""
+    cpus = sorted(allowed)
+    k = max(1, min(granted, len(cpus)) // max(world, 1))
+    start = (rank * k) % len(cpus)
+    return [cpus[(start + i) % len(cpus)] for i in range(min(k, len(cpus)))]
+
+
+def pin_rank_cpus(rank: int, world: int) -> List[int]:
+    """Pin this process to its share (world > 1 only) and size torch's intra-op pool to it.  Returns the CPUs kept."""
+    if world <= 1 or not hasattr(os, "sched_setaffinity"):
+        return sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else []
+    share = rank_cpu_share(rank, world, os.sched_getaffinity(0), granted_cpus())
+    try:
+        os.sched_setaffinity(0, share)
+        torch.set_num_threads(len(share))
+    except OSError:
+        pass
+    return share
+
+
 def launched_as_rank() -> bool:
     """True when an outer launcher (torch.distributed.run, spawn_ranks) already made this process a rank."""
     return "RANK" in os.environ and "WORLD_SIZE" in os.environ
@@ -85,7 +139,7 @@ def spawn_ranks(n: int, argv: Sequence[str], extra_env: Optional[Dict[str, str]]
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this driver (RCCL needs it)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # as rank_environment(): set for the child before it starts
         env.update(extra_env or {})
         procs.append(subprocess.Popen(list(argv), env=env))
     deadline = None if timeout is None else time.monotonic() + timeout
@@ -114,6 +168,7 @@ def init_rank(device_type: str = "cuda", expect_world: Optional[int] = None) -> 
     """(rank, local_rank, world) from the launcher's environment; joins the process group when there is one
     ("nccl" = RCCL over xGMI for GPU ranks, "gloo" for the CPU tests).  ``expect_world`` (the ``--gpus`` /
     ``-ng`` value) must match WORLD_SIZE: a mismatch fails instead of silently measuring fewer ranks."""
+    rank_environment()      # no-op when main() already did it; a caller that skipped it gets it before the first GPU call here
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", rank))
     world = int(os.environ.get("WORLD_SIZE", 1))

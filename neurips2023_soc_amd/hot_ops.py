@@ -62,6 +62,19 @@ def record_ws_linear_calls(on: bool):
     return calls
 
 
+_k23_calls = None  # bench.py: when a list, mlp_split appends its arguments
+
+
+def record_mlp_split_calls(on: bool):
+    """As record_linear_split_calls, for K23: the recorded dicts are keyword arguments of mlp_split."""
+    global _k23_calls
+    if on:
+        _k23_calls = []
+        return None
+    calls, _k23_calls = _k23_calls, None
+    return calls
+
+
 def profile_begin() -> None:
     global _prof
     _prof = {}
@@ -1077,6 +1090,8 @@ def mlp_split(x: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor, act: st
         g, be, eps = _f32c(ln[0]), _f32c(ln[1]), float(ln[2])
     ptr = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
     b1c, b2c = _f32c(b1), _f32c(b2)
+    if _k23_calls is not None:
+        _k23_calls.append(dict(x=x, w1=w1, b1=b1, w2=w2, b2=b2, act=act, ln=ln, residual=residual, post_ln=post_ln, cut=cut))
     if cut is None:
         nbytes = lib.soc_mlp_split_workspace_bytes(M, C_, F_)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None

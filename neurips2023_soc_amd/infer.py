@@ -220,6 +220,7 @@ def parse_args(argv=None):
 
 def main(argv=None):
     a = parse_args(argv)
+    CP.rank_environment()           # before anything touches the GPU: the same process environment in both launch modes
     if a.gpus > 1 and not CP.launched_as_rank():
         # one process per GPU, started before this process touches the GPU (reference infer_refytb.py:84-109)
         import sys
@@ -232,6 +233,7 @@ def main(argv=None):
     from . import weights as W
 
     rank, local, world = CP.init_rank("cuda", expect_world=a.gpus)
+    CP.pin_rank_cpus(rank, world)
     dev = torch.device("cuda", local)
     model, _, _ = build_model(default_args(a.backbone, text_encoder_random_init=True))
     W.load_synthetic(model, 2023)

@@ -126,3 +126,53 @@ def test_bench_consumes_gpus_flag_without_a_gpu():
     r = _run(["bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0"], timeout=600)
     assert r.returncode != 0
     assert r.stderr.count("AssertionError: bench.py measures the HIP path") >= 1, r.stderr[-2000:]
+
+
+def _stub_line(r):
+    import json
+    assert r.returncode == 0, r.stderr[-2000:]
+    return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+
+
+def test_bench_rank_loop_two_ranks_self_launched():
+    """bench.py's OWN main -- argument handling, the fan-out, init_rank, CPU pinning, the warm-up gather, timed_sharded_run,
+    the world / ranks_seen assertion, the contract keys of the JSON line -- at world 2 over gloo with the stub step."""
+    line = _stub_line(_run(["bench.py", "--stub", "--gpus", "2", "--steps", "6", "--warmup", "2"], timeout=300))
+    assert line["stub"] is True and line["records_ok"] is True
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == [0, 1] and line["steps"] == 6 and line["warmup"] == 2
+    assert line["scaling"] == "weak" and line["unit"] == "clips/s" and line["higher_is_better"] is True
+    assert abs(line["value"] * line["ms_per_step"] / 1e3 - 2) < 1e-6            # whole-job clips/s x s per clip = ranks
+    assert len(line["seconds_per_rank"]) == 2 and max(line["seconds_per_rank"]) * 1e3 / 6 == line["ms_per_step"]
+
+
+def test_bench_rank_loop_under_torch_distributed_run():
+    """The driver's launch line (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`): the ranks exist
+    already, bench.py must not fan out again and must see the same process environment as the self-launched ranks."""
+    port = CP.free_port()
+    line = _stub_line(_run(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                            "--master-port", str(port), "bench.py", "--stub", "--gpus", "2", "--steps", "4", "--warmup", "1"],
+                           timeout=300))
+    assert line["stub"] is True and line["records_ok"] is True and line["n_gpus"] == 2 and line["ranks_seen"] == [0, 1]
+
+
+def test_rank_environment_is_the_same_in_both_launch_modes(monkeypatch):
+    """HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC, what RCCL needs on this pool) used to be set for self-launched ranks only;
+    now every rank sets it before its first GPU call, and an explicit caller setting wins."""
+    monkeypatch.delenv("HSA_ENABLE_IPC_MODE_LEGACY", raising=False)
+    CP.rank_environment()
+    assert os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", "1")
+    CP.rank_environment()
+    assert os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] == "1"
+
+
+def test_rank_cpu_shares_partition_the_granted_cpus():
+    """8 ranks behind a 16-CPU quota on a 256-CPU affinity mask: two CPUs each, disjoint; more ranks than CPUs: one each,
+    wrapping; one rank keeps everything the quota grants."""
+    allowed = list(range(256))
+    shares = [CP.rank_cpu_share(r, 8, allowed, 16) for r in range(8)]
+    assert all(len(s) == 2 for s in shares) and len({c for s in shares for c in s}) == 16
+    assert CP.rank_cpu_share(0, 1, allowed, 16) == list(range(16))
+    shares = [CP.rank_cpu_share(r, 8, [3, 5, 7, 9], 4) for r in range(8)]
+    assert all(len(s) == 1 for s in shares) and {s[0] for s in shares} == {3, 5, 7, 9}
+    assert CP.rank_cpu_share(2, 4, [10, 11, 12, 13, 14, 15, 16, 17], 8) == [14, 15]
