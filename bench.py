@@ -357,8 +357,9 @@ def main():
     def mlp_cost(c):
         Ff, Cc = c["w1"].shape
         Mm = c["x"].numel() // Cc
-        return (4.0 * Mm * Ff * Cc, 4.0 * (Mm * Cc * (2 + (c["residual"] is not None)) + 2 * Ff * Cc),
-                (Mm, Cc, Ff, c["act"], c["ln"] is not None, c["post_ln"] is not None))
+        return (4.0 * Mm * Ff * Cc,
+                4.0 * (Mm * Cc * (2 + (c["residual"] is not None) + bool(c.get("return_sum"))) + 2 * Ff * Cc),
+                (Mm, Cc, Ff, c["act"], c["ln"] is not None, c["post_ln"] is not None, bool(c.get("return_sum"))))
 
     families = {}
     for fam, rec, fn, cost, star in (

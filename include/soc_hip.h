@@ -261,7 +261,8 @@ int soc_ffn_split_f32(const float* x, const void* packed, const float* b1, const
  * (C <= 256) or 4 (C = 384) row tiles of 16 per CU; a short last round, or a short input altogether, is cut over `nfs` hidden ranges whose
  * partial sums a second kernel adds in a fixed order (deterministic).
  *   x [M, C], w1 [F, C], b1 [F], w2 [C, F], b2 [C], ln_gamma / ln_beta [C] or both NULL, residual [M, C] or NULL,
- *   post_gamma / post_beta [C] or both NULL, out [M, C]; C in {96, 128, 192, 256, 384}, F % 32 == 0; every pointer 16-byte aligned.
+ *   post_gamma / post_beta [C] or both NULL, out [M, C], out_sum [M, C] or NULL (with LN2: the sum in front of it, i.e. the
+ *   shortcut the next Video-Swin block needs beside norm1 of it); C in {96, 128, 192, 256, 384}, F % 32 == 0; every pointer 16-byte aligned.
  *   soc_mlp_split_packed_bytes / soc_mlp_split_pack_f32: split and lay out both weights ONCE (opaque image `packed`);
  *   re-pack after the weights change.  soc_mlp_split_workspace_bytes: scratch for the partial sums (0 when none are needed).
  *   soc_mlp_split_plan: the (workgroup rows, hidden ranges) cut chosen for M rows taken as ONE launch.
@@ -274,12 +275,12 @@ size_t soc_mlp_split_workspace_bytes(long M, int C, int F);
 int soc_mlp_split_plan(long M, int C, int F, int* nrg, int* nfs);
 int soc_mlp_split_f32(const float* x, const void* packed, const float* b1, const float* b2, const float* ln_gamma,
                       const float* ln_beta, float ln_eps, const float* residual, const float* post_gamma,
-                      const float* post_beta, float post_eps, float* out, float* workspace, size_t workspace_bytes, long M,
-                      int C, int F, int act, void* stream);
+                      const float* post_beta, float post_eps, float* out, float* out_sum, float* workspace,
+                      size_t workspace_bytes, long M, int C, int F, int act, void* stream);
 int soc_mlp_split_variant_f32(const float* x, const void* packed, const float* b1, const float* b2, const float* ln_gamma,
                               const float* ln_beta, float ln_eps, const float* residual, const float* post_gamma,
-                              const float* post_beta, float post_eps, float* out, float* workspace, long M, int C, int F,
-                              int act, int nrg, int nfs, int variant, void* stream);
+                              const float* post_beta, float post_eps, float* out, float* out_sum, float* workspace, long M,
+                              int C, int F, int act, int nrg, int nfs, int variant, void* stream);
 
 /*
  * K21 -- Video-Swin patch embedding: the (1,4,4) / stride (1,4,4) convolution + LayerNorm(C) in one pass.  Replaces

@@ -130,9 +130,9 @@ def load() -> C.CDLL:
     lib.soc_mlp_split_plan.restype = i
     lib.soc_mlp_split_plan.argtypes = [C.c_long, i, i, C.POINTER(i), C.POINTER(i)]
     lib.soc_mlp_split_f32.restype = i
-    lib.soc_mlp_split_f32.argtypes = [p, p, p, p, p, p, f, p, p, p, f, p, p, C.c_size_t, C.c_long, i, i, i, p]
+    lib.soc_mlp_split_f32.argtypes = [p, p, p, p, p, p, f, p, p, p, f, p, p, p, C.c_size_t, C.c_long, i, i, i, p]
     lib.soc_mlp_split_variant_f32.restype = i
-    lib.soc_mlp_split_variant_f32.argtypes = [p, p, p, p, p, p, f, p, p, p, f, p, p, C.c_long, i, i, i, i, i, i, p]
+    lib.soc_mlp_split_variant_f32.argtypes = [p, p, p, p, p, p, f, p, p, p, f, p, p, p, C.c_long, i, i, i, i, i, i, p]
     lib.soc_patch_embed_layernorm_f32.restype = i
     lib.soc_patch_embed_layernorm_f32.argtypes = [p, p, p, p, p, p, i, i, i, i, f, p]
     lib.soc_linear_act_f32.restype = i

@@ -50,21 +50,23 @@ __device__ __forceinline__ void handoff() {        // my part of the next block 
 }
 
 // DBG (diagnostics only) bit 0: no LDS-DMA inside the block loop, bit 1: no MFMA work (stream ceiling), bit 2: no fragment
-// reads after a piece's first group, bit 3: no activation.  PF: fragment groups read ahead.
+// reads after a piece's first group, bit 3: no activation.  PF: fragment groups read ahead.  STAG bit 0: waves 4..7 run one ring
+// piece behind waves 0..3, bit 1: the activation runs at raised wave priority.
 // NW waves per workgroup: 8 (two per SIMD, 256 registers each) or 4 (one per SIMD, 512 registers: wider rows or more row tiles
 // per wave, so that a weight fragment read from LDS feeds more MFMAs).  RT row tiles per wave.
-template <int C, int ACT, bool HAS_LN, int NW, int RT, int NSLOT, int SB, int PF, int DBG>
+template <int C, int ACT, bool HAS_LN, int NW, int RT, int NSLOT, int SB, int STAG, int PF, int DBG>
 __global__ __launch_bounds__(NW * 64, NW / 4) void mlp_split_kernel(
     const float* __restrict__ x, const u32x4* __restrict__ img, const float* __restrict__ b1, const float* __restrict__ b2,
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps, const float* __restrict__ res,
-    const float* __restrict__ gamma2, const float* __restrict__ beta2, float eps2, float* __restrict__ out, long M, int F,
-    int nrg, int nfs) {
+    const float* __restrict__ gamma2, const float* __restrict__ beta2, float eps2, float* __restrict__ out,
+    float* __restrict__ out_sum, long M, int F, int nrg, int nfs) {
     using G = Geo<C>;
     constexpr int THREADS = NW * 64;
     // a block travels in SB ring pieces (a piece = a slot = one DMA round set): P LDS-DMA instructions per thread and piece
     constexpr int KS = G::KS, OT = G::OT, BLKP = G::BLKP_U4, SLOT = BLKP / SB, P = SLOT / THREADS;
     static_assert(OT % SB == 0 && SLOT % THREADS == 0 && (SB == 1 || BLKP == G::BLK_U4), "pieces are whole fragment groups");
-    constexpr int D = NSLOT - 1;                                        // pieces in flight ahead of the one being consumed
+    static_assert(STAG == 0 || NW == 8, "the stagger pairs the two waves of a SIMD");
+    constexpr int D = NSLOT - 1 - (STAG ? 1 : 0);                       // pieces in flight ahead of the one being consumed
     static_assert(D >= 1 && (D - 1) * P < 64, "ring depth");
     extern __shared__ __attribute__((aligned(16))) u32x4 lds[];
     u32x4* slots = lds;
@@ -105,8 +107,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mlp_split_kernel(
     __syncthreads();
     // One pass = up to 8 RT row tiles through the whole hidden range.  NRT (compile time) = this wave's tiles in the pass:
     // the accumulator updates are straight-line code for every count, a wave without tiles only feeds the ring.
-    auto pass = [&](auto nrt_c, long pt) {
+    auto pass = [&](auto nrt_c, auto late_c, long pt) {
         constexpr int NRT = decltype(nrt_c)::value;
+        constexpr bool LATE = decltype(late_c)::value;
         constexpr int NX = NRT > 0 ? NRT : 1;
         bf16x8 xb[NX][KS][3];
         {
@@ -215,6 +218,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mlp_split_kernel(
 #pragma unroll
             for (int q = 0; q < PF; ++q) frag(wf[q], wl, q);
             if (sb == 0) {
+                if (STAG & 2) __builtin_amdgcn_s_setprio(1);   // the vector work goes in front of the partner wave's MFMAs
 #pragma unroll
                 for (int rt = 0; rt < NRT; ++rt) {
                     float v[8];
@@ -231,6 +235,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mlp_split_kernel(
                     }
                     split8(v, hb[rt][0], hb[rt][1], hb[rt][2]);
                 }
+                if (STAG & 2) __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
@@ -246,32 +251,45 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mlp_split_kernel(
             }
         };
         if (nq >= D) handoff<(D - 1) * P>(); else handoff<0>();         // piece 0 has landed
-        int slot = 0, dslot = D % NSLOT, q = 0;                         // the slot being consumed / the slot the next DMA fills
-        // one ring step: the piece D ahead goes out, this piece is consumed, the next one is waited for
-        auto step = [&](auto&& work) {
+        // Ring step t: the piece D ahead goes out, a piece is consumed, the next one is waited for.  Waves 0..3 consume piece t;
+        // with the stagger (LATE) waves 4..7 consume piece t - 1, whose slot is `pslot`: on every SIMD one wave then starts a
+        // step with the activation (vector ALU, at raised priority) while its partner starts with MFMAs.
+        int slot = 0, pslot = 0, dslot = D % NSLOT, q = 0;
+        // piece K of a chunk: K < SB -> W1 piece K, else W2 piece K - SB
+        auto piece = [&](auto k_c, int blk, int sl) {
+            constexpr int K_ = decltype(k_c)::value;
+            if constexpr (K_ < SB) first(blk, std::integral_constant<int, K_>{}, sl);
+            else second(std::integral_constant<int, K_ - SB>{}, sl);
+        };
+        auto step = [&](auto k_c, int blk) {
+            constexpr int K_ = decltype(k_c)::value;
             const bool more = q + D < nq;
             if (!(DBG & 1) && more) { dma(q + D, dslot); dslot = next_slot(dslot); }
-            work(slot);
+            if constexpr (!LATE) piece(k_c, blk, slot);
+            else if (K_ > 0) piece(std::integral_constant<int, (K_ > 0 ? K_ - 1 : 0)>{}, blk, pslot);
+            else if (blk > 0) piece(std::integral_constant<int, 2 * SB - 1>{}, blk - 2, pslot);
             if (q + 1 < nq) {
                 if (more) handoff<(D - 1) * P>(); else handoff<0>();
             }
+            pslot = slot;
             slot = next_slot(slot);
             ++q;
         };
         for (int blk = 0; blk < nb; blk += 2) {
-            step([&](int sl) { first(blk, std::integral_constant<int, 0>{}, sl); });
-            if constexpr (SB >= 2) step([&](int sl) { first(blk, std::integral_constant<int, 1>{}, sl); });
-            if constexpr (SB >= 4) {
-                step([&](int sl) { first(blk, std::integral_constant<int, 2>{}, sl); });
-                step([&](int sl) { first(blk, std::integral_constant<int, 3>{}, sl); });
+            step(std::integral_constant<int, 0>{}, blk);
+            step(std::integral_constant<int, 1>{}, blk);
+            if constexpr (SB >= 2) {
+                step(std::integral_constant<int, 2>{}, blk);
+                step(std::integral_constant<int, 3>{}, blk);
             }
-            step([&](int sl) { second(std::integral_constant<int, 0>{}, sl); });
-            if constexpr (SB >= 2) step([&](int sl) { second(std::integral_constant<int, 1>{}, sl); });
             if constexpr (SB >= 4) {
-                step([&](int sl) { second(std::integral_constant<int, 2>{}, sl); });
-                step([&](int sl) { second(std::integral_constant<int, 3>{}, sl); });
+                step(std::integral_constant<int, 4>{}, blk);
+                step(std::integral_constant<int, 5>{}, blk);
+                step(std::integral_constant<int, 6>{}, blk);
+                step(std::integral_constant<int, 7>{}, blk);
             }
         }
+        if constexpr (LATE) piece(std::integral_constant<int, 2 * SB - 1>{}, nb - 2, pslot);
         // ---- lane (r, kq) holds out[m][16 ot + 4 kq .. + 3] of its tiles.  b2 and the residual are added LAST, to the finished
         // sum of products (starting the accumulators from them would round every product at the residual's magnitude); the
         // loads of a tile go out together
@@ -297,7 +315,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mlp_split_kernel(
                     }
                 }
                 if (nfs == 1 && gamma2) {
-                    // LayerNorm behind the block (the encoder's norm2): the row lives in lanes (r, kq = 0..3), two-pass
+                    // LayerNorm behind the block (the encoder's norm2, or norm1 of the next Video-Swin block with the sum kept as
+                    // the shortcut: out_sum): the row lives in lanes (r, kq = 0..3), two-pass
+                    if (out_sum) {
+#pragma unroll
+                        for (int ot = 0; ot < OT; ++ot) *reinterpret_cast<f32x4*>(out_sum + mo + 16 * ot) = acc2[rt][ot];
+                    }
                     const float inv_c = in_vgpr(1.0f / C), eps_v = in_vgpr(eps2);
                     float sm = 0.f;
 #pragma unroll
@@ -333,11 +356,15 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mlp_split_kernel(
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
             if (pt + NW * rt + wave < t1) nrt = rt + 1;
-        if (RT >= 4 && nrt == 4) pass(std::integral_constant<int, RT >= 4 ? 4 : 0>{}, pt);
-        else if (RT >= 3 && nrt == 3) pass(std::integral_constant<int, RT >= 3 ? 3 : 0>{}, pt);
-        else if (RT >= 2 && nrt == 2) pass(std::integral_constant<int, RT >= 2 ? 2 : 0>{}, pt);
-        else if (nrt == 1) pass(std::integral_constant<int, 1>{}, pt);
-        else pass(std::integral_constant<int, 0>{}, pt);
+        auto run = [&](auto late_c) {
+            if (RT >= 4 && nrt == 4) pass(std::integral_constant<int, RT >= 4 ? 4 : 0>{}, late_c, pt);
+            else if (RT >= 3 && nrt == 3) pass(std::integral_constant<int, RT >= 3 ? 3 : 0>{}, late_c, pt);
+            else if (RT >= 2 && nrt == 2) pass(std::integral_constant<int, RT >= 2 ? 2 : 0>{}, late_c, pt);
+            else if (nrt == 1) pass(std::integral_constant<int, 1>{}, late_c, pt);
+            else pass(std::integral_constant<int, 0>{}, late_c, pt);
+        };
+        if (STAG && wave >= NW / 2) run(std::integral_constant<bool, STAG != 0>{});
+        else run(std::false_type{});
     }
     __syncthreads();        // the waves retire together
 }
@@ -346,7 +373,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mlp_split_kernel(
 __global__ __launch_bounds__(256) void mlp_reduce_kernel(const float* __restrict__ part, int nfs, const float* __restrict__ b2,
                                                          const float* __restrict__ res, const float* __restrict__ gamma2,
                                                          const float* __restrict__ beta2, float eps2, float* __restrict__ out,
-                                                         long M, int C) {
+                                                         float* __restrict__ out_sum, long M, int C) {
     const int lane = threadIdx.x & 63;
     const long n4 = M * C / 4;
     for (long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6); m < M; m += (long)gridDim.x * 4) {
@@ -373,6 +400,11 @@ __global__ __launch_bounds__(256) void mlp_reduce_kernel(const float* __restrict
             }
         }
         if (gamma2) {
+            if (out_sum) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    if (on[h]) reinterpret_cast<float4*>(out_sum)[m * (C / 4) + lane + 64 * h] = a[h];
+            }
             float sm = ((a[0].x + a[0].y) + (a[0].z + a[0].w)) + ((a[1].x + a[1].y) + (a[1].z + a[1].w));
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) sm += __shfl_xor(sm, d);
@@ -463,14 +495,15 @@ struct Args {
     const u32x4* img;
     float eps;
     float* out;
+    float* out_sum;
     long M;
     int F, nrg, nfs;
     hipStream_t st;
 };
 
-template <int C, int ACT, bool HAS_LN, int NW, int RT, int NSLOT, int SB, int PF, int DBG>
+template <int C, int ACT, bool HAS_LN, int NW, int RT, int NSLOT, int SB, int STAG, int PF, int DBG>
 int launch(const Args& a) {
-    const void* fn = reinterpret_cast<const void*>(mlp_split_kernel<C, ACT, HAS_LN, NW, RT, NSLOT, SB, PF, DBG>);
+    const void* fn = reinterpret_cast<const void*>(mlp_split_kernel<C, ACT, HAS_LN, NW, RT, NSLOT, SB, STAG, PF, DBG>);
     const size_t lds = lds_bytes<C>(NSLOT, SB, a.F, a.nfs);
     if (lds > 160 * 1024) return SOC_EUNSUPPORTED;
     static std::atomic<bool> attr_set[SOC_MAX_DEVICES];
@@ -480,9 +513,9 @@ int launch(const Args& a) {
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return SOC_ELAUNCH;
         attr_set[dev].store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL((mlp_split_kernel<C, ACT, HAS_LN, NW, RT, NSLOT, SB, PF, DBG>), dim3((unsigned)(a.nrg * a.nfs)),
+    hipLaunchKernelGGL((mlp_split_kernel<C, ACT, HAS_LN, NW, RT, NSLOT, SB, STAG, PF, DBG>), dim3((unsigned)(a.nrg * a.nfs)),
                        dim3(NW * 64), lds, a.st, a.x, a.img, a.b1, a.b2, a.gamma, a.beta, a.eps, a.res, a.gamma2, a.beta2, a.eps2,
-                       a.out, a.M, a.F, a.nrg, a.nfs);
+                       a.out, a.out_sum, a.M, a.F, a.nrg, a.nfs);
     return soc_check_launch();
 }
 
@@ -495,27 +528,24 @@ constexpr int form_ns() {
     return ns >= 4 ? 4 : ns;
 }
 
-// variant = NSLOT + 8 * log2(SB) + 32 * DBG + 512 * (PF - 1) + 1024 * form (1: 4 waves x 1 tile, 2: 4 x 2, 3: 4 x 4, 4: 8 x 1,
-// 5: 8 x 2); 0 = the shipped choice for the width
+// variant = NSLOT + 8 * log2(SB) + 32 * DBG + 512 * (PF - 1) + 1024 * STAG; 0 = the shipped choice for the width
 template <int C, int ACT, bool HAS_LN>
 int launch_variant(const Args& a, int variant) {
     static_assert(form_ns<C>() >= 3, "three slots at least");
-    if (variant == 0) return launch<C, ACT, HAS_LN, form_nw(C), form_rt(C), form_ns<C>(), form_sb(C), 1, 0>(a);
+    if (variant == 0) return launch<C, ACT, HAS_LN, form_nw(C), form_rt(C), form_ns<C>(), form_sb(C), 0, 1, 0>(a);
 #ifdef SOC_K23_VARIANTS         // diagnostic build (tools/experiments/k23_time.py)
-#define V(FORM, NW_, RT_, NS, LSB, PFD, DB)                                                                      \
-    case NS + 8 * LSB + 32 * DB + 512 * (PFD - 1) + 1024 * FORM:                                                 \
+#define V(NS, LSB, ST, PFD, DB)                                                                                  \
+    case NS + 8 * LSB + 32 * DB + 512 * (PFD - 1) + 1024 * ST:                                                   \
         if constexpr ((size_t)NS * (Geo<C>::BLKP_U4 >> LSB) * 16 + 8 * C + 4096 <= 160 * 1024 &&                 \
                       (Geo<C>::OT >> LSB) >= 1 && (LSB == 0 || Geo<C>::BLKP_U4 == Geo<C>::BLK_U4) &&             \
-                      (Geo<C>::BLKP_U4 >> LSB) % (NW_ * 64) == 0 &&                                              \
-                      (3 * C / 8 + C / 4) * RT_ + 40 <= (NW_ == 8 ? 256 : 512))                                  \
-            return launch<C, ACT, HAS_LN, NW_, RT_, NS, (1 << LSB), PFD, DB>(a);                                 \
+                      (Geo<C>::BLKP_U4 >> LSB) % (NW0 * 64) == 0 && (ST == 0 || NW0 == 8))                       \
+            return launch<C, ACT, HAS_LN, NW0, RT0, NS, (1 << LSB), ST, PFD, DB>(a);                             \
         else break;
     constexpr int NW0 = form_nw(C), RT0 = form_rt(C);
     switch (variant) {
-        V(0, NW0, RT0, 2, 0, 1, 0) V(0, NW0, RT0, 3, 0, 1, 0) V(0, NW0, RT0, 4, 1, 1, 0) V(0, NW0, RT0, 3, 1, 1, 0)
-        V(0, NW0, RT0, 4, 1, 2, 0) V(0, NW0, RT0, 6, 2, 1, 0) V(0, NW0, RT0, 7, 2, 1, 0)
-        V(0, NW0, RT0, 3, 0, 1, 1) V(0, NW0, RT0, 3, 0, 1, 2) V(0, NW0, RT0, 3, 0, 1, 13) V(0, NW0, RT0, 4, 1, 1, 1)
-        V(0, NW0, RT0, 4, 1, 1, 2) V(0, NW0, RT0, 4, 1, 1, 13)
+        V(2, 0, 0, 1, 0) V(3, 0, 0, 1, 0) V(4, 1, 0, 1, 0) V(3, 1, 0, 1, 0)
+        V(3, 0, 1, 1, 0) V(3, 0, 3, 1, 0) V(3, 0, 2, 1, 0) V(4, 0, 1, 1, 0) V(4, 0, 3, 1, 0) V(4, 0, 2, 1, 0)
+        V(3, 0, 0, 1, 1) V(3, 0, 0, 1, 2) V(3, 0, 0, 1, 13) V(4, 1, 0, 1, 1) V(4, 1, 0, 1, 2) V(4, 1, 0, 1, 13)
         default: break;
     }
 #undef V
@@ -613,23 +643,24 @@ extern "C" size_t soc_mlp_split_workspace_bytes(long M, int C, int F) {
 extern "C" int soc_mlp_split_variant_f32(const float* x, const void* packed, const float* b1, const float* b2,
                                          const float* ln_gamma, const float* ln_beta, float ln_eps, const float* residual,
                                          const float* post_gamma, const float* post_beta, float post_eps, float* out,
-                                         float* workspace, long M, int C, int F, int act, int nrg, int nfs, int variant,
-                                         void* stream) {
+                                         float* out_sum, float* workspace, long M, int C, int F, int act, int nrg, int nfs,
+                                         int variant, void* stream) {
     if (M < 0 || F <= 0) return SOC_EINVAL;
     if (M == 0) return SOC_OK;
     if (!x || !packed || !b1 || !b2 || !out || (ln_gamma == nullptr) != (ln_beta == nullptr) ||
-        (post_gamma == nullptr) != (post_beta == nullptr))
+        (post_gamma == nullptr) != (post_beta == nullptr) || (out_sum && !post_gamma))
         return SOC_EINVAL;
     if (!width_ok(C) || F % 32 != 0 || (act != 1 && act != 2)) return SOC_EUNSUPPORTED;
     if ((((uintptr_t)x | (uintptr_t)packed | (uintptr_t)b1 | (uintptr_t)b2 | (uintptr_t)residual | (uintptr_t)out |
-          (uintptr_t)ln_gamma | (uintptr_t)ln_beta | (uintptr_t)post_gamma | (uintptr_t)post_beta | (uintptr_t)workspace) & 15) != 0)
+          (uintptr_t)ln_gamma | (uintptr_t)ln_beta | (uintptr_t)post_gamma | (uintptr_t)post_beta | (uintptr_t)workspace |
+          (uintptr_t)out_sum) & 15) != 0)
         return SOC_EUNSUPPORTED;
     if (nrg <= 0 || nfs <= 0 || nfs > F / 32 || nrg > (M + 15) / 16) return SOC_EINVAL;
     if (nfs > 1 && !workspace) return SOC_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     Args a{x, b1, b2, ln_gamma, ln_beta, nfs > 1 ? nullptr : residual, nfs > 1 ? nullptr : post_gamma,
            nfs > 1 ? nullptr : post_beta, post_eps, reinterpret_cast<const u32x4*>(packed), ln_eps,
-           nfs > 1 ? workspace : out, M, F, nrg, nfs, st};
+           nfs > 1 ? workspace : out, nfs > 1 ? nullptr : out_sum, M, F, nrg, nfs, st};
     int rc;
     switch (C) {
         case 96: rc = launch_c<96>(a, act, variant); break;
@@ -641,14 +672,14 @@ extern "C" int soc_mlp_split_variant_f32(const float* x, const void* packed, con
     if (rc != SOC_OK || nfs == 1) return rc;
     const int blocks = (int)((M + 3) / 4 > 8192 ? 8192 : (M + 3) / 4);
     hipLaunchKernelGGL(mlp_reduce_kernel, dim3(blocks), dim3(256), 0, st, workspace, nfs, b2, residual, post_gamma, post_beta,
-                       post_eps, out, M, C);
+                       post_eps, out, out_sum, M, C);
     return soc_check_launch();
 }
 
 extern "C" int soc_mlp_split_f32(const float* x, const void* packed, const float* b1, const float* b2, const float* ln_gamma,
                                  const float* ln_beta, float ln_eps, const float* residual, const float* post_gamma,
-                                 const float* post_beta, float post_eps, float* out, float* workspace, size_t workspace_bytes,
-                                 long M, int C, int F, int act, void* stream) {
+                                 const float* post_beta, float post_eps, float* out, float* out_sum, float* workspace,
+                                 size_t workspace_bytes, long M, int C, int F, int act, void* stream) {
     if (M < 0 || F <= 0) return SOC_EINVAL;
     if (M == 0) return SOC_OK;
     if (!width_ok(C) || F % 32 != 0) return SOC_EUNSUPPORTED;
@@ -658,14 +689,14 @@ extern "C" int soc_mlp_split_f32(const float* x, const void* packed, const float
     int nrg = 0, nfs = 0;
     if (m0 < M) {       // whole rounds first, then the tail over split hidden ranges
         const int rc = soc_mlp_split_variant_f32(x, packed, b1, b2, ln_gamma, ln_beta, ln_eps, residual, post_gamma, post_beta,
-                                                 post_eps, out, nullptr, m0, C, F, act, cus, 1, 0, stream);
+                                                 post_eps, out, out_sum, nullptr, m0, C, F, act, cus, 1, 0, stream);
         if (rc != SOC_OK) return rc;
         plan_rows(M - m0, C, F, cus, &nrg, &nfs);
         return soc_mlp_split_variant_f32(x + m0 * C, packed, b1, b2, ln_gamma, ln_beta, ln_eps,
                                          residual ? residual + m0 * C : nullptr, post_gamma, post_beta, post_eps, out + m0 * C,
-                                         workspace, M - m0, C, F, act, nrg, nfs, 0, stream);
+                                         out_sum ? out_sum + m0 * C : nullptr, workspace, M - m0, C, F, act, nrg, nfs, 0, stream);
     }
     plan_rows(M, C, F, cus, &nrg, &nfs);
     return soc_mlp_split_variant_f32(x, packed, b1, b2, ln_gamma, ln_beta, ln_eps, residual, post_gamma, post_beta, post_eps, out,
-                                     workspace, M, C, F, act, nrg, nfs, 0, stream);
+                                     out_sum, workspace, M, C, F, act, nrg, nfs, 0, stream);
 }

@@ -152,15 +152,15 @@ class BasicLayer(nn.Module):
         _, h = hot_ops.add_layernorm(x, None, blocks[0].norm1.weight, blocks[0].norm1.bias, blocks[0].norm1.eps)
         if fused.mlp_ok(x, blocks[0].mlp.fc1, blocks[0].mlp.fc2):
             # stage 2 (C = 384): the shortcut rides in the projection's epilogue, norm2 + fc1 + GELU + fc2 + shortcut are one K23
-            # launch; one LayerNorm pass per block is left (norm1 of the next block)
+            # launch that also emits norm1 of the next block: no LayerNorm pass inside the stage
             for i, blk in enumerate(blocks):
                 x = blk.attn(h, blk.shift_size, residual=x)
                 m = blk.mlp
-                x = hot_ops.mlp_split(x, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias, "gelu",
-                                      ln=(blk.norm2.weight, blk.norm2.bias, blk.norm2.eps), residual=x)
-                if i + 1 < len(blocks):
-                    nxt = blocks[i + 1].norm1
-                    _, h = hot_ops.add_layernorm(x, None, nxt.weight, nxt.bias, nxt.eps)
+                nxt = blocks[i + 1].norm1 if i + 1 < len(blocks) else None
+                y = hot_ops.mlp_split(x, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias, "gelu",
+                                      ln=(blk.norm2.weight, blk.norm2.bias, blk.norm2.eps), residual=x,
+                                      post_ln=None if nxt is None else (nxt.weight, nxt.bias, nxt.eps), return_sum=nxt is not None)
+                x, h = y if nxt is not None else (y, None)        # norm1 of the next block leaves in the same launch
             return x
         for i, blk in enumerate(blocks):
             a = blk.attn(h, blk.shift_size)

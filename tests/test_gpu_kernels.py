@@ -1328,3 +1328,18 @@ def test_mlp_split_post_layernorm(ops, M, cut):
     print(f"K23 + norm2, M = {M}: split {e_k:.2e}  library f32 {e_lib:.2e}")
     assert e_k < 2e-5 and e_k <= 1.5 * e_lib + 1e-6, (e_k, e_lib)
     assert torch.equal(got, ops.mlp_split(x, w1, b1, w2, b2, "relu", residual=x, post_ln=(gam, bet, 1e-5), cut=cut))
+
+
+@pytest.mark.parametrize("M,Cw,F", [(7360, 384, 1536), (28800, 192, 768), (5000, 96, 384)])
+def test_mlp_split_emits_sum_and_next_layernorm(ops, M, Cw, F):
+    """The Video-Swin stage-2 form of K23: x + mlp(norm2(x)) AND norm1 of the next block of it in one launch (reference
+    models/video_swin_transformer.py:219,262-272): both outputs against f64, the sum bit-equal to the launch without LN2."""
+    x, w1, b1, w2, b2, lnp = _mlp_case(M, Cw, F, "gelu", True, 11 * M + Cw)
+    g = torch.Generator().manual_seed(5)
+    gam, bet = (torch.rand(Cw, generator=g) + 0.5).cuda(), (torch.randn(Cw, generator=g) * 0.1).cuda()
+    s, h = ops.mlp_split(x, w1, b1, w2, b2, "gelu", lnp, residual=x, post_ln=(gam, bet, 1e-5), return_sum=True)
+    want = _mlp_f64(x, w1, b1, w2, b2, "gelu", lnp, x)
+    assert torch.equal(s, ops.mlp_split(x, w1, b1, w2, b2, "gelu", lnp, residual=x))
+    assert float((s.double() - want).abs().max()) < 1e-5 * float(want.abs().max())
+    want_h = torch.nn.functional.layer_norm(want, (Cw,), gam.double(), bet.double(), 1e-5)
+    assert float((h.double() - want_h).abs().max()) < 2e-5

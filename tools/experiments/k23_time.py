@@ -39,7 +39,7 @@ lib.soc_mlp_split_packed_bytes.restype = C.c_size_t
 lib.soc_mlp_split_packed_bytes.argtypes = [i, i]
 lib.soc_mlp_split_pack_f32.argtypes = [p, p, p, i, i, p]
 lib.soc_mlp_split_plan.argtypes = [C.c_long, i, i, C.POINTER(i), C.POINTER(i)]
-lib.soc_mlp_split_variant_f32.argtypes = [p, p, p, p, p, p, f, p, p, p, f, p, p, C.c_long, i, i, i, i, i, i, p]
+lib.soc_mlp_split_variant_f32.argtypes = [p, p, p, p, p, p, f, p, p, p, f, p, p, p, C.c_long, i, i, i, i, i, i, p]
 g = torch.Generator().manual_seed(0)
 quick = "--quick" in sys.argv
 
@@ -94,7 +94,7 @@ def case(name, M, Cw, F, act, ln, res, cuts, variants):
         for v in variants:
             def run():
                 return lib.soc_mlp_split_variant_f32(x.data_ptr(), packed.data_ptr(), b1.data_ptr(), b2.data_ptr(), ptr(gam),
-                                                     ptr(bet), 1e-5, ptr(r), None, None, 0.0, out.data_ptr(), ptr(ws), M, Cw, F,
+                                                     ptr(bet), 1e-5, ptr(r), None, None, 0.0, out.data_ptr(), None, ptr(ws), M, Cw, F,
                                                      1 if act == "relu" else 2, nrg, nfs, v, st)
             out.zero_()
             rc = run()
@@ -105,19 +105,18 @@ def case(name, M, Cw, F, act, ln, res, cuts, variants):
             err = (out.double() - ref).abs().max().item() / scale
             us = t(run, 10 if quick else 20)
             dbg = (v >> 5) & 15
-            tag = f"  NS={v & 7} SB={1 << ((v >> 3) & 3)} PF={((v >> 9) & 1) + 1}" + ("" if not dbg else "  [wrong on purpose:" + "".join(
+            tag = f"  NS={v & 7} SB={1 << ((v >> 3) & 3)} PF={((v >> 9) & 1) + 1} STAG={v >> 10}" + ("" if not dbg else "  [wrong on purpose:" + "".join(
                 n for b, n in ((1, " no DMA in loop"), (2, " no MFMA"), (4, " no fragment reads"), (8, " no activation")) if dbg & b) + "]")
             print(f"{name} M={M} C={Cw} F={F} cut ({nrg},{nfs}) variant {v:3d}: {us:7.1f} us  {fl / us / 1e6:6.1f} TFLOP/s  "
                   f"max err / max|ref| {err:.2e}{tag}", flush=True)
     return x, w1, b1, w2, b2, gam, bet, r, ref, scale
 
 
-def vr(ns=3, lsb=0, pf=1, dbg=0):
-    return ns + 8 * lsb + 32 * dbg + 512 * (pf - 1)
+def vr(ns=3, lsb=0, stag=0, pf=1, dbg=0):
+    return ns + 8 * lsb + 32 * dbg + 512 * (pf - 1) + 1024 * stag
 
 
-V = [0, vr(3, 1), vr(4, 1, pf=2), vr(6, 2), vr(7, 2), vr(4, 1, dbg=1), vr(4, 1, dbg=2), vr(4, 1, dbg=13)]
-x, w1, b1, w2, b2, gam, bet, r, ref, scale = case("s2", 7360, 384, 1536, "gelu", True, True, [None, (115, 1)], V)
-case("s2", 7360, 384, 1536, "gelu", True, True, [(58, 4), (230, 1), (77, 3)], [0])
-two = t(lambda: fused.linear(hot_ops.ws_linear(torch.nn.functional.layer_norm(x, (384,), gam, bet), w1, b1, None, None, "gelu"), w2, b2, residual=r))
-print(f"   LayerNorm, K13b fc1 + GELU, library fc2 + add on the same rows: {two:.1f} us", flush=True)
+V = [0, vr(3), vr(3, stag=1), vr(3, stag=3), vr(3, stag=2), vr(4, stag=1), vr(4, stag=3), vr(4, stag=2)]
+case("enc", 32768, 256, 2048, "relu", False, True, [(256, 1)], V)
+case("s0", 115200, 96, 384, "gelu", True, True, [(256, 1)], V)
+case("s1", 28800, 192, 768, "gelu", True, True, [None], V)
