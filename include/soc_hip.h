@@ -236,25 +236,11 @@ int soc_patch_merge_layernorm_f32(const float* x, const float* gamma, const floa
                                   int H, int W, int C, float eps, void* stream);
 
 /*
- * K22 -- the deformable encoder's feed-forward block in one launch, on the bf16 matrix cores (exact three-way operand
- * split, f32-grade results -- see soc_linear_split_f32): out = ReLU(x W1^T + b1) W2^T + b2 (+ residual).  Replaces
- * linear1 -> activation -> linear2 of DeformableTransformerEncoderLayer.forward_ffn (models/deformable_transformer.py:
- * 253-263); the [M, F] hidden tensor is never written.
- *   x [M, C], w1 [F, C], b1 [F], w2 [C, F], b2 [C], residual [M, C] or NULL, out [M, C]; C = 256, F % 32 == 0.
- *   soc_ffn_split_packed_bytes / soc_ffn_split_pack_f32: split and lay out both weights ONCE (opaque image `packed`);
- *   re-pack after the weights change.  Every pointer 16-byte aligned.
- */
-size_t soc_ffn_split_packed_bytes(int C, int F);
-int soc_ffn_split_pack_f32(const float* w1, const float* w2, void* packed, int C, int F, void* stream);
-int soc_ffn_split_f32(const float* x, const void* packed, const float* b1, const float* b2, const float* residual,
-                      float* out, long M, int C, int F, void* stream);
-
-/*
  * K23 -- a two-layer perceptron block in one launch, on the bf16 matrix cores (exact three-way operand split, f32-grade
  * results -- see soc_linear_split_f32):
  *     out = LN2(act(LN(x) W1^T + b1) W2^T + b2 + residual),   act 1 = ReLU, 2 = exact (erf) GELU;  LN, LN2, residual optional.
  * Replaces  x + mlp(norm2(x))  of SwinTransformerBlock3D.forward_part2 (models/video_swin_transformer.py:262-272 with
- * Mlp.forward :24-37: norm2, fc1, nn.GELU, fc2, the residual add) and, as K22 does, linear1 -> ReLU -> linear2 of
+ * Mlp.forward :24-37: norm2, fc1, nn.GELU, fc2, the residual add) and linear1 -> ReLU -> linear2 of
  * DeformableTransformerEncoderLayer.forward_ffn (models/deformable_transformer.py:253-263) with the residual add and norm2
  * behind it (post_gamma / post_beta: `src = norm2(src + dropout3(src2))`, :261-262).  The [M, F] hidden tensor is
  * never written.  Every row is taken: whole rounds of the chip stream both weight matrices once per 16 (C <= 96), 8

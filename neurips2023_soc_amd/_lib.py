@@ -16,8 +16,7 @@ EXPORTS = ("soc_hip_abi_version", "soc_hip_error_string", "soc_msda_fwd_f32", "s
            "soc_linear_small_f32", "soc_linear_small_multi_f32", "soc_box_refine_f32",
            "soc_upsample_merge_labels_u8", "soc_resize_workspace_bytes", "soc_resize_normalize_u8_f32",
            "soc_msda_bwd_f32", "soc_msda_bwd_f64", "soc_groupnorm_tokens_workspace_bytes",
-           "soc_groupnorm_tokens_f32", "soc_patch_merge_layernorm_f32", "soc_patch_embed_layernorm_f32", "soc_ffn_split_packed_bytes",
-           "soc_ffn_split_pack_f32", "soc_ffn_split_f32", "soc_linear_act_f32",
+           "soc_groupnorm_tokens_f32", "soc_patch_merge_layernorm_f32", "soc_patch_embed_layernorm_f32", "soc_linear_act_f32",
            "soc_linear_act_multi_f32", "soc_ws_linear_f32", "soc_ws_linear_set_split", "soc_ws_linear_get_split", "soc_decoder_cross_attn_f32",
            "soc_row_mlp_f32", "soc_groupnorm_nchw_f32", "soc_upsample_add_nchw_f32",
            "soc_upsample_add_tokens_f32", "soc_conv3x3_tokens_f32", "soc_linear_split_packed_bytes",
@@ -115,12 +114,6 @@ def load() -> C.CDLL:
     lib.soc_groupnorm_tokens_f32.argtypes = [p, p, p, p, i, i, i, i, f, i, p, C.c_size_t, p]
     lib.soc_patch_merge_layernorm_f32.restype = i
     lib.soc_patch_merge_layernorm_f32.argtypes = [p, p, p, p, i, i, i, i, f, p]
-    lib.soc_ffn_split_packed_bytes.restype = C.c_size_t
-    lib.soc_ffn_split_packed_bytes.argtypes = [i, i]
-    lib.soc_ffn_split_pack_f32.restype = i
-    lib.soc_ffn_split_pack_f32.argtypes = [p, p, p, i, i, p]
-    lib.soc_ffn_split_f32.restype = i
-    lib.soc_ffn_split_f32.argtypes = [p, p, p, p, p, p, C.c_long, i, i, p]
     lib.soc_mlp_split_packed_bytes.restype = C.c_size_t
     lib.soc_mlp_split_packed_bytes.argtypes = [i, i]
     lib.soc_mlp_split_pack_f32.restype = i

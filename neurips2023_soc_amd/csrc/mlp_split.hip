@@ -1,30 +1,35 @@
-// K23: a two-layer perceptron block in one kernel, on the bf16 matrix cores (exact three-way split) -- the generalisation of
-// K22 (ffn_split.hip) to the widths, activations and LayerNorm prologue of the Video-Swin MLP.
+// K23: a two-layer perceptron block in one kernel, on the bf16 matrix cores (exact three-way operand split).
 //
-//   out[M, C] = act(LN(x)[M, C] . W1[F, C]^T + b1) . W2[C, F]^T + b2 (+ residual)                  (f32 in, f32 out)
+//   out[M, C] = LN2(act(LN(x)[M, C] . W1[F, C]^T + b1) . W2[C, F]^T + b2 + residual)               (f32 in, f32 out)
 //
-// Replaces  x + mlp(norm2(x))  = norm2 -> fc1 -> GELU -> fc2 -> residual of SwinTransformerBlock3D.forward_part2
-// (reference models/video_swin_transformer.py:24-37, 262-272) and linear1 -> ReLU -> linear2 of the deformable encoder's
-// forward_ffn (models/deformable_transformer.py:253-263).  The [M, F] hidden tensor (177 MB per block at Video-Swin stage 0,
-// 316 MB per encoder layer) never exists.
+// Replaces  x + mlp(norm2(x))  = norm2 -> fc1 -> GELU -> fc2 -> shortcut of SwinTransformerBlock3D.forward_part2 (reference
+// models/video_swin_transformer.py:24-37, 262-272; optionally together with norm1 of the NEXT block, :219) and
+// norm2(src + linear2(relu(linear1(src)))) of the deformable encoder's forward_ffn (models/deformable_transformer.py:253-263).
+// The [M, F] hidden tensor (177 MB per block at Video-Swin stage 0, 316 MB per encoder layer) never exists.
 //
-// Data flow (K22's, see ffn_split.hip for the operand-layout argument):
+// Data flow:
 //   * a wave owns RT 16-row tiles of x and keeps them, normalised and split, as bf16 MFMA fragments (K = C);
-//   * the hidden layer is produced 32 columns (one chunk) at a time, H^T[32 x 16] = W1_chunk . x^T, + b1, activation; the two
-//     accumulator tiles ARE the B operand of the second product once split (the packed image of W2 carries the k-permutation);
-//   * out^T[C x 16] += W2_chunk . H_chunk^T over the chunks; + b2 (+ residual), 16-B stores.
-// New here:
-//   * the weight stream is a RING of NSLOT LDS slots filled by LDS-DMA up to NSLOT - 1 blocks ahead, handed over with a COUNTED
-//     vmcnt wait (only the block needed next must have landed) -- K22 had one block in flight and sat at the barrier for it;
-//   * weight fragments are read one group ahead of the MFMAs that consume them;
-//   * optional stagger: waves 4..7 run one block behind waves 0..3, so that the activation / split VALU phase of one wave of a
-//     SIMD sits beside the MFMAs of its partner (MI355X_MICROARCH.md, "Two waves per SIMD", item 9);
-//   * every row is taken: a workgroup owns a balanced contiguous share of the row tiles and deals the tiles of a part-filled
-//     pass round-robin over its waves (one per SIMD first), and for few rows the hidden dimension is split over `nfs`
-//     workgroup columns that write partial sums (deterministic: a reduce kernel adds them in a fixed order);
-//   * LayerNorm prologue as K13b (two-pass, the row lives in the four lanes that share it), exact-erf GELU.
-// Co-residence rule: all 256 VGPRs claimed, waves retire behind a barrier, packed f32 code has VGPR
-// operands only (tests/test_isa_rules.py).
+//   * the hidden layer is produced 32 columns (one chunk) at a time: H^T[32 x 16] = W1_chunk . x^T on
+//     v_mfma_f32_16x16x32_bf16 (six products per k-step, smallest first), starting from b1; lane (row m, kq) of the two
+//     16 x 16 accumulator tiles holds hidden columns 4 kq .. 4 kq + 3 of each -- once activated and split, that IS the B operand
+//     of the second product: eight k values per lane, in an order the packed image of W2 mirrors (k-permutation at pack time);
+//   * out^T[C x 16] += W2_chunk . H_chunk^T over the chunks in C / 4 accumulator registers per tile; b2 and the residual are
+//     added last, then (optionally) LayerNorm over the row, which lives in the four lanes (m, kq = 0..3); 16-B stores.
+// The weights stream through LDS:
+//   * per chunk a W1 block and a W2 block, pre-split, pre-permuted, laid out as the fragments are read (soc_mlp_split_pack_f32),
+//     travel through a RING of NSLOT slots filled by LDS-DMA up to NSLOT - 1 pieces ahead (a piece = 1 / SB of a block) and
+//     handed over with a COUNTED vmcnt wait: only the piece needed next must have landed;
+//   * the LDS-DMA is issued from inline assembly (see dma below): with a compiler-visible LDS-DMA in flight every LDS wait of
+//     the loop degrades to lgkmcnt(0) and fragment reads cannot run ahead of the MFMAs;
+//   * weight fragments are read PF groups ahead of the MFMAs that consume them (sched_group_barrier pins the order).
+// Every row is taken: a workgroup owns a balanced contiguous share of the row tiles and deals the tiles of a part-filled pass
+// round-robin over its waves (one per SIMD first); for few rows the hidden dimension is split over `nfs` workgroup columns
+// that write partial sums, which a reduce kernel adds in a fixed order (deterministic) together with b2 / residual / LN2.
+// C <= 256: eight 256-register waves (two per SIMD); C = 384: four 512-register waves, blocks travel as half-block pieces.
+// Measured null and kept as diagnostic variants only (SOC_K23_VARIANTS): waves 4..7 one piece behind waves 0..3, the
+// activation at raised wave priority, deeper fragment prefetch, four-wave forms for C <= 256 (tools/experiments/README.md).
+// Co-residence rule: the whole register file is claimed, waves retire behind a barrier, packed f32 code
+// has VGPR operands only (tests/test_isa_rules.py).
 #include "soc_common.h"
 #include "split_math.h"
 #include <atomic>

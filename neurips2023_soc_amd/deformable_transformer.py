@@ -36,7 +36,7 @@ class DeformableTransformerEncoderLayer(nn.Module):
             # K23: linear1 + ReLU + linear2 + residual + norm2 in one launch (whole rounds of the chip + a split tail)
             return hot_ops.mlp_split(src, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias, "relu",
                                      residual=src, post_ln=(self.norm2.weight, self.norm2.bias, self.norm2.eps))
-        return _add_norm(src, fused.ffn_relu(src, self.linear1, self.linear2), self.norm2)     # K22 + remainder
+        return _add_norm(src, fused.ffn_relu(src, self.linear1, self.linear2), self.norm2)
 
 
 class DeformableTransformerEncoder(nn.Module):

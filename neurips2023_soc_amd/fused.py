@@ -25,24 +25,10 @@ def is_small(x: torch.Tensor) -> bool:
 
 def ffn_relu(x: torch.Tensor, lin1: nn.Linear, lin2: nn.Linear) -> torch.Tensor:
     """lin2(relu(lin1(x))) -- the deformable encoder's feed-forward block (reference models/deformable_transformer.py:
-    253-263).  K22 keeps the hidden layer in registers; a launch streams both weight matrices once per 32 768 rows (8 waves
-    x 16 rows on each of the 256 CUs), so whole multiples of that go to K22 and a short remainder (5 792 of the 38 560
-    rows at the BASELINE config: 374 + 120 us instead of 630) to the two-GEMM path."""
-    C = x.shape[-1]
-    rows = x.numel() // C
-    if hot_ops.ffn_split_supported(x, lin1.weight, lin2.weight) and lin1.bias is not None and lin2.bias is not None \
-            and rows >= 4096:
-        unit = 32768
-        full = (rows // unit) * unit
-        if rows - full >= (3 * unit) // 5 or full == 0:
-            full = rows                                   # the last pass is filled well enough (or it is the only one)
-        x2 = x.reshape(rows, C)
-        if full == rows:
-            return hot_ops.ffn_split(x2, lin1.weight, lin1.bias, lin2.weight, lin2.bias).view(x.shape)
-        out = torch.empty_like(x2)
-        hot_ops.ffn_split(x2[:full], lin1.weight, lin1.bias, lin2.weight, lin2.bias, out=out[:full])
-        out[full:] = apply(lin2, linear_relu(x2[full:], lin1))
-        return out.view(x.shape)
+    253-263): K23 in one launch where it covers the shape (the encoder layer calls it with the residual and norm2 folded in as
+    well), the two-GEMM path otherwise (SOC_MATMUL=f32, SOC_SPLIT_OFF=mlp, few rows)."""
+    if mlp_ok(x, lin1, lin2):
+        return hot_ops.mlp_split(x, lin1.weight, lin1.bias, lin2.weight, lin2.bias, "relu")
     return apply(lin2, linear_relu(x, lin1))
 
 
@@ -77,24 +63,51 @@ def _split_ok(x: torch.Tensor, weight: torch.Tensor, fused_passes: int, site: st
             and hot_ops.split_wins(x.numel() // K, weight.shape[0], K, fused_passes, site))
 
 
+def route_linear(x, weight, bias=None, add=None, relu: bool = False, mul=None, residual=None) -> str:
+    """Which kernel runs mul * act((x [+ add]) @ weight.T + bias) + residual: "k7" (few rows), "k13b", "k20", or "library".
+    Decided from shapes, dtypes and devices only (tests/test_routes.py drives it with stand-ins for every layer of the five
+    BASELINE configurations and pins the answers, so that a silent fall-back to the library fails a test)."""
+    if is_small(x):
+        return "k7"
+    if add is None and mul is None and ws_plain_ok(x, weight):
+        return "k13b"
+    n_fused = int(add is not None) + int(relu) + int(mul is not None) + int(residual is not None)
+    site = "relu" if relu else ("mul" if mul is not None else ("res" if residual is not None else ("add" if add is not None else "plain")))
+    if _split_ok(x, weight, n_fused, site) and (add is None or tuple(add.shape) == tuple(x.shape)):
+        return "k20"
+    return "library"
+
+
+def route_gelu(x, weight) -> str:
+    """Which kernel runs gelu(x @ weight.T + bias): "k13b", "k20", "k12" or "library" (+ a GELU pass)."""
+    K = x.shape[-1]
+    rows = x.numel() // K
+    if ws_dense_ok(x, weight):
+        return "k13b"
+    if _split_ok(x, weight, 1, "gelu"):
+        return "k20"
+    if x.is_cuda and x.dtype == torch.float32 and rows >= 16384 and K <= 256 and K % 16 == 0 and weight.shape[0] % 4 == 0:
+        return "k12"
+    return "library"
+
+
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
            add: Optional[torch.Tensor] = None, relu: bool = False, mul: Optional[torch.Tensor] = None,
            residual: Optional[torch.Tensor] = None) -> torch.Tensor:
     """mul * act((x [+ add]) @ weight.T + bias) + residual; `add` broadcasts like `x + add`."""
     K = x.shape[-1]
-    if is_small(x):
+    route = route_linear(x, weight, bias, add, relu, mul, residual)
+    if route == "k7":
         if add is not None and add.shape != x.shape:
             add = add.expand_as(x)
         y = hot_ops.linear_small(x, weight, bias, add, relu)
         if mul is not None:
             y = y * mul
         return y if residual is None else y + residual
-    if add is None and mul is None and ws_plain_ok(x, weight):
-        return hot_ops.ws_linear(x, weight, bias, None, residual, "relu" if relu else "none")       # K13b
-    n_fused = int(add is not None) + int(relu) + int(mul is not None) + int(residual is not None)
-    site = "relu" if relu else ("mul" if mul is not None else ("res" if residual is not None else ("add" if add is not None else "plain")))
-    if _split_ok(x, weight, n_fused, site) and (add is None or add.shape == x.shape):
-        # K20: the positional add in front and ReLU / mul / residual behind are part of the launch
+    if route == "k13b":
+        return hot_ops.ws_linear(x, weight, bias, None, residual, "relu" if relu else "none")
+    if route == "k20":
+        # the positional add in front and ReLU / mul / residual behind are part of the launch
         return hot_ops.linear_split(x, weight, bias, None, residual, "relu" if relu else "none", add, mul)
     if mul is not None or residual is not None:
         y = linear(x, weight, bias, add, relu)
@@ -111,21 +124,32 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     return F.relu(y) if relu else y
 
 
-def linear_multi(x: torch.Tensor, layers, add: Optional[torch.Tensor] = None):
-    """[(x + add if use_add else x) @ W.T + b for (W, b, use_add) in layers]: one K7 launch for few rows,
-    one library GEMM per layer otherwise."""
+def route_linear_multi(x, layers, add=None) -> str:
+    """Which kernel runs several layers on the same (x [+ add]): "k7" (few rows, up to four layers), "k20" (two stacked layers
+    as one two-output launch, x + pos in the loader), "k12" (the f32-MFMA form of the same) or "library"."""
     if is_small(x) and len(layers) <= 4:
-        return hot_ops.linear_small_multi(x, layers, add)
+        return "k7"
     K = x.shape[-1]
-    if (x.is_cuda and x.dtype == torch.float32 and len(layers) == 2 and add is not None and add.shape == x.shape
-            and all(u for _, _, u in layers) and all(b is not None for _, b, _ in layers)
-            and _split_ok(x, layers[0][0], 2, "multi") and layers[0][0].shape[0] % 4 == 0 and layers[1][0].shape[0] % 4 == 0):
+    two_on_sum = (x.is_cuda and x.dtype == torch.float32 and len(layers) == 2 and add is not None
+                  and tuple(add.shape) == tuple(x.shape) and all(u for _, _, u in layers)
+                  and all(w.shape[0] % 4 == 0 for w, _, _ in layers))
+    if two_on_sum and all(b is not None for _, b, _ in layers) and _split_ok(x, layers[0][0], 2, "multi"):
+        return "k20"
+    if two_on_sum and K % 16 == 0 and K <= 256:
+        return "k12"
+    return "library"
+
+
+def linear_multi(x: torch.Tensor, layers, add: Optional[torch.Tensor] = None):
+    """[(x + add if use_add else x) @ W.T + b for (W, b, use_add) in layers] on the kernel route_linear_multi names."""
+    route = route_linear_multi(x, layers, add)
+    if route == "k7":
+        return hot_ops.linear_small_multi(x, layers, add)
+    if route == "k20":
         # K20 with two outputs: both layers' rows stacked into one weight image (cached), x + pos in the loader
         w, b = _stacked(layers[0][0], layers[0][1], layers[1][0], layers[1][1])
         return list(hot_ops.linear_split(x, w, b, add=add, split_at=layers[0][0].shape[0]))
-    if (x.is_cuda and x.dtype == torch.float32 and len(layers) == 2 and add is not None and add.shape == x.shape
-            and all(u for _, _, u in layers) and K % 16 == 0 and K <= 256
-            and all(w.shape[0] % 4 == 0 for w, _, _ in layers)):
+    if route == "k12":
         # two pixel-sized layers on x + pos (the deformable encoder's sampling offsets and attention weights):
         # one K12 launch with the add in its prologue instead of an add kernel and two library GEMMs
         return hot_ops.linear_act_multi(x, [(w, b) for w, b, _ in layers], add)
@@ -158,17 +182,14 @@ def linear_relu(x: torch.Tensor, lin: nn.Linear) -> torch.Tensor:
 
 
 def linear_gelu(x: torch.Tensor, lin: nn.Linear) -> torch.Tensor:
-    """gelu(lin(x)), exact (erf) GELU.  Tall inputs with a short reduction (Video-Swin stages 0-1: >= 16384
-    tokens, K <= 256) run as K12 with the GELU applied to the accumulators; elsewhere the library GEMM is
-    faster than K12 by more than the separate GELU pass costs (tools/gemm_probe.py) and is kept."""
-    K = x.shape[-1]
-    rows = x.numel() // K
-    if ws_dense_ok(x, lin.weight):
-        return hot_ops.ws_linear(x, lin.weight, lin.bias, act="gelu")           # K13b, GELU on the accumulators
-    if _split_ok(x, lin.weight, 1, "gelu"):
-        return hot_ops.linear_split(x, lin.weight, lin.bias, act="gelu")      # K20: GELU on the accumulators
-    if (x.is_cuda and x.dtype == torch.float32 and rows >= 16384 and K <= 256 and K % 16 == 0
-            and lin.out_features % 4 == 0):
+    """gelu(lin(x)), exact (erf) GELU, on the kernel route_gelu names: K13b / K20 apply it to the accumulators; K12 (tall inputs
+    with a short reduction, f32 MFMA) likewise; elsewhere the library GEMM + a GELU pass."""
+    route = route_gelu(x, lin.weight)
+    if route == "k13b":
+        return hot_ops.ws_linear(x, lin.weight, lin.bias, act="gelu")
+    if route == "k20":
+        return hot_ops.linear_split(x, lin.weight, lin.bias, act="gelu")
+    if route == "k12":
         return hot_ops.linear_act(x, lin.weight, lin.bias, "gelu")
     return F.gelu(lin(x))
 

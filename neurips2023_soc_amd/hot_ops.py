@@ -984,50 +984,6 @@ def split_tile_for(M: int, N: int, K: int) -> int:
     return cfg
 
 
-_ffn_cache = {}
-
-
-def ffn_split_supported(x: Tensor, w1: Tensor, w2: Tensor) -> bool:
-    """K22 takes ReLU(x w1^T + b1) w2^T + b2: CUDA fp32, model width 256, hidden width a multiple of 32, split arithmetic on."""
-    return (x.is_cuda and x.dtype == torch.float32 and split_enabled() and "ffn" not in _SPLIT_OFF and x.shape[-1] == 256
-            and tuple(w1.shape[1:]) == (256,) and w2.shape == (256, w1.shape[0]) and w1.shape[0] % 32 == 0
-            and w1.dtype == torch.float32 and w2.dtype == torch.float32)
-
-
-def ffn_split(x: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor, residual: Optional[Tensor] = None,
-              out: Optional[Tensor] = None) -> Tensor:
-    """K22: ReLU(x @ w1.T + b1) @ w2.T + b2 (+ residual) in one launch, the hidden layer in registers.  The packed weight
-    image is cached per (weights, versions) and rebuilt after an in-place update."""
-    _need_gpu(x, w1, b1, w2, b2, residual)
-    lib = _lib.load()
-    x = _f32c(x)
-    F_, C_ = w1.shape
-    M = x.numel() // C_
-    key = (w1.data_ptr(), w2.data_ptr(), w1._version, w2._version, F_, C_, x.device.index)
-    ent = _ffn_cache.get((w1.data_ptr(), w2.data_ptr()))
-    if ent is None or ent[0] != key:
-        packed = torch.empty(lib.soc_ffn_split_packed_bytes(C_, F_), dtype=torch.uint8, device=x.device)
-        _lib.check(lib.soc_ffn_split_pack_f32(_f32c(w1).data_ptr(), _f32c(w2).data_ptr(), packed.data_ptr(), C_, F_, _stream()),
-                   "soc_ffn_split_pack_f32")
-        if len(_ffn_cache) > 256:
-            _ffn_cache.clear()
-        ent = (key, packed, (w1, w2))                 # the keyed tensors stay alive: their addresses cannot be reused
-        _ffn_cache[(w1.data_ptr(), w2.data_ptr())] = ent
-    if out is None:
-        out = torch.empty_like(x)
-    elif out.shape != x.shape or out.dtype != torch.float32 or not out.is_contiguous() or out.device != x.device:
-        raise _lib.SocHipError("ffn_split: `out` must be a contiguous float32 tensor of the input's shape on its device")
-    if residual is not None:
-        residual = _f32c(residual)
-        if residual.shape != x.shape:
-            raise _lib.SocHipError("ffn_split: residual shape differs from the input's")
-    with _timed("ffn_split", 4.0 * M * F_ * C_):
-        rc = lib.soc_ffn_split_f32(x.data_ptr(), ent[1].data_ptr(), _f32c(b1).data_ptr(), _f32c(b2).data_ptr(),
-                                   residual.data_ptr() if residual is not None else None, out.data_ptr(), M, C_, F_, _stream())
-    _lib.check(rc, "soc_ffn_split_f32")
-    return out
-
-
 MLP_SPLIT_C = (96, 128, 192, 256, 384)  # model widths K23 is built for
 _MLP_ACT = {"relu": 1, "gelu": 2}
 _mlp_cache = {}

@@ -98,7 +98,7 @@ class MSDeformAttn(nn.Module):
         _, S, _ = input_flatten.shape
         M, L, P = self.n_heads, self.n_levels, self.n_points
         if value is None:
-            value = self.value_proj(input_flatten)
+            value = fused.apply(self.value_proj, input_flatten)     # K13b on pixel-sized memories, K7 / library otherwise
         offsets_raw, logits_raw = fused.linear_multi(
             query, [(self.sampling_offsets.weight, self.sampling_offsets.bias, True),
                     (self.attention_weights.weight, self.attention_weights.bias, True)], query_pos)

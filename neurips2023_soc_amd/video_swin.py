@@ -111,10 +111,8 @@ class BasicLayer(nn.Module):
         with the LayerNorm that consumes its result (K5): x += attn -> norm2, x += mlp -> next block's norm1.  Same
         values as block-by-block."""
         blocks = self.blocks
-        # stage 1 (C = 192) in the split arithmetic: K13b beats K20 on qkv / proj / fc1 (49 / 24 / 71 against 60 / 30 / 74 us,
-        # tools/experiments/k13b_time.py); with SOC_SPLIT_OFF=k13 the K20 flow below takes it
-        prefer_ws = hot_ops.k13_split_enabled() and x.shape[-1] in hot_ops.WS_SPLIT_LN_K and self._weight_stationary(x)
-        if not prefer_ws and self._split_flow(x):
+        flow = self.stage_flow(x)
+        if flow == "k20":
             # K20 (bf16 matrix cores, exact three-way split): LayerNorm folded into the layer, GELU / residual in its
             # epilogue -- norm1 + qkv | K1 | proj + residual | norm2 + fc1 + GELU | fc2 + residual
             for blk in blocks:
@@ -123,6 +121,10 @@ class BasicLayer(nn.Module):
                 o = hot_ops.window_attention3d(qkv, a.qkv.bias, a.relative_position_bias_table, a.num_heads,
                                                a.window_size, blk.shift_size)
                 x = hot_ops.linear_split(o, a.proj.weight, a.proj.bias, residual=x)
+                if fused.mlp_ok(x, m.fc1, m.fc2):      # C = 256 (Swin-B stage 1): norm2 + fc1 + GELU + fc2 + shortcut in one K23 launch
+                    x = hot_ops.mlp_split(x, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias, "gelu",
+                                          ln=(blk.norm2.weight, blk.norm2.bias, blk.norm2.eps), residual=x)
+                    continue
                 h = hot_ops.linear_split(x, m.fc1.weight, m.fc1.bias, ln=(blk.norm2.weight, blk.norm2.bias, blk.norm2.eps),
                                          act="gelu")
                 if _FORCE_SPLIT_FLOW:
@@ -130,7 +132,7 @@ class BasicLayer(nn.Module):
                 else:
                     x = fused.linear(h, m.fc2.weight, m.fc2.bias, residual=x)  # K20 or library + add (split_wins)
             return x
-        if self._weight_stationary(x):
+        if flow == "ws":
             for blk in blocks:
                 a = blk.attn
                 qkv = hot_ops.ws_linear(x, a.qkv.weight, a.qkv.bias, ln=(blk.norm1.weight, blk.norm1.bias, blk.norm1.eps))
@@ -150,7 +152,7 @@ class BasicLayer(nn.Module):
                     x = x + blk.mlp.fc2(h)
             return x
         _, h = hot_ops.add_layernorm(x, None, blocks[0].norm1.weight, blocks[0].norm1.bias, blocks[0].norm1.eps)
-        if fused.mlp_ok(x, blocks[0].mlp.fc1, blocks[0].mlp.fc2):
+        if flow == "k23":
             # stage 2 (C = 384): the shortcut rides in the projection's epilogue, norm2 + fc1 + GELU + fc2 + shortcut are one K23
             # launch that also emits norm1 of the next block: no LayerNorm pass inside the stage
             for i, blk in enumerate(blocks):
@@ -172,6 +174,25 @@ class BasicLayer(nn.Module):
             else:
                 x = x + m
         return x
+
+    def stage_flow(self, x) -> str:
+        """How the blocks of this stage run (shapes, dtypes and devices only -- tests/test_routes.py pins it per configuration):
+        "ws"  K13b launches around K1, LayerNorms in their prologues, the MLP as one K23 launch where K23 covers the width
+              (tall stages of width 96 / 128 / 192: stages 0-1 of Swin-T / -S, stage 0 of Swin-B);
+        "k20" every layer on K20, LayerNorm folded into the packed weights (tall stages wider than that: Swin-B stage 1, and
+              stage 1 of the others with SOC_SPLIT_OFF=k13);
+        "k23" one LayerNorm pass at the stage's entry, then per block qkv | K1 | proj + shortcut | K23 (norm2 + MLP + shortcut +
+              norm1 of the next block): stage 2 of Swin-T / -S (C = 384);
+        "k5"  every shortcut add fused with the LayerNorm that consumes it (K5), GEMMs per fused.route_*: the rest."""
+        blk = self.blocks[0]
+        # stage 1 (C = 192) in the split arithmetic: K13b beats K20 on qkv / proj / fc1 (49 / 24 / 71 against 60 / 30 / 74 us,
+        # tools/experiments/k13b_time.py); with SOC_SPLIT_OFF=k13 the K20 flow takes it
+        prefer_ws = hot_ops.k13_split_enabled() and x.shape[-1] in hot_ops.WS_SPLIT_LN_K and self._weight_stationary(x)
+        if not prefer_ws and self._split_flow(x):
+            return "k20"
+        if self._weight_stationary(x):
+            return "ws"
+        return "k23" if fused.mlp_ok(x, blk.mlp.fc1, blk.mlp.fc2) else "k5"
 
     def _split_flow(self, x: torch.Tensor) -> bool:
         """Tall stages wider than K13's sweet spot (C >= 192: stage 1 of Swin-T / -S, stages 1 of Swin-B): every layer on

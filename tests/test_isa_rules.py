@@ -1,12 +1,14 @@
-"""ISA-level rules of the two bf16-MFMA kernels (K20 split linear, K1 split window attention), checked on the
-cross-compiled gfx950 assembly (no GPU needed).
+"""ISA-level rules of EVERY kernel that issues bf16 MFMAs (K20 split linear, K1 split window attention, K13b, K23, and
+whatever comes next), checked on the cross-compiled gfx950 assembly (no GPU needed).  The source files are DISCOVERED -- any
+csrc/*.hip that names a bf16 MFMA builtin -- so a new kernel cannot skip the lint by not being listed here.
 
 Measured on MI355X (tools/experiments/pk_mfma_probe.hip, profiles/r03_pk_mfma_probe.txt): while a wave that mixes bf16
-MFMAs with LDS traffic (LDS-DMA loads in K20, ds reads in K1) is resident, v_pk_fma_f32 instructions with an SGPR source
-executed by OTHER waves of the same SIMD -- another kernel's included -- return wrong low halves in lanes 48..63.  Both
-kernels therefore (a) claim the whole register file of their SIMDs, so that no other kernel's wave is ever resident
-beside them, and (b) keep their own packed f32 arithmetic on VGPR operands.  Both are properties of the generated code,
-not of the source, so they are tested on the assembly."""
+MFMAs with LDS traffic (LDS-DMA loads in K20 / K23, ds reads in K1 / K13b) is resident, v_pk_fma_f32 instructions with
+an SGPR source executed by OTHER waves of the same SIMD -- another kernel's included -- return wrong low halves in lanes
+48..63.  These kernels therefore (a) claim the whole register file of their SIMDs, so that no other kernel's wave is ever
+resident beside them, (b) keep their own packed f32 arithmetic on VGPR operands, (c) retire their waves behind a barrier.
+All three are properties of the generated code, not of the source, so they are tested on the assembly."""
+import glob
 import os
 import re
 import shutil
@@ -15,96 +17,113 @@ import subprocess
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "neurips2023_soc_amd", "csrc")
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+BF16_MFMA_SRC = re.compile(r"__builtin_amdgcn_mfma_f32_\d+x\d+x\d+_?bf16|mfma6\(")
+BF16_MFMA_ISA = re.compile(r"\bv_mfma_f32_\d+x\d+x\d+_bf16\b")
 
 
-def _asm(tmp_path_factory, source):
+def bf16_mfma_sources():
+    """csrc/*.hip that issue bf16 MFMAs, directly or through split_math.h's mfma6()."""
+    out = []
+    for path in sorted(glob.glob(os.path.join(CSRC, "*.hip"))):
+        with open(path) as f:
+            if BF16_MFMA_SRC.search(f.read()):
+                out.append(os.path.basename(path))
+    return out
+
+
+SOURCES = bf16_mfma_sources()
+
+
+def test_every_known_bf16_mfma_kernel_file_is_discovered():
+    assert {"linear_split.hip", "win_attn3d.hip", "ws_linear_split.hip", "mlp_split.hip"} <= set(SOURCES), SOURCES
+
+
+@pytest.fixture(scope="module", params=SOURCES)
+def unit(request, tmp_path_factory):
     if not os.path.exists(HIPCC):
         pytest.skip("hipcc not available")
-    out = tmp_path_factory.mktemp("isa") / (source + ".s")
-    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", os.path.join(ROOT, "include"),
-                    "--cuda-device-only", "-S", "-o", str(out),
-                    os.path.join(ROOT, "neurips2023_soc_amd", "csrc", source)], check=True)
-    return out.read_text()
+    src = request.param
+    out = tmp_path_factory.mktemp("isa") / (src + ".s")
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-I", CSRC,
+                    "--cuda-device-only", "-S", "-o", str(out), os.path.join(CSRC, src)], check=True)
+    asm = out.read_text()
+    bodies = {m.group(1): m.group(2) for m in re.finditer(r"^(_Z\w+):[^\n]*\n(.*?)s_endpgm", asm, re.S | re.M)}
+    meta = {}
+    for m in re.finditer(r"- \.agpr_count:\s+(\d+)\n(.*?)\.wavefront_size:", asm, re.S):
+        block = m.group(0)
+        name = re.search(r"\.name:\s+(\S+)", block).group(1)
+        meta[name] = {k: int(re.search(r"\.%s:\s+(\d+)" % k, block).group(1))
+                      for k in ("agpr_count", "vgpr_count", "max_flat_workgroup_size", "private_segment_fixed_size")}
+    kernels = {n: b for n, b in bodies.items() if BF16_MFMA_ISA.search(b)}
+    assert kernels, f"{src}: no kernel with a bf16 MFMA found in the assembly"
+    assert set(kernels) <= set(meta), sorted(set(kernels) - set(meta))[:3]
+    return src, kernels, meta
 
 
-@pytest.fixture(scope="module")
-def k20_asm(tmp_path_factory):
-    return _asm(tmp_path_factory, "linear_split.hip")
-
-
-@pytest.fixture(scope="module")
-def k1_asm(tmp_path_factory):
-    return _asm(tmp_path_factory, "win_attn3d.hip")
-
-
-def _kernel_bodies(asm, needle):
-    # "<symbol>:" ... "s_endpgm"
-    for m in re.finditer(r"^(_Z\w*%s\w*):[^\n]*\n(.*?)s_endpgm" % needle, asm, re.S | re.M):
-        yield m.group(1), m.group(2)
-
-
-def test_k20_keeps_packed_f32_math_off_sgpr_operands(k20_asm):
-    bodies = list(_kernel_bodies(k20_asm, "linear_split_kernel"))
-    assert len(bodies) == 5, [b[0] for b in bodies]
-    for name, body in bodies:
-        assert "global_load_lds_dwordx4" in body and "v_mfma_f32_32x32x16_bf16" in body, name
+def test_packed_f32_math_stays_off_sgpr_operands(unit):
+    src, kernels, _ = unit
+    for name, body in kernels.items():
         bad = [ln.strip() for ln in body.splitlines()
                if re.search(r"\bv_pk_(fma|mul|add)_f32\b", ln) and re.search(r"[ ,]s\[\d+:\d+\]", ln)]
-        assert not bad, (name, bad[:4])
+        assert not bad, (src, name, bad[:4])
 
 
-def test_k20_claims_the_whole_register_file(k20_asm):
-    counts = re.findall(r"\.name:\s+(_Z\w*linear_split_kernel\w*)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)", k20_asm)
-    assert len(counts) == 5, counts
-    for name, vgprs in counts:      # 2 waves per SIMD x 256 = the 512-entry file: nothing else fits on the CU
-        assert int(vgprs) == 256, (name, vgprs)
-    assert not re.search(r"linear_split_kernel\w*\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+[1-9]", k20_asm)
+def test_the_whole_register_file_is_claimed(unit):
+    """2 waves per SIMD x 256 registers or 1 wave x 512 = the 512-entry file: nothing else fits on the CU (`.vgpr_count` of the
+    code object metadata is the unified allocation, accumulation registers included)."""
+    src, kernels, meta = unit
+    for name in kernels:
+        m = meta[name]
+        waves_per_simd = max(1, m["max_flat_workgroup_size"] // 256)
+        assert m["vgpr_count"] * waves_per_simd == 512, (src, name, m)
 
 
-def test_k1_split_follows_the_same_rules(k1_asm):
-    bodies = list(_kernel_bodies(k1_asm, "win_attn3d_split_kernel"))
-    assert len(bodies) == 2, [b[0] for b in bodies]
-    for name, body in bodies:
-        assert "v_mfma_f32_16x16x32_bf16" in body and "ds_read_b64_tr_b16" in body, name
-        bad = [ln.strip() for ln in body.splitlines()
-               if re.search(r"\bv_pk_(fma|mul|add)_f32\b", ln) and re.search(r"[ ,]s\[\d+:\d+\]", ln)]
-        assert not bad, (name, bad[:4])
-    counts = re.findall(r"\.name:\s+(_Z\w*win_attn3d_split_kernel\w*)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)", k1_asm)
-    assert len(counts) == 2 and all(int(v) == 256 for _, v in counts), counts
+def test_the_waves_retire_behind_a_barrier(unit):
+    src, kernels, _ = unit
+    for name, body in kernels.items():
+        tail = body[body.rfind("s_barrier"):] if "s_barrier" in body else None
+        assert tail is not None, (src, name)
+        assert not BF16_MFMA_ISA.search(tail), (src, name, "MFMAs behind the last barrier")
 
 
-@pytest.fixture(scope="module")
-def k13b_asm(tmp_path_factory):
-    return _asm(tmp_path_factory, "ws_linear_split.hip")
+def test_no_scratch_in_the_shipped_kernels(unit):
+    """A spilled register is re-loaded through the vector-memory counter the LDS-DMA ring is paced by (K23: a scratch load in
+    the block loop would wait for every piece in flight)."""
+    src, kernels, meta = unit
+    for name in kernels:
+        assert meta[name]["private_segment_fixed_size"] == 0, (src, name, meta[name])
 
 
-def test_k13b_follows_the_same_rules(k13b_asm):
-    bodies = list(_kernel_bodies(k13b_asm, "ws_linear_split_kernel"))
-    assert len(bodies) >= 20, len(bodies)
-    for name, body in bodies:
-        assert "v_mfma_f32_16x16x32_bf16" in body and "s_barrier" in body, name
-        bad = [ln.strip() for ln in body.splitlines()
-               if re.search(r"\bv_pk_(fma|mul|add)_f32\b", ln) and re.search(r"[ ,]s\[\d+:\d+\]", ln)]
-        assert not bad, (name, bad[:4])
-    counts = re.findall(r"\.name:\s+(_Z\w*ws_linear_split_kernel\w*)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)", k13b_asm)
-    assert len(counts) == len(bodies) and all(int(v) == 256 for _, v in counts), counts[:3]
-    spills = re.findall(r"\.name:\s+_Z\w*ws_linear_split_kernel\w*\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)", k13b_asm)
-    assert spills and all(int(v) == 0 for v in spills), spills
-
-
-@pytest.fixture(scope="module")
-def k22_asm(tmp_path_factory):
-    return _asm(tmp_path_factory, "ffn_split.hip")
-
-
-def test_k22_follows_the_same_rules(k22_asm):
-    bodies = list(_kernel_bodies(k22_asm, "ffn_split_kernel"))
-    assert len(bodies) == 1
-    name, body = bodies[0]
-    assert "v_mfma_f32_16x16x32_bf16" in body and "global_load_lds_dwordx4" in body and "s_barrier" in body
-    bad = [ln.strip() for ln in body.splitlines()
-           if re.search(r"\bv_pk_(fma|mul|add)_f32\b", ln) and re.search(r"[ ,]s\[\d+:\d+\]", ln)]
-    assert not bad, bad[:4]
-    counts = re.findall(r"\.name:\s+(_Z\w*ffn_split_kernel\w*)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)", k22_asm)
-    assert counts and all(int(v) == 256 for _, v in counts), counts
+def test_k23_ring_discipline(unit):
+    """mlp_split.hip issues its LDS-DMA from inline assembly (so that the compiler keeps counted lgkmcnt waits for the fragment
+    reads) and paces the ring with its own counted vmcnt in front of every barrier: m0 is written inside those statements
+    only and every hand-off barrier follows its own counted s_waitcnt vmcnt."""
+    src, kernels, _ = unit
+    if src != "mlp_split.hip":
+        pytest.skip("K23 only")
+    for name, body in kernels.items():
+        n_dma = n_handoff = 0
+        in_asm = False
+        prev = ""
+        for raw in body.splitlines():
+            ln = raw.strip()
+            if "#ASMSTART" in ln:
+                in_asm = True
+                continue
+            if "#ASMEND" in ln:
+                in_asm = False
+                continue
+            if not ln or ln.startswith(";"):
+                continue
+            if re.search(r"\bm0\b", ln):
+                assert in_asm, (name, ln)
+            if ln.startswith("global_load_lds"):
+                assert in_asm, (name, ln)
+                n_dma += 1
+            if ln.startswith("s_barrier") and in_asm:      # a ring hand-off (the two __syncthreads() sit outside the ring)
+                assert prev.startswith("s_waitcnt vmcnt("), (name, prev, ln)
+                n_handoff += 1
+            prev = ln
+        assert n_dma > 0 and n_handoff > 0, name

@@ -1,5 +1,5 @@
 """Launch one hot kernel repeatedly at a BASELINE-config geometry (for rocprofv3 --pmc passes).
-usage: python tools/run_kernel.py {k1s0|k1s1|k1s2|k1s3|msda|vlf|dyn|k20ffn|k20qkv1|k20fc1s2|k13qkv0|k13fc1s0|k13qkv2|k22|k23s0|k23s1|k23s2|k23enc} [reps]
+usage: python tools/run_kernel.py {k1s0|k1s1|k1s2|k1s3|msda|vlf|dyn|k20ffn|k20qkv1|k20fc1s2|k13qkv0|k13fc1s0|k13qkv2|k23s0|k23s1|k23s2|k23enc} [reps]
 (SOC_MATMUL=f32 in the environment keeps K1 on the f32-input MFMA form: the ablation partner of the default split form)"""
 import sys
 
@@ -54,11 +54,6 @@ elif which.startswith("k13"):
     b = torch.randn(N, generator=g).to(dev)
     ln = ((torch.rand(K, generator=g) + 0.5).to(dev), torch.randn(K, generator=g).to(dev), 1e-5) if use_ln else None
     fn = lambda: hot_ops.ws_linear(x, wt, b, ln, None, act)  # noqa: E731
-elif which == "k22":
-    x = torch.randn(32768, 256, generator=g).to(dev)
-    w1, b1 = (torch.randn(2048, 256, generator=g) / 16).to(dev), torch.randn(2048, generator=g).to(dev)
-    w2, b2 = (torch.randn(256, 2048, generator=g) / 45).to(dev), torch.randn(256, generator=g).to(dev)
-    fn = lambda: hot_ops.ffn_split(x, w1, b1, w2, b2)  # noqa: E731
 elif which.startswith("k23"):
     # K23 at its four call sites: Video-Swin stage 0 / 1 / 2 MLP (norm2 + fc1 + GELU + fc2 + shortcut), the encoder's FFN + norm2
     M, Cw, F, act, use_ln = {"k23s0": (115200, 96, 384, "gelu", True), "k23s1": (28800, 192, 768, "gelu", True),
