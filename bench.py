@@ -366,6 +366,7 @@ def main():
             ("win_attn3d", hot_ops.record_window_attention_calls, hot_ops.window_attention3d, k1_cost, True),
             ("linear_split", hot_ops.record_linear_split_calls, hot_ops.linear_split, linear_cost, False),
             ("ws_linear", hot_ops.record_ws_linear_calls, hot_ops.ws_linear, linear_cost, False),
+            ("xs_linear", hot_ops.record_xs_linear_calls, hot_ops.xs_linear, linear_cost, False),
             ("mlp_split", hot_ops.record_mlp_split_calls, hot_ops.mlp_split, mlp_cost, False)):
         rec(True)
         step(0)
@@ -425,15 +426,16 @@ def main():
                 continue
         default_cfg = (a.backbone, T, H, Wd) == ("video-swin-t", 8, 360, 640)
         split_on = {"win_attn3d": hot_ops.k1_split_enabled(), "linear_split": hot_ops.split_enabled(),
-                    "ws_linear": hot_ops.k13_split_enabled(), "mlp_split": True}
+                    "ws_linear": hot_ops.k13_split_enabled(), "mlp_split": True, "xs_linear": True}
         desc = {"win_attn3d": "soc_win_attn3d_f32 (K1, 3-D shifted-window attention)",
                 "linear_split": "soc_linear_split_f32 (K20, tiled linear layers)",
                 "ws_linear": "soc_ws_linear_f32 (K13 / K13b, weight-stationary linear layers)",
+                "xs_linear": "soc_xs_linear_f32 (K24, x-stationary linear layers: rows split once, weights streamed)",
                 "mlp_split": "soc_mlp_split_f32 (K23: LayerNorm + linear + activation + linear + residual (+ LayerNorm) in one "
                              "launch, hidden layer in registers -- the Video-Swin MLPs of stages 0-2 and the encoder's feed-forward "
                              "blocks)"}
         stats_rows = {"win_attn3d": "win_attn3d_split_kernel<false|true>", "linear_split": "linear_split_kernel<...>",
-                      "ws_linear": "ws_linear_split_kernel<...> (+ ws_linear_kernel<...>)",
+                      "ws_linear": "ws_linear_split_kernel<...> (+ ws_linear_kernel<...>)", "xs_linear": "xs_linear_kernel<...>",
                       "mlp_split": "mlp_split_kernel<...> (+ mlp_reduce_kernel)"}
 
         def ceiling(fam, shapes):

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SOC_HIP_ABI_VERSION 11
+#define SOC_HIP_ABI_VERSION 12
 
 #define SOC_OK 0
 #define SOC_EINVAL (-1)       /* null pointer / non-positive dimension */
@@ -267,6 +267,28 @@ int soc_mlp_split_variant_f32(const float* x, const void* packed, const float* b
                               const float* ln_beta, float ln_eps, const float* residual, const float* post_gamma,
                               const float* post_beta, float post_eps, float* out, float* out_sum, float* workspace, long M,
                               int C, int F, int act, int nrg, int nfs, int variant, void* stream);
+
+/*
+ * K24 -- an x-stationary linear layer on the bf16 matrix cores (exact three-way operand split, f32-grade results -- see
+ * soc_linear_split_f32): out = act(LN(x) W^T + bias) + residual, act 0 = none, 1 = ReLU, 2 = exact (erf) GELU; LN, bias,
+ * residual optional.  Replaces the pixel-sized nn.Linear calls of input widths 192 / 256 / 384 / 768: qkv / proj of
+ * WindowAttention3D in Video-Swin stages 1-3 (models/video_swin_transformer.py:144-166, norm1 :219 in front, the shortcut
+ * :254-259 behind), the PatchMerging reduction into stage 2 (:277-312), value_proj / output_proj of MSDeformAttn
+ * (models/ops/modules/ms_deform_attn.py:95,114), the query projection of the fusion blocks (models/vla.py:18-24) and
+ * input_proj of level 1 (models/soc.py:226-230).  A wave keeps its 16 rows as split MFMA fragments (split once); the weights
+ * stream through an LDS ring; a launch is cut into `nrg` workgroup rows x `ncr` column ranges (0, 0: the library plans it).
+ *   x [M, K], w [N, K] (nn.Linear.weight layout), bias [N] or NULL, ln_gamma / ln_beta [K] or both NULL, residual [M, N] or
+ *   NULL, out [M, N]; K in {192, 256, 384, 768}, N % 32 == 0 and N / 16 divisible into ranges of 4 / 6 / 8 / 12 / 16 / 18
+ *   column tiles (soc_xs_linear_plan says whether and how); every pointer 16-byte aligned.
+ *   soc_xs_linear_packed_bytes / soc_xs_linear_pack_f32: split and lay out the weights ONCE (opaque image); re-pack after a
+ *   weight update.
+ */
+size_t soc_xs_linear_packed_bytes(int N, int K);
+int soc_xs_linear_pack_f32(const float* w, void* packed, int N, int K, void* stream);
+int soc_xs_linear_plan(long M, int N, int K, int* nrg, int* ncr, int* nct);
+int soc_xs_linear_f32(const float* x, const void* packed, const float* bias, const float* ln_gamma, const float* ln_beta,
+                      float ln_eps, const float* residual, float* out, long M, int N, int K, int act, int nrg, int ncr,
+                      void* stream);
 
 /*
  * K21 -- Video-Swin patch embedding: the (1,4,4) / stride (1,4,4) convolution + LayerNorm(C) in one pass.  Replaces

@@ -22,8 +22,9 @@ EXPORTS = ("soc_hip_abi_version", "soc_hip_error_string", "soc_msda_fwd_f32", "s
            "soc_upsample_add_tokens_f32", "soc_conv3x3_tokens_f32", "soc_linear_split_packed_bytes",
            "soc_linear_split_pack_f32", "soc_row_stats_f32", "soc_linear_split_f32", "soc_win_attn3d_set_split",
            "soc_win_attn3d_get_split", "soc_mlp_split_packed_bytes", "soc_mlp_split_pack_f32",
-           "soc_mlp_split_workspace_bytes", "soc_mlp_split_plan", "soc_mlp_split_f32", "soc_mlp_split_variant_f32")
-ABI_VERSION = 11
+           "soc_mlp_split_workspace_bytes", "soc_mlp_split_plan", "soc_mlp_split_f32", "soc_mlp_split_variant_f32",
+           "soc_xs_linear_packed_bytes", "soc_xs_linear_pack_f32", "soc_xs_linear_plan", "soc_xs_linear_f32")
+ABI_VERSION = 12
 SOC_EUNSUPPORTED = -2      # include/soc_hip.h: shape outside what the kernel is built for
 
 _lib = None
@@ -126,6 +127,14 @@ def load() -> C.CDLL:
     lib.soc_mlp_split_f32.argtypes = [p, p, p, p, p, p, f, p, p, p, f, p, p, p, C.c_size_t, C.c_long, i, i, i, p]
     lib.soc_mlp_split_variant_f32.restype = i
     lib.soc_mlp_split_variant_f32.argtypes = [p, p, p, p, p, p, f, p, p, p, f, p, p, p, C.c_long, i, i, i, i, i, i, p]
+    lib.soc_xs_linear_packed_bytes.restype = C.c_size_t
+    lib.soc_xs_linear_packed_bytes.argtypes = [i, i]
+    lib.soc_xs_linear_pack_f32.restype = i
+    lib.soc_xs_linear_pack_f32.argtypes = [p, p, i, i, p]
+    lib.soc_xs_linear_plan.restype = i
+    lib.soc_xs_linear_plan.argtypes = [C.c_long, i, i, C.POINTER(i), C.POINTER(i), C.POINTER(i)]
+    lib.soc_xs_linear_f32.restype = i
+    lib.soc_xs_linear_f32.argtypes = [p, p, p, p, p, f, p, p, C.c_long, i, i, i, i, i, p]
     lib.soc_patch_embed_layernorm_f32.restype = i
     lib.soc_patch_embed_layernorm_f32.argtypes = [p, p, p, p, p, p, i, i, i, i, f, p]
     lib.soc_linear_act_f32.restype = i

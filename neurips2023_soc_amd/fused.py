@@ -63,12 +63,25 @@ def _split_ok(x: torch.Tensor, weight: torch.Tensor, fused_passes: int, site: st
             and hot_ops.split_wins(x.numel() // K, weight.shape[0], K, fused_passes, site))
 
 
+def xs_ok(x, weight) -> bool:
+    """K24 (x split once per row tile, weights streamed) where it measured faster than K13b / K20 / the library
+    (tools/experiments/k24_time.py): input widths 384 and 768 on pixel-sized inputs (Video-Swin stage 2 / 3 qkv, proj, fc1, the
+    patch-merging reduction into stage 2), and width 256 up to one pass of the chip (the fusion blocks' query projection; the
+    encoder's 38 560-row projections stay on K13b)."""
+    K = x.shape[-1]
+    rows = x.numel() // K
+    return (rows * weight.shape[0] >= 2_000_000 and (K in (384, 768) or (K == 256 and 16384 <= rows <= 32768))
+            and hot_ops.xs_linear_supported(x, weight))       # (narrow outputs on few rows: the library's small tiles win)
+
+
 def route_linear(x, weight, bias=None, add=None, relu: bool = False, mul=None, residual=None) -> str:
-    """Which kernel runs mul * act((x [+ add]) @ weight.T + bias) + residual: "k7" (few rows), "k13b", "k20", or "library".
+    """Which kernel runs mul * act((x [+ add]) @ weight.T + bias) + residual: "k7" (few rows), "k24", "k13b", "k20", or "library".
     Decided from shapes, dtypes and devices only (tests/test_routes.py drives it with stand-ins for every layer of the five
     BASELINE configurations and pins the answers, so that a silent fall-back to the library fails a test)."""
     if is_small(x):
         return "k7"
+    if add is None and mul is None and xs_ok(x, weight):
+        return "k24"
     if add is None and mul is None and ws_plain_ok(x, weight):
         return "k13b"
     n_fused = int(add is not None) + int(relu) + int(mul is not None) + int(residual is not None)
@@ -79,9 +92,11 @@ def route_linear(x, weight, bias=None, add=None, relu: bool = False, mul=None, r
 
 
 def route_gelu(x, weight) -> str:
-    """Which kernel runs gelu(x @ weight.T + bias): "k13b", "k20", "k12" or "library" (+ a GELU pass)."""
+    """Which kernel runs gelu(x @ weight.T + bias): "k24", "k13b", "k20", "k12" or "library" (+ a GELU pass)."""
     K = x.shape[-1]
     rows = x.numel() // K
+    if xs_ok(x, weight):
+        return "k24"
     if ws_dense_ok(x, weight):
         return "k13b"
     if _split_ok(x, weight, 1, "gelu"):
@@ -104,6 +119,8 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
         if mul is not None:
             y = y * mul
         return y if residual is None else y + residual
+    if route == "k24":
+        return hot_ops.xs_linear(x, weight, bias, None, residual, "relu" if relu else "none")
     if route == "k13b":
         return hot_ops.ws_linear(x, weight, bias, None, residual, "relu" if relu else "none")
     if route == "k20":
@@ -185,6 +202,8 @@ def linear_gelu(x: torch.Tensor, lin: nn.Linear) -> torch.Tensor:
     """gelu(lin(x)), exact (erf) GELU, on the kernel route_gelu names: K13b / K20 apply it to the accumulators; K12 (tall inputs
     with a short reduction, f32 MFMA) likewise; elsewhere the library GEMM + a GELU pass."""
     route = route_gelu(x, lin.weight)
+    if route == "k24":
+        return hot_ops.xs_linear(x, lin.weight, lin.bias, act="gelu")
     if route == "k13b":
         return hot_ops.ws_linear(x, lin.weight, lin.bias, act="gelu")
     if route == "k20":

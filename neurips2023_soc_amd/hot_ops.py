@@ -984,6 +984,86 @@ def split_tile_for(M: int, N: int, K: int) -> int:
     return cfg
 
 
+XS_LINEAR_K = (192, 256, 384, 768)      # input widths K24 is built for
+_XS_NCT = (18, 16, 12, 8, 6, 4)         # column tiles per range it is built for
+_xs_cache = {}
+_k24_calls = None  # bench.py: when a list, xs_linear appends its arguments
+
+
+def record_xs_linear_calls(on: bool):
+    """As record_linear_split_calls, for K24: the recorded dicts are keyword arguments of xs_linear."""
+    global _k24_calls
+    if on:
+        _k24_calls = []
+        return None
+    calls, _k24_calls = _k24_calls, None
+    return calls
+
+
+def xs_linear_supported(x, weight) -> bool:
+    """K24 takes act(LN(x) weight^T + bias) + residual: CUDA fp32, input width 192 / 256 / 384 / 768, an output width whose 16-
+    column tiles divide into ranges of a built size, split arithmetic on (SOC_SPLIT_OFF=k24 switches it off)."""
+    N, K = weight.shape
+    ctp = 2 if K <= 256 else 1
+    return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and split_enabled()
+            and "k24" not in _SPLIT_OFF and x.shape[-1] == K and K in XS_LINEAR_K and N % 32 == 0
+            and any((N // 16) % n == 0 and n % ctp == 0 for n in _XS_NCT))
+
+
+def _xs_packed(weight: Tensor) -> Tensor:
+    lib = _lib.load()
+    N, K = weight.shape
+    ident = weight.data_ptr()
+    key = (ident, weight._version, N, K, weight.device.index, tuple(weight.stride()))
+    ent = _xs_cache.get(ident)
+    if ent is None or ent[0] != key:
+        packed = torch.empty(lib.soc_xs_linear_packed_bytes(N, K), dtype=torch.uint8, device=weight.device)
+        wc = _f32c(weight.detach())
+        _lib.check(lib.soc_xs_linear_pack_f32(wc.data_ptr(), packed.data_ptr(), N, K, _stream()), "soc_xs_linear_pack_f32")
+        ent = (key, packed, weight)
+        _xs_cache[ident] = ent
+    return ent[1]
+
+
+def xs_linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, ln: Optional[Tuple[Tensor, Tensor, float]] = None,
+              residual: Optional[Tensor] = None, act: str = "none", cut: Optional[Tuple[int, int]] = None) -> Tensor:
+    """K24: act(LN(x) @ weight.T + bias) + residual, every part optional; ln = (gamma, beta, eps); x [..., K] -> [..., N].
+    `cut` = (workgroup rows, column ranges) forces the decomposition (tests, probes)."""
+    _need_gpu(x, weight, bias, residual, *(ln[:2] if ln else ()))
+    lib = _lib.load()
+    x = _f32c(x)
+    N, K = weight.shape
+    M = x.numel() // K
+    packed = _xs_packed(weight)
+    out = torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=x.device)
+    if residual is not None:
+        residual = _f32c(residual)
+        if residual.shape != out.shape:
+            raise _lib.SocHipError(f"xs_linear: residual shape {tuple(residual.shape)} != output {tuple(out.shape)}")
+    g = be = None
+    eps = 0.0
+    if ln is not None:
+        g, be, eps = _f32c(ln[0]), _f32c(ln[1]), float(ln[2])
+    b = _f32c(bias) if bias is not None else None
+    if _k24_calls is not None:
+        _k24_calls.append(dict(x=x, weight=weight, bias=bias, ln=ln, residual=residual, act=act, cut=cut))
+    ptr = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
+    nrg, ncr = cut if cut is not None else (0, 0)
+    with _timed("xs_linear", 2.0 * M * N * K):
+        rc = lib.soc_xs_linear_f32(x.data_ptr(), packed.data_ptr(), ptr(b), ptr(g), ptr(be), eps, ptr(residual), out.data_ptr(),
+                                   M, N, K, {"none": 0, "relu": 1, "gelu": 2}[act], int(nrg), int(ncr), _stream())
+    _lib.check(rc, "soc_xs_linear_f32")
+    return out
+
+
+def xs_linear_plan(M: int, N: int, K: int) -> Tuple[int, int, int]:
+    """(workgroup rows, column ranges, column tiles per range) K24 cuts an [M, K] x [N, K]^T layer into."""
+    lib = _lib.load()
+    a, b, c = C.c_int(0), C.c_int(0), C.c_int(0)
+    _lib.check(lib.soc_xs_linear_plan(M, N, K, C.byref(a), C.byref(b), C.byref(c)), "soc_xs_linear_plan")
+    return a.value, b.value, c.value
+
+
 MLP_SPLIT_C = (96, 128, 192, 256, 384)  # model widths K23 is built for
 _MLP_ACT = {"relu": 1, "gelu": 2}
 _mlp_cache = {}

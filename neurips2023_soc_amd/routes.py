@@ -79,10 +79,12 @@ def table(backbone: str, T: int, H: int, W: int) -> Dict[str, str]:
             else:
                 out[f"swin{s}.fc1"] = "k20"
                 out[f"swin{s}.fc2"] = fused.route_linear(hid, blk.mlp.fc2.weight, blk.mlp.fc2.bias, residual=x)
+        elif flow == "k24":
+            out[f"swin{s}.qkv"] = out[f"swin{s}.proj"] = out[f"swin{s}.fc1"] = "k24"
+            out[f"swin{s}.fc2"] = fused.route_linear(hid, blk.mlp.fc2.weight, blk.mlp.fc2.bias, residual=x)
         else:
-            ws = fused.ws_dense_ok(x, blk.attn.qkv.weight)
-            out[f"swin{s}.qkv"] = "k13b" if ws else "library"
-            out[f"swin{s}.proj"] = "k13b" if ws and fused.ws_dense_ok(x, blk.attn.proj.weight) else "library"
+            out[f"swin{s}.qkv"] = fused.route_linear(x, blk.attn.qkv.weight, blk.attn.qkv.bias)
+            out[f"swin{s}.proj"] = fused.route_linear(x, blk.attn.proj.weight, blk.attn.proj.bias, residual=x)
             if flow == "k23":
                 out[f"swin{s}.mlp"] = "k23"
             else:
@@ -91,7 +93,7 @@ def table(backbone: str, T: int, H: int, W: int) -> Dict[str, str]:
         if s < 3:
             h, w = -(-h // 2), -(-w // 2)
             merged = Stand(1, T, h, w, 4 * C)
-            out[f"merge{s}"] = "k13b" if fused.ws_plain_ok(merged, Stand(2 * C, 4 * C)) else "library"
+            out[f"merge{s}"] = fused.route_linear(merged, Stand(2 * C, 4 * C), None)
     # input_proj of levels 1..3 (1x1 convolutions as GEMMs over tokens), fusion blocks, deformable encoder
     enc_rows = 0
     for lvl in (1, 2, 3):

@@ -57,15 +57,11 @@ class WindowAttention3D(nn.Module):
 
     def forward(self, x: torch.Tensor, shift: Sequence[int], residual: Optional[torch.Tensor] = None) -> torch.Tensor:
         """x [B,D,H,W,C] (after norm1, un-padded) -> attention branch output [B,D,H,W,C] (+ residual: the block's
-        shortcut, added in the projection's epilogue where K13b runs it)."""
-        ws = fused.ws_dense_ok(x, self.qkv.weight)              # stage 2: K13b instead of the library GEMMs
-        qkv = hot_ops.ws_linear(x, self.qkv.weight, self.qkv.bias) if ws else self.qkv(x)
+        shortcut, added in the projection's epilogue where a hand-written kernel runs it: fused.route_linear)."""
+        qkv = fused.linear(x, self.qkv.weight, self.qkv.bias)           # stage 2: K24 (K13b with SOC_SPLIT_OFF=k24)
         attn = hot_ops.window_attention3d(qkv, self.qkv.bias, self.relative_position_bias_table,
                                           self.num_heads, self.window_size, shift)
-        if ws and fused.ws_dense_ok(attn, self.proj.weight):
-            return hot_ops.ws_linear(attn, self.proj.weight, self.proj.bias, residual=residual)
-        out = self.proj(attn)
-        return out if residual is None else out + residual
+        return fused.linear(attn, self.proj.weight, self.proj.bias, residual=residual)
 
 
 class Mlp(nn.Module):
@@ -151,6 +147,16 @@ class BasicLayer(nn.Module):
                 else:
                     x = x + blk.mlp.fc2(h)
             return x
+        if flow == "k24":
+            for blk in blocks:
+                a, m = blk.attn, blk.mlp
+                qkv = hot_ops.xs_linear(x, a.qkv.weight, a.qkv.bias, ln=(blk.norm1.weight, blk.norm1.bias, blk.norm1.eps))
+                o = hot_ops.window_attention3d(qkv, a.qkv.bias, a.relative_position_bias_table, a.num_heads,
+                                               a.window_size, blk.shift_size)
+                x = hot_ops.xs_linear(o, a.proj.weight, a.proj.bias, residual=x)
+                h = hot_ops.xs_linear(x, m.fc1.weight, m.fc1.bias, ln=(blk.norm2.weight, blk.norm2.bias, blk.norm2.eps), act="gelu")
+                x = fused.linear(h, m.fc2.weight, m.fc2.bias, residual=x)
+            return x
         _, h = hot_ops.add_layernorm(x, None, blocks[0].norm1.weight, blocks[0].norm1.bias, blocks[0].norm1.eps)
         if flow == "k23":
             # stage 2 (C = 384): the shortcut rides in the projection's epilogue, norm2 + fc1 + GELU + fc2 + shortcut are one K23
@@ -183,6 +189,8 @@ class BasicLayer(nn.Module):
               stage 1 of the others with SOC_SPLIT_OFF=k13);
         "k23" one LayerNorm pass at the stage's entry, then per block qkv | K1 | proj + shortcut | K23 (norm2 + MLP + shortcut +
               norm1 of the next block): stage 2 of Swin-T / -S (C = 384);
+        "k24" norm1 + qkv | K1 | proj + shortcut | norm2 + fc1 + GELU as K24 launches (LayerNorm in their prologues), fc2 + shortcut
+              through fused.linear: stage 3 of Swin-T / -S (C = 768; the hidden width 3072 is beyond K24);
         "k5"  every shortcut add fused with the LayerNorm that consumes it (K5), GEMMs per fused.route_*: the rest."""
         blk = self.blocks[0]
         # stage 1 (C = 192) in the split arithmetic: K13b beats K20 on qkv / proj / fc1 (49 / 24 / 71 against 60 / 30 / 74 us,
@@ -192,7 +200,12 @@ class BasicLayer(nn.Module):
             return "k20"
         if self._weight_stationary(x):
             return "ws"
-        return "k23" if fused.mlp_ok(x, blk.mlp.fc1, blk.mlp.fc2) else "k5"
+        if fused.mlp_ok(x, blk.mlp.fc1, blk.mlp.fc2):
+            return "k23"
+        if (x.shape[-1] == 768 and x.numel() // 768 >= 1024
+                and all(hot_ops.xs_linear_supported(x, w) for w in (blk.attn.qkv.weight, blk.attn.proj.weight, blk.mlp.fc1.weight))):
+            return "k24"
+        return "k5"
 
     def _split_flow(self, x: torch.Tensor) -> bool:
         """Tall stages wider than K13's sweet spot (C >= 192: stage 1 of Swin-T / -S, stages 1 of Swin-B): every layer on
@@ -228,9 +241,7 @@ class PatchMerging(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         h = hot_ops.patch_merge_layernorm(x, self.norm.weight, self.norm.bias, self.norm.eps)
-        if fused.ws_plain_ok(h, self.reduction.weight):          # K = 384 / 512 reductions: K13b (stage 0 -> 1)
-            return hot_ops.ws_linear(h, self.reduction.weight, None)
-        return self.reduction(h)
+        return fused.linear(h, self.reduction.weight, None)      # K13b (stage 0 -> 1), K24 (1 -> 2), library (2 -> 3: K = 1536)
 
     def forward_unfused(self, x: torch.Tensor) -> torch.Tensor:
         """The reference's sequence of ops (pad, four strided slices, cat, norm, reduction)."""

@@ -1314,3 +1314,48 @@ def test_mlp_split_emits_sum_and_next_layernorm(ops, M, Cw, F):
     assert float((s.double() - want).abs().max()) < 1e-5 * float(want.abs().max())
     want_h = torch.nn.functional.layer_norm(want, (Cw,), gam.double(), bet.double(), 1e-5)
     assert float((h.double() - want_h).abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize("M,N,K,act,ln,res", [
+    (7360, 1152, 384, "none", False, False),    # Video-Swin stage-2 qkv (four ranges of 18 column tiles)
+    (7360, 384, 384, "none", False, True),      # ... proj + shortcut
+    (28800, 576, 192, "none", True, False),     # stage-1 norm1 + qkv
+    (28800, 192, 192, "none", False, True),     # stage-1 proj + shortcut
+    (38560, 256, 256, "none", False, False),    # the encoder's value_proj / output_proj
+    (7360, 384, 768, "none", False, False),     # patch-merging reduction into stage 2 (four 512-register waves)
+    (1920, 2304, 768, "none", True, False),     # stage-3 norm1 + qkv
+    (1920, 768, 768, "none", False, True),      # stage-3 proj + shortcut
+    (1920, 3072, 768, "gelu", True, False),     # stage-3 norm2 + fc1 + GELU
+    (28800, 256, 192, "none", False, False),    # input_proj of level 1
+    (33, 64, 192, "relu", False, True), (4099, 1152, 384, "gelu", True, True), (17, 576, 256, "none", True, False)])
+def test_xs_linear_vs_f64(ops, M, N, K, act, ln, res):
+    """K24 (x-stationary linear layer, weights streamed through the LDS ring, bf16 matrix cores with the exact split) against f64
+    and the f32 library path: f32-grade error, LayerNorm prologue, GELU / ReLU / residual epilogues, bit-repeatable, repack
+    after an in-place weight update, every legal cut gives the same bits."""
+    g = torch.Generator().manual_seed(M + N + K)
+    x = (torch.randn(M, K, generator=g) * 1.2).cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    b = (torch.randn(N, generator=g) * 0.1).cuda()
+    lnp = ((torch.rand(K, generator=g) + 0.5).cuda(), (torch.randn(K, generator=g) * 0.1).cuda(), 1e-5) if ln else None
+    r = torch.randn(M, N, generator=g).cuda() if res else None
+    assert ops.xs_linear_supported(x, w)
+
+    def ref(dt):
+        xd = x.to(dt)
+        if lnp is not None:
+            xd = torch.nn.functional.layer_norm(xd, (K,), lnp[0].to(dt), lnp[1].to(dt), 1e-5)
+        y = torch.nn.functional.linear(xd, w.to(dt), b.to(dt))
+        y = y.relu() if act == "relu" else (torch.nn.functional.gelu(y) if act == "gelu" else y)
+        return y if r is None else y + r.to(dt)
+    got = ops.xs_linear(x, w, b, lnp, r, act)
+    assert torch.equal(got, ops.xs_linear(x, w, b, lnp, r, act))
+    want, lib = ref(torch.float64), ref(torch.float32)
+    scale = float(want.abs().max())
+    e_k, e_lib = float((got.double() - want).abs().max()), float((lib.double() - want).abs().max())
+    print(f"K24 {M}x{N}x{K} {act}: split {e_k / scale:.2e}  library f32 {e_lib / scale:.2e}  plan {ops.xs_linear_plan(M, N, K)}")
+    assert e_k < 1e-5 * scale and e_k <= 1.5 * e_lib + 3e-7 * scale, (e_k, e_lib)
+    nrg, ncr, nct = ops.xs_linear_plan(M, N, K)
+    for cut in {(max(1, nrg // 2), ncr), (min((M + 15) // 16, nrg + 3), ncr)}:
+        assert torch.equal(got, ops.xs_linear(x, w, b, lnp, r, act, cut=cut)), cut
+    w.mul_(0.5)
+    assert float((ops.xs_linear(x, w, b, lnp, r, act).double() - ref(torch.float64)).abs().max()) < 1e-5 * scale
