@@ -31,6 +31,9 @@ PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32-input MFMA peak
 PEAK_HBM_GBS = 8000.0          # HBM3E spec
 HBM_ACHIEVABLE_GBS = 6300.0    # MI355X_MICROARCH.md: measured float4 copy rate (79 % of spec): what a streaming kernel can reach
 PEAK_BF16_MFMA_TFLOPS = 2500.0 # MI355X_MICROARCH.md: dense bf16 MFMA peak (spec; the clock held on random data is lower)
+_REL_LATE = os.environ.get('BENCH_REL_LATE', '0') == '1'
+_NO_RECORD_COPY = os.environ.get('BENCH_NO_RECORD_COPY', '0') == '1'
+_FEED_DEPTH = int(os.environ.get('BENCH_FEED_DEPTH', '2'))     # device slots of the streamed pass's feeder
 WEIGHT_SEED = 2023
 
 
@@ -209,7 +212,7 @@ def main():
 
     def run_steps(n, out, feed=None):
         """n clips through the chosen path, results into out[i % len(out)].  `feed` = (feeder, host clips): every clip
-        then crosses PCIe inside the loop (pinned host buffer -> one of three device slots on a copy stream, one clip
+        then crosses PCIe inside the loop (pinned host buffer -> one of two device slots on a copy stream, one clip
         ahead of the compute stream) as in the reference's loop (infer_refytb.py:206-212); without it the clips are
         the HBM-resident pool."""
         m = out.shape[0]
@@ -232,14 +235,17 @@ def main():
                 done += 1
             else:
                 graph.stage_inputs(clip, text["input_ids"])
-                if feeder is not None:
+                if feeder is not None and not _REL_LATE:
                     feeder.release()       # the slot has been copied into the graph's static input: reusable from here
                 rec = graph.replay()
+                if feeder is not None and _REL_LATE:
+                    feeder.release()
                 if not pipelined:
                     out[i % m].copy_(graph.record, non_blocking=True)
                     done += 1
                 elif rec is not None:      # software pipeline: a replay returns the record of an earlier clip
-                    out[done % m].copy_(graph.record, non_blocking=True)
+                    if not _NO_RECORD_COPY:
+                        out[done % m].copy_(graph.record, non_blocking=True)
                     done += 1
             if feeder is not None and graph is None:
                 feeder.release()
@@ -271,7 +277,7 @@ def main():
         n_host = min(a.steps, 24)                        # distinct host clips (22 MB pinned each), cycled beyond that
         host = [clips_cpu[i] if i < n_pool else W.synthetic_clip(1 + 1000 * rank + i, T, H, Wd) for i in range(n_host)]
         host = [h.pin_memory() for h in host]
-        feeder = DoubleBufferedH2D((T, 3, H, Wd), torch.float32, dev, depth=3)
+        feeder = DoubleBufferedH2D((T, 3, H, Wd), torch.float32, dev, depth=_FEED_DEPTH)
         # A driver recycles a few pinned buffers (clip_io.PinnedPool), so every buffer it copies from has been through the
         # DMA engine before; the first transfer out of a fresh pinned allocation is several times slower than the 0.41 ms
         # (54 GB/s) of the later ones.  Each host clip is therefore copied once, untimed, before the pass.
@@ -408,7 +414,7 @@ def main():
             **({"stream_ms_per_step": 1e3 * stream["seconds"] / a.steps, "stream_value": world * a.steps / stream["seconds"],
                 "stream": f"same loop with every clip copied host->device inside the timed region: {stream['n_host']} "
                           "pinned host clips (seeds seed0 + i; each buffer DMA-ed once before the pass, as a recycled pinned pool is), "
-                          "three device slots, copy stream one clip ahead "
+                          "two device slots (a slot is released right behind the copy into the graph's static input), copy stream one clip ahead "
                           "(clip_io.DoubleBufferedH2D); 22 MB per clip at 360x640",
                 "stream_record0_max_abs_diff_vs_resident": float((stream["records"][0] - timed_records[0]).abs().max())}
                if stream is not None else {}),

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SOC_HIP_ABI_VERSION 12
+#define SOC_HIP_ABI_VERSION 13
 
 #define SOC_OK 0
 #define SOC_EINVAL (-1)       /* null pointer / non-positive dimension */
@@ -31,6 +31,15 @@ extern "C" {
 #define SOC_EWORKSPACE (-4)   /* workspace too small */
 
 int soc_hip_abi_version(void);
+
+/*
+ * CUs left free by the persistent kernels (one workgroup per CU for a whole launch: K13 / K13b, K20, K23, K24): their grids
+ * are sized for the device's CU count minus this reserve, so that the short launches of a concurrent stream -- the query
+ * chain of the previous clip and the text branch in the software pipeline of graph_runner.PipelinedClipGraph -- find a CU at
+ * once.  Process-wide, read at launch time; 0 (default) = every CU.  At most half the chip can be reserved.
+ */
+void soc_set_reserved_cus(int n);
+int soc_get_reserved_cus(void);
 const char* soc_hip_error_string(int code);
 
 /*

@@ -23,8 +23,9 @@ EXPORTS = ("soc_hip_abi_version", "soc_hip_error_string", "soc_msda_fwd_f32", "s
            "soc_linear_split_pack_f32", "soc_row_stats_f32", "soc_linear_split_f32", "soc_win_attn3d_set_split",
            "soc_win_attn3d_get_split", "soc_mlp_split_packed_bytes", "soc_mlp_split_pack_f32",
            "soc_mlp_split_workspace_bytes", "soc_mlp_split_plan", "soc_mlp_split_f32", "soc_mlp_split_variant_f32",
-           "soc_xs_linear_packed_bytes", "soc_xs_linear_pack_f32", "soc_xs_linear_plan", "soc_xs_linear_f32")
-ABI_VERSION = 12
+           "soc_xs_linear_packed_bytes", "soc_xs_linear_pack_f32", "soc_xs_linear_plan", "soc_xs_linear_f32",
+           "soc_set_reserved_cus", "soc_get_reserved_cus")
+ABI_VERSION = 13
 SOC_EUNSUPPORTED = -2      # include/soc_hip.h: shape outside what the kernel is built for
 
 _lib = None
@@ -153,8 +154,13 @@ def load() -> C.CDLL:
     lib.soc_row_stats_f32.argtypes = [p, p, C.c_long, i, f, p]
     lib.soc_linear_split_f32.restype = i
     lib.soc_linear_split_f32.argtypes = [p] * 10 + [i, C.c_long, i, i, i, i, p]
+    lib.soc_set_reserved_cus.restype = None
+    lib.soc_set_reserved_cus.argtypes = [i]
+    lib.soc_get_reserved_cus.restype = i
+    lib.soc_get_reserved_cus.argtypes = []
     if lib.soc_hip_abi_version() != ABI_VERSION:
         raise SocHipError("libsoc_hip.so ABI version mismatch; rebuild it")
+    lib.soc_set_reserved_cus(int(os.environ.get("SOC_RESERVED_CUS", "0")))
     _lib = lib
     return lib
 

@@ -474,12 +474,7 @@ __global__ __launch_bounds__(256) void mlp_pack_kernel(const float* __restrict__
     }
 }
 
-int num_cus() {
-    const int dev = soc_current_device();
-    int v = 0;
-    if (dev >= 0 && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) return v;
-    return 256;
-}
+int num_cus() { return soc_num_cus(); }      // device CUs minus the host's reserve (soc_capi.hip)
 
 // The shipped form of a width: waves per workgroup and row tiles per wave.  256-register waves (NW = 8) hold the x fragments
 // (3 C / 8 registers per tile) and the output accumulators (C / 4 per tile) of RT tiles up to C = 256; C = 384 needs the 512

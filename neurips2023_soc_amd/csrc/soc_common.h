@@ -21,3 +21,6 @@ static inline int soc_current_device() {
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SOC_MAX_DEVICES) return -1;
     return dev;
 }
+
+// defined in soc_capi.hip: the CU count persistent kernels size their grids for (device count minus soc_set_reserved_cus())
+int soc_num_cus();

@@ -178,19 +178,7 @@ __global__ __launch_bounds__(THREADS, 2) void ws_linear_kernel(
     }
 }
 
-int num_cus() {
-    static std::atomic<int> cached[SOC_MAX_DEVICES];
-    const int dev = soc_current_device();
-    if (dev < 0) return 256;
-    int n = cached[dev].load(std::memory_order_relaxed);
-    if (n == 0) {
-        n = 256;
-        int v = 0;
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
-        cached[dev].store(n, std::memory_order_relaxed);
-    }
-    return n;
-}
+int num_cus() { return soc_num_cus(); }      // device CUs minus the host's reserve (soc_capi.hip)
 
 // columns of W per workgroup: even ranges, multiples of 16, that fit the LDS; 0 if N cannot be split that way
 int split_columns(int N, int K) {

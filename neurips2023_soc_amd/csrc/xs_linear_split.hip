@@ -239,12 +239,7 @@ __global__ __launch_bounds__(256) void xs_pack_kernel(const float* __restrict__ 
     }
 }
 
-int num_cus() {
-    const int dev = soc_current_device();
-    int v = 0;
-    if (dev >= 0 && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) return v;
-    return 256;
-}
+int num_cus() { return soc_num_cus(); }      // device CUs minus the host's reserve (soc_capi.hip)
 
 struct Args {
     const float *x, *bias, *gamma, *beta, *res;

@@ -249,7 +249,7 @@ def main(argv=None):
     clips = [W.synthetic_clip(1 + i, T, H, Wd).pin_memory() for i in mine]
     ids = [W.synthetic_token_ids(1 + i, L).to(dev) for i in mine]
     from .clip_io import DoubleBufferedH2D
-    feeder = DoubleBufferedH2D((T, 3, H, Wd), torch.float32, dev, depth=3)
+    feeder = DoubleBufferedH2D((T, 3, H, Wd), torch.float32, dev, depth=2)
 
     def run_local(out):
         # H2D inside the loop, like the reference (infer_refytb.py:206-212), but from pinned memory on a copy stream,
