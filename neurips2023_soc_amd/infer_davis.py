@@ -46,7 +46,7 @@ def save_label_map(labels: np.ndarray, path: str, palette: Sequence[int]) -> Non
     from PIL import Image
     img = Image.fromarray(labels.astype(np.uint8))
     img.putpalette(list(palette))
-    img.save(path)
+    img.save(path, compress_level=1)      # same pixels and palette, zlib level 1 (see infer_refytb.save_binary_mask)
 
 
 @torch.no_grad()
