@@ -9,7 +9,8 @@ import json
 import sys
 
 GROUPS = collections.OrderedDict([
-    ("win_attn3d", ("win_attn3d",)), ("linear_split", ("::linear_split_kernel",)), ("row_stats", ("row_stats_kernel",)), ("ffn_split", ("ffn_split_kernel",)),
+    ("win_attn3d", ("win_attn3d",)), ("linear_split", ("::linear_split_kernel",)), ("row_stats", ("row_stats_kernel",)), ("mlp_split", ("mlp_split_kernel", "mlp_reduce_kernel")),
+    ("xs_linear", ("xs_linear_kernel",)),
     ("msda_fwd", ("msda_fwd", "msda_fused")), ("xattn", ("xattn_",)), ("dyn_mask", ("dyn_mask",)),
     ("add_layernorm", ("add_layernorm",)), ("linear_small", ("linear_small",)), ("linear_act", ("gemm_nt_kernel",)),
     ("groupnorm_tokens", ("gn_stats", "gn_apply")), ("patch_merge_layernorm", ("patch_merge",)), ("patch_embed_layernorm", ("patch_embed_ln",)), ("ws_linear", ("ws_linear_kernel", "ws_linear_split_kernel")),
