@@ -174,21 +174,14 @@ def linear_multi(x: torch.Tensor, layers, add: Optional[torch.Tensor] = None):
     return [F.linear(xa if u else x, w, b) for w, b, u in layers]
 
 
-_stack_cache = {}
+_stack_cache = hot_ops.DerivedCache()
 
 
 def _stacked(w0, b0, w1, b1):
-    """cat of two layers' (weight, bias), cached until one of them changes (K20 packs the stacked matrix once)."""
-    key = (w0.data_ptr(), w1.data_ptr(), b0.data_ptr(), b1.data_ptr())
-    ver = (w0._version, w1._version, b0._version, b1._version)
-    hit = _stack_cache.get(key)
-    if hit is None or hit[0] != ver:
-        if len(_stack_cache) > 256:
-            _stack_cache.clear()
-        hit = (ver, torch.cat([w0.detach(), w1.detach()], 0).contiguous(),
-               torch.cat([b0.detach(), b1.detach()], 0).contiguous(), (w0, w1, b0, b1))
-        _stack_cache[key] = hit
-    return hit[1], hit[2]
+    """cat of two layers' (weight, bias), cached until one of them changes (K20 packs the stacked matrix once) and freed
+    with the layers."""
+    return _stack_cache.get((w0, b0, w1, b1), lambda: (torch.cat([w0.detach(), w1.detach()], 0).contiguous(),
+                                                      torch.cat([b0.detach(), b1.detach()], 0).contiguous()))
 
 
 def linear_relu(x: torch.Tensor, lin: nn.Linear) -> torch.Tensor:

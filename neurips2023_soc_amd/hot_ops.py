@@ -906,9 +906,44 @@ def split_wins(rows: int, N: int, K: int, fused_passes: int = 0, site: str = "pl
     return True
 
 
+class DerivedCache:
+    """Values derived from parameter tensors (packed weight images, stacked layers): built once per (tensors, versions),
+    rebuilt after an in-place update (load_state_dict bumps `_version`), and dropped when a keyed tensor dies.
+
+    The key is what the tensors ARE, not a temporary made from them: (data_ptr, storage offset, shape, strides, device) of each,
+    so that views created per call (`in_proj_weight[:E]`) hit, and a contiguous copy made on the way never enters the key.  An
+    entry holds only WEAK references to the tensors' owners (the view's base, i.e. the nn.Parameter): the model can be freed,
+    and when it is, the entry -- and the device memory of the image -- goes with it.  Nothing is ever bulk-cleared: a captured
+    hipGraph that has a packed image's address baked in keeps its model alive, and with the model the entry."""
+
+    def __init__(self):
+        self._d = {}
+
+    @staticmethod
+    def _ident(t: Tensor):
+        return (t.data_ptr(), t.storage_offset(), tuple(t.shape), tuple(t.stride()), str(t.dtype), t.device.index)
+
+    def get(self, tensors, build, extra=()):
+        import weakref
+        ts = [t for t in tensors if t is not None]
+        key = tuple(self._ident(t) for t in ts) + tuple(extra)
+        version = tuple(t._version for t in ts)
+        hit = self._d.get(key)
+        if hit is not None and hit[0] == version and all(r() is not None for r in hit[2]):
+            return hit[1]
+        value = build()
+        owners = [t._base if t._base is not None else t for t in ts]
+        refs = tuple(weakref.ref(o, lambda _r, k=key: self._d.pop(k, None)) for o in owners)
+        self._d[key] = (version, value, refs)
+        return value
+
+    def __len__(self):
+        return len(self._d)
+
+
 _SPLIT_ACT = {"none": 0, "relu": 1, "gelu": 2}
 SPLIT_TILES = {0: (128, 256), 1: (256, 128), 2: (128, 128), 3: (256, 96), 4: (128, 64)}
-_split_cache = {}         # id(weight storage) -> (version, packed image)
+_split_cache = DerivedCache()
 
 
 def split_pack(weight: Tensor, bias: Optional[Tensor] = None, gamma: Optional[Tensor] = None,
@@ -920,31 +955,23 @@ def split_pack(weight: Tensor, bias: Optional[Tensor] = None, gamma: Optional[Te
     of exactly the f32 values in the image (both summed in f64, rounded once)."""
     _need_gpu(weight, bias, gamma, beta)
     lib = _lib.load()
-    w = _f32c(weight.detach())
-    parts = [t for t in (weight, bias, gamma, beta) if t is not None]
-    key = (w.data_ptr(), tuple(w.shape), w.device.index, gamma.data_ptr() if gamma is not None else 0,
-           bias.data_ptr() if bias is not None else 0)
-    version = tuple(t._version for t in parts)
-    hit = _split_cache.get(key)
-    if hit is not None and hit[0] == version:
-        return hit[1], hit[2], hit[3]
-    N, K = w.shape
-    eff_bias = _f32c(bias.detach()) if bias is not None else None
-    colsum = None
-    if gamma is not None:
-        eb = w.double() @ beta.detach().double()
-        if bias is not None:
-            eb = eb + bias.detach().double()
-        eff_bias = eb.float().contiguous()
-        w = (w * gamma.detach()[None, :]).contiguous()
-        colsum = w.double().sum(1).float().contiguous()
-    nbytes = lib.soc_linear_split_packed_bytes(N, K)
-    packed = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
-    _lib.check(lib.soc_linear_split_pack_f32(w.data_ptr(), packed.data_ptr(), N, K, _stream()), "soc_linear_split_pack_f32")
-    if len(_split_cache) > 4096:
-        _split_cache.clear()
-    _split_cache[key] = (version, packed, eff_bias, colsum, parts)      # `parts` keeps the keyed tensors alive
-    return packed, eff_bias, colsum
+
+    def build():
+        w = _f32c(weight.detach())
+        N, K = w.shape
+        eff_bias = _f32c(bias.detach()) if bias is not None else None
+        colsum = None
+        if gamma is not None:
+            eb = w.double() @ beta.detach().double()
+            if bias is not None:
+                eb = eb + bias.detach().double()
+            eff_bias = eb.float().contiguous()
+            w = (w * gamma.detach()[None, :]).contiguous()
+            colsum = w.double().sum(1).float().contiguous()
+        packed = torch.empty(lib.soc_linear_split_packed_bytes(N, K), dtype=torch.uint8, device=w.device)
+        _lib.check(lib.soc_linear_split_pack_f32(w.data_ptr(), packed.data_ptr(), N, K, _stream()), "soc_linear_split_pack_f32")
+        return packed, eff_bias, colsum
+    return _split_cache.get((weight, bias, gamma, beta), build, extra=(bias is None, gamma is None))
 
 
 def row_stats(x: Tensor, eps: float) -> Tensor:
@@ -986,7 +1013,7 @@ def split_tile_for(M: int, N: int, K: int) -> int:
 
 XS_LINEAR_K = (192, 256, 384, 768)      # input widths K24 is built for
 _XS_NCT = (18, 16, 12, 8, 6, 4)         # column tiles per range it is built for
-_xs_cache = {}
+_xs_cache = DerivedCache()
 _k24_calls = None  # bench.py: when a list, xs_linear appends its arguments
 
 
@@ -1013,16 +1040,13 @@ def xs_linear_supported(x, weight) -> bool:
 def _xs_packed(weight: Tensor) -> Tensor:
     lib = _lib.load()
     N, K = weight.shape
-    ident = weight.data_ptr()
-    key = (ident, weight._version, N, K, weight.device.index, tuple(weight.stride()))
-    ent = _xs_cache.get(ident)
-    if ent is None or ent[0] != key:
+
+    def build():
         packed = torch.empty(lib.soc_xs_linear_packed_bytes(N, K), dtype=torch.uint8, device=weight.device)
         wc = _f32c(weight.detach())
         _lib.check(lib.soc_xs_linear_pack_f32(wc.data_ptr(), packed.data_ptr(), N, K, _stream()), "soc_xs_linear_pack_f32")
-        ent = (key, packed, weight)
-        _xs_cache[ident] = ent
-    return ent[1]
+        return packed
+    return _xs_cache.get((weight,), build)
 
 
 def xs_linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, ln: Optional[Tuple[Tensor, Tensor, float]] = None,
@@ -1066,7 +1090,7 @@ def xs_linear_plan(M: int, N: int, K: int) -> Tuple[int, int, int]:
 
 MLP_SPLIT_C = (96, 128, 192, 256, 384)  # model widths K23 is built for
 _MLP_ACT = {"relu": 1, "gelu": 2}
-_mlp_cache = {}
+_mlp_cache = DerivedCache()
 
 
 def mlp_split_supported(x: Tensor, w1: Tensor, w2: Tensor) -> bool:
@@ -1079,20 +1103,17 @@ def mlp_split_supported(x: Tensor, w1: Tensor, w2: Tensor) -> bool:
 
 
 def _mlp_packed(w1: Tensor, w2: Tensor) -> Tensor:
-    """The K23 weight image of (w1, w2): built once, rebuilt after an in-place update; the keyed tensors stay alive with it."""
+    """The K23 weight image of (w1, w2): built once, rebuilt after an in-place update, freed with the model."""
     lib = _lib.load()
     F_, C_ = w1.shape
-    ident = (w1.data_ptr(), w2.data_ptr())
-    key = ident + (w1._version, w2._version, F_, C_, w1.device.index, tuple(w1.stride()), tuple(w2.stride()))
-    ent = _mlp_cache.get(ident)
-    if ent is None or ent[0] != key:
+
+    def build():
         packed = torch.empty(lib.soc_mlp_split_packed_bytes(C_, F_), dtype=torch.uint8, device=w1.device)
         w1c, w2c = _f32c(w1.detach()), _f32c(w2.detach())
         _lib.check(lib.soc_mlp_split_pack_f32(w1c.data_ptr(), w2c.data_ptr(), packed.data_ptr(), C_, F_, _stream()),
                    "soc_mlp_split_pack_f32")
-        ent = (key, packed, (w1, w2))
-        _mlp_cache[ident] = ent
-    return ent[1]
+        return packed
+    return _mlp_cache.get((w1, w2), build)
 
 
 def mlp_split(x: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor, act: str = "gelu",

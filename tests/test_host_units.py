@@ -131,3 +131,34 @@ def test_plugin_module_name_and_surface():
         MSDA.ms_deform_attn_forward(*args, 0)
     with pytest.raises(Exception, match="no CPU fallback|MI355X"):
         MSDA.ms_deform_attn_forward(*args, 1)
+
+
+def test_derived_cache_keys_on_the_tensors_and_dies_with_them():
+    """the packed-image caches held strong references (models were never freed), bulk-cleared at a size threshold
+    (freeing images whose addresses live captured graphs had baked in) and one keyed on a temporary copy's address.  The
+    shared DerivedCache keys on what the tensors are (so per-call views hit), rebuilds after an in-place update, holds weak
+    references only and never bulk-clears."""
+    import gc
+
+    import torch
+
+    from neurips2023_soc_amd import hot_ops
+    c = hot_ops.DerivedCache()
+    w, b = torch.nn.Parameter(torch.randn(6, 4)), torch.nn.Parameter(torch.randn(6))
+    built = []
+
+    def build():
+        built.append(len(built))
+        return len(built)
+    assert c.get((w[:3], b[:3]), build) == 1 and c.get((w[:3], b[:3]), build) == 1          # a fresh view per call: same entry
+    assert c.get((w[3:], b[3:]), build) == 2                                                # other rows: another entry
+    wt = w.t()                                                                              # non-contiguous: keyed as it is
+    assert c.get((wt,), build) == 3 and c.get((w.t(),), build) == 3
+    with torch.no_grad():
+        w.mul_(2)
+    assert c.get((w[:3], b[:3]), build) == 4                                                # in-place update: rebuilt
+    assert c.get((w[:3], None), build, extra=("no bias",)) == 5
+    assert len(c) == 4
+    del w, wt
+    gc.collect()
+    assert len(c) == 0                                                                      # freed with the parameter
