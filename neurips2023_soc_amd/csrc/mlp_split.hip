@@ -56,7 +56,8 @@ __device__ __forceinline__ void handoff() {        // my part of the next block 
 
 // DBG (diagnostics only) bit 0: no LDS-DMA inside the block loop, bit 1: no MFMA work (stream ceiling), bit 2: no fragment
 // reads after a piece's first group, bit 3: no activation.  PF: fragment groups read ahead.  STAG bit 0: waves 4..7 run one ring
-// piece behind waves 0..3, bit 1: the activation runs at raised wave priority.
+// piece behind waves 0..3, bit 1: the activation runs at raised wave priority, bit 2: the LDS-DMA instructions of a piece are
+// issued between the MFMA groups of the step instead of in front of them.
 // NW waves per workgroup: 8 (two per SIMD, 256 registers each) or 4 (one per SIMD, 512 registers: wider rows or more row tiles
 // per wave, so that a weight fragment read from LDS feeds more MFMAs).  RT row tiles per wave.
 template <int C, int ACT, bool HAS_LN, int NW, int RT, int NSLOT, int SB, int STAG, int PF, int DBG>
@@ -70,8 +71,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mlp_split_kernel(
     // a block travels in SB ring pieces (a piece = a slot = one DMA round set): P LDS-DMA instructions per thread and piece
     constexpr int KS = G::KS, OT = G::OT, BLKP = G::BLKP_U4, SLOT = BLKP / SB, P = SLOT / THREADS;
     static_assert(OT % SB == 0 && SLOT % THREADS == 0 && (SB == 1 || BLKP == G::BLK_U4), "pieces are whole fragment groups");
-    static_assert(STAG == 0 || NW == 8, "the stagger pairs the two waves of a SIMD");
-    constexpr int D = NSLOT - 1 - (STAG ? 1 : 0);                       // pieces in flight ahead of the one being consumed
+    static_assert((STAG & 3) == 0 || NW == 8, "the stagger pairs the two waves of a SIMD");
+    constexpr int D = NSLOT - 1 - ((STAG & 1) ? 1 : 0);                       // pieces in flight ahead of the one being consumed
     static_assert(D >= 1 && (D - 1) * P < 64, "ring depth");
     extern __shared__ __attribute__((aligned(16))) u32x4 lds[];
     u32x4* slots = lds;
@@ -107,6 +108,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mlp_split_kernel(
         for (int u = 0; u < P; ++u)
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
                          ::"s"(dst + u * (THREADS * 16)), "v"(voff), "s"(src + u * (THREADS * 16)) : "memory");
+    };
+    auto dma_one = [&](int piece, int slot, int u) {      // instruction u of a piece's P (STAG bit 2: spread between the MFMAs)
+        const char* src = ibase + (long)piece * (SLOT * 16);
+        const unsigned dst = lds_slots + (unsigned)slot * (SLOT * 16);
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                     ::"s"(dst + u * (THREADS * 16)), "v"(voff), "s"(src + u * (THREADS * 16)) : "memory");
     };
     auto next_slot = [](int s) { return s + 1 == NSLOT ? 0 : s + 1; };
     __syncthreads();
@@ -181,6 +188,15 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mlp_split_kernel(
         // ---- the two kinds of block, one ring piece (1 / SB of a block: NGS fragment groups) at a time.  Fragment groups are
         // read PF groups ahead of the MFMAs that consume them.
         constexpr int NGS = OT / SB;
+        constexpr bool SPREAD = (STAG & 4) != 0 && NRT > 0 && !(DBG & 2);
+        int dq = -1, dsl = 0;                   // the piece whose LDS-DMA instructions this step still has to issue (SPREAD)
+        auto spread = [&](int gi) {             // instruction u goes out behind fragment group (u + 1) NGS / (P + 1) - 1
+            if constexpr (SPREAD) {
+#pragma unroll
+                for (int u = 0; u < P; ++u)
+                    if (gi == ((u + 1) * NGS) / (P + 1) && dq >= 0) dma_one(dq, dsl, u);
+            }
+        };
         auto frag = [&](bf16x8 (&wf)[3], const u32x4* wl, int gi) {
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) wf[pl] = __builtin_bit_cast(bf16x8, wl[(gi * 3 + pl) * 64]);
@@ -211,6 +227,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mlp_split_kernel(
                 if (gi + PF < NGS && !(DBG & 4)) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 6 * NRT, 0);
                 __builtin_amdgcn_sched_barrier(0);
+                spread(gi);
             }
         };
         // piece `sb` of a W2 block in slot `sl`: (activation and split of the chunk first), then its output tiles get the
@@ -253,6 +270,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mlp_split_kernel(
                 if (gi + PF < NGS && !(DBG & 4)) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 6 * NRT, 0);
                 __builtin_amdgcn_sched_barrier(0);
+                spread(gi);
             }
         };
         if (nq >= D) handoff<(D - 1) * P>(); else handoff<0>();         // piece 0 has landed
@@ -269,7 +287,13 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mlp_split_kernel(
         auto step = [&](auto k_c, int blk) {
             constexpr int K_ = decltype(k_c)::value;
             const bool more = q + D < nq;
-            if (!(DBG & 1) && more) { dma(q + D, dslot); dslot = next_slot(dslot); }
+            if (!(DBG & 1) && more) {
+                if constexpr (SPREAD && !LATE) { dq = q + D; dsl = dslot; }
+                else dma(q + D, dslot);
+                dslot = next_slot(dslot);
+            } else {
+                dq = -1;
+            }
             if constexpr (!LATE) piece(k_c, blk, slot);
             else if (K_ > 0) piece(std::integral_constant<int, (K_ > 0 ? K_ - 1 : 0)>{}, blk, pslot);
             else if (blk > 0) piece(std::integral_constant<int, 2 * SB - 1>{}, blk - 2, pslot);
@@ -368,7 +392,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mlp_split_kernel(
             else if (nrt == 1) pass(std::integral_constant<int, 1>{}, late_c, pt);
             else pass(std::integral_constant<int, 0>{}, late_c, pt);
         };
-        if (STAG && wave >= NW / 2) run(std::integral_constant<bool, STAG != 0>{});
+        if ((STAG & 1) && wave >= NW / 2) run(std::integral_constant<bool, (STAG & 1) != 0>{});
         else run(std::false_type{});
     }
     __syncthreads();        // the waves retire together
@@ -538,13 +562,13 @@ int launch_variant(const Args& a, int variant) {
     case NS + 8 * LSB + 32 * DB + 512 * (PFD - 1) + 1024 * ST:                                                   \
         if constexpr ((size_t)NS * (Geo<C>::BLKP_U4 >> LSB) * 16 + 8 * C + 4096 <= 160 * 1024 &&                 \
                       (Geo<C>::OT >> LSB) >= 1 && (LSB == 0 || Geo<C>::BLKP_U4 == Geo<C>::BLK_U4) &&             \
-                      (Geo<C>::BLKP_U4 >> LSB) % (NW0 * 64) == 0 && (ST == 0 || NW0 == 8))                       \
+                      (Geo<C>::BLKP_U4 >> LSB) % (NW0 * 64) == 0 && ((ST & 3) == 0 || NW0 == 8))                       \
             return launch<C, ACT, HAS_LN, NW0, RT0, NS, (1 << LSB), ST, PFD, DB>(a);                             \
         else break;
     constexpr int NW0 = form_nw(C), RT0 = form_rt(C);
     switch (variant) {
         V(2, 0, 0, 1, 0) V(3, 0, 0, 1, 0) V(4, 1, 0, 1, 0) V(3, 1, 0, 1, 0)
-        V(3, 0, 1, 1, 0) V(3, 0, 3, 1, 0) V(3, 0, 2, 1, 0) V(4, 0, 1, 1, 0) V(4, 0, 3, 1, 0) V(4, 0, 2, 1, 0)
+        V(3, 0, 1, 1, 0) V(3, 0, 3, 1, 0) V(3, 0, 2, 1, 0) V(3, 0, 4, 1, 0) V(4, 0, 4, 1, 0) V(4, 1, 4, 1, 0) V(2, 0, 4, 1, 0)
         V(3, 0, 0, 1, 1) V(3, 0, 0, 1, 2) V(3, 0, 0, 1, 13) V(4, 1, 0, 1, 1) V(4, 1, 0, 1, 2) V(4, 1, 0, 1, 13)
         default: break;
     }

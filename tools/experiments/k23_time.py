@@ -116,7 +116,8 @@ def vr(ns=3, lsb=0, stag=0, pf=1, dbg=0):
     return ns + 8 * lsb + 32 * dbg + 512 * (pf - 1) + 1024 * stag
 
 
-V = [0, vr(3), vr(3, stag=1), vr(3, stag=3), vr(3, stag=2), vr(4, stag=1), vr(4, stag=3), vr(4, stag=2)]
+V = [0, vr(3), vr(3, stag=4), vr(2, stag=4)]
 case("enc", 32768, 256, 2048, "relu", False, True, [(256, 1)], V)
-case("s0", 115200, 96, 384, "gelu", True, True, [(256, 1)], V)
+case("s0", 115200, 96, 384, "gelu", True, True, [(256, 1)], [0, vr(3), vr(3, stag=4), vr(4, stag=4)])
 case("s1", 28800, 192, 768, "gelu", True, True, [None], V)
+case("s2", 7360, 384, 1536, "gelu", True, True, [None], [0, vr(4, 1), vr(4, 1, stag=4)])
