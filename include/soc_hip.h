@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SOC_HIP_ABI_VERSION 13
+#define SOC_HIP_ABI_VERSION 14
 
 #define SOC_OK 0
 #define SOC_EINVAL (-1)       /* null pointer / non-positive dimension */
@@ -247,11 +247,13 @@ int soc_patch_merge_layernorm_f32(const float* x, const float* gamma, const floa
 /*
  * K23 -- a two-layer perceptron block in one launch, on the bf16 matrix cores (exact three-way operand split, f32-grade
  * results -- see soc_linear_split_f32):
- *     out = LN2(act(LN(x) W1^T + b1) W2^T + b2 + residual),   act 1 = ReLU, 2 = exact (erf) GELU;  LN, LN2, residual optional.
+ *     out = LN2(act(LN(x) W1^T + b1) W2^T + b2 + residual),   act 1 = ReLU, 2 = exact (erf) GELU;  LN, LN2, residual optional;
+ *     with residual_ln != 0 the shortcut is LN(residual) (the same LayerNorm as in front of W1) instead of residual itself.
  * Replaces  x + mlp(norm2(x))  of SwinTransformerBlock3D.forward_part2 (models/video_swin_transformer.py:262-272 with
  * Mlp.forward :24-37: norm2, fc1, nn.GELU, fc2, the residual add) and linear1 -> ReLU -> linear2 of
  * DeformableTransformerEncoderLayer.forward_ffn (models/deformable_transformer.py:253-263) with the residual add and norm2
- * behind it (post_gamma / post_beta: `src = norm2(src + dropout3(src2))`, :261-262).  The [M, F] hidden tensor is
+ * behind it (post_gamma / post_beta: `src = norm2(src + dropout3(src2))`, :261-262) and norm1 in front (ln_gamma / ln_beta with
+ * residual_ln: `src = norm1(src + dropout1(src2))`, :249-250, whose result is both the block's input and its shortcut).  The [M, F] hidden tensor is
  * never written.  Every row is taken: whole rounds of the chip stream both weight matrices once per 16 (C <= 96), 8
  * (C <= 256) or 4 (C = 384) row tiles of 16 per CU; a short last round, or a short input altogether, is cut over `nfs` hidden ranges whose
  * partial sums a second kernel adds in a fixed order (deterministic).
@@ -271,11 +273,11 @@ int soc_mlp_split_plan(long M, int C, int F, int* nrg, int* nfs);
 int soc_mlp_split_f32(const float* x, const void* packed, const float* b1, const float* b2, const float* ln_gamma,
                       const float* ln_beta, float ln_eps, const float* residual, const float* post_gamma,
                       const float* post_beta, float post_eps, float* out, float* out_sum, float* workspace,
-                      size_t workspace_bytes, long M, int C, int F, int act, void* stream);
+                      size_t workspace_bytes, long M, int C, int F, int act, int residual_ln, void* stream);
 int soc_mlp_split_variant_f32(const float* x, const void* packed, const float* b1, const float* b2, const float* ln_gamma,
                               const float* ln_beta, float ln_eps, const float* residual, const float* post_gamma,
                               const float* post_beta, float post_eps, float* out, float* out_sum, float* workspace, long M,
-                              int C, int F, int act, int nrg, int nfs, int variant, void* stream);
+                              int C, int F, int act, int residual_ln, int nrg, int nfs, int variant, void* stream);
 
 /*
  * K24 -- an x-stationary linear layer on the bf16 matrix cores (exact three-way operand split, f32-grade results -- see

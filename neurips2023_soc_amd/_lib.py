@@ -25,7 +25,7 @@ EXPORTS = ("soc_hip_abi_version", "soc_hip_error_string", "soc_msda_fwd_f32", "s
            "soc_mlp_split_workspace_bytes", "soc_mlp_split_plan", "soc_mlp_split_f32", "soc_mlp_split_variant_f32",
            "soc_xs_linear_packed_bytes", "soc_xs_linear_pack_f32", "soc_xs_linear_plan", "soc_xs_linear_f32",
            "soc_set_reserved_cus", "soc_get_reserved_cus")
-ABI_VERSION = 13
+ABI_VERSION = 14
 SOC_EUNSUPPORTED = -2      # include/soc_hip.h: shape outside what the kernel is built for
 
 _lib = None
@@ -125,9 +125,9 @@ def load() -> C.CDLL:
     lib.soc_mlp_split_plan.restype = i
     lib.soc_mlp_split_plan.argtypes = [C.c_long, i, i, C.POINTER(i), C.POINTER(i)]
     lib.soc_mlp_split_f32.restype = i
-    lib.soc_mlp_split_f32.argtypes = [p, p, p, p, p, p, f, p, p, p, f, p, p, p, C.c_size_t, C.c_long, i, i, i, p]
+    lib.soc_mlp_split_f32.argtypes = [p, p, p, p, p, p, f, p, p, p, f, p, p, p, C.c_size_t, C.c_long, i, i, i, i, p]
     lib.soc_mlp_split_variant_f32.restype = i
-    lib.soc_mlp_split_variant_f32.argtypes = [p, p, p, p, p, p, f, p, p, p, f, p, p, p, C.c_long, i, i, i, i, i, i, p]
+    lib.soc_mlp_split_variant_f32.argtypes = [p, p, p, p, p, p, f, p, p, p, f, p, p, p, C.c_long, i, i, i, i, i, i, i, p]
     lib.soc_xs_linear_packed_bytes.restype = C.c_size_t
     lib.soc_xs_linear_packed_bytes.argtypes = [i, i]
     lib.soc_xs_linear_pack_f32.restype = i

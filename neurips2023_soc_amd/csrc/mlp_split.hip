@@ -65,7 +65,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mlp_split_kernel(
     const float* __restrict__ x, const u32x4* __restrict__ img, const float* __restrict__ b1, const float* __restrict__ b2,
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps, const float* __restrict__ res,
     const float* __restrict__ gamma2, const float* __restrict__ beta2, float eps2, float* __restrict__ out,
-    float* __restrict__ out_sum, long M, int F, int nrg, int nfs) {
+    float* __restrict__ out_sum, long M, int F, int nrg, int nfs, int res_ln) {
     using G = Geo<C>;
     constexpr int THREADS = NW * 64;
     // a block travels in SB ring pieces (a piece = a slot = one DMA round set): P LDS-DMA instructions per thread and piece
@@ -124,6 +124,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mlp_split_kernel(
         constexpr bool LATE = decltype(late_c)::value;
         constexpr int NX = NRT > 0 ? NRT : 1;
         bf16x8 xb[NX][KS][3];
+        float ln_mean[NX], ln_rstd[NX];         // kept for a residual that is LN(x) itself (res_ln: the encoder's norm1 folded in)
         {
             float4 xn[NX][KS][2];
 #pragma unroll
@@ -163,6 +164,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mlp_split_kernel(
                     q += __shfl_xor(q, 16);
                     q += __shfl_xor(q, 32);
                     const float rstd = rsqrtf(fmaf(q, inv_c, eps_v));
+                    ln_mean[rt] = mean; ln_rstd[rt] = rstd;
 #pragma unroll
                     for (int s = 0; s < KS; ++s) {
                         const float4* gp = reinterpret_cast<const float4*>(gs + 32 * s + 8 * kq);
@@ -336,6 +338,15 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mlp_split_kernel(
                         f32x4 rr[OT];
 #pragma unroll
                         for (int ot = 0; ot < OT; ++ot) rr[ot] = *reinterpret_cast<const f32x4*>(res + mo + 16 * ot);
+                        if (HAS_LN && res_ln) {     // the shortcut is LN(x), not x: the prologue's formula on the output layout
+#pragma unroll
+                            for (int ot = 0; ot < OT; ++ot) {
+                                const f32x4 g1 = *reinterpret_cast<const f32x4*>(gs + 16 * ot + 4 * kq);
+                                const f32x4 e1 = *reinterpret_cast<const f32x4*>(bs + 16 * ot + 4 * kq);
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) rr[ot][i] = fmaf((rr[ot][i] - ln_mean[rt]) * ln_rstd[rt], g1[i], e1[i]);
+                            }
+                        }
 #pragma unroll
                         for (int ot = 0; ot < OT; ++ot) acc2[rt][ot] = (acc2[rt][ot] + bq[ot]) + rr[ot];
                     } else {
@@ -400,19 +411,21 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mlp_split_kernel(
 
 // out = [LayerNorm](sum over the hidden ranges (fixed order) + b2 (+ residual)); a wave per row, up to two float4 per lane
 __global__ __launch_bounds__(256) void mlp_reduce_kernel(const float* __restrict__ part, int nfs, const float* __restrict__ b2,
-                                                         const float* __restrict__ res, const float* __restrict__ gamma2,
-                                                         const float* __restrict__ beta2, float eps2, float* __restrict__ out,
-                                                         float* __restrict__ out_sum, long M, int C) {
+                                                         const float* __restrict__ res, const float* __restrict__ gamma1,
+                                                         const float* __restrict__ beta1, float eps1,
+                                                         const float* __restrict__ gamma2, const float* __restrict__ beta2,
+                                                         float eps2, float* __restrict__ out, float* __restrict__ out_sum,
+                                                         long M, int C) {
     const int lane = threadIdx.x & 63;
     const long n4 = M * C / 4;
     for (long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6); m < M; m += (long)gridDim.x * 4) {
-        float4 a[2];
+        float4 a[2], rr[2];
         bool on[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int c4 = lane + 64 * h;
             on[h] = c4 < C / 4;
-            a[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+            a[h] = rr[h] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (on[h]) {
                 const long i = m * (C / 4) + c4;
                 a[h] = reinterpret_cast<const float4*>(part)[i];
@@ -422,11 +435,36 @@ __global__ __launch_bounds__(256) void mlp_reduce_kernel(const float* __restrict
                 }
                 const float4 bq = *reinterpret_cast<const float4*>(b2 + 4 * c4);
                 a[h].x += bq.x; a[h].y += bq.y; a[h].z += bq.z; a[h].w += bq.w;
-                if (res) {
-                    const float4 rr = reinterpret_cast<const float4*>(res)[i];
-                    a[h].x += rr.x; a[h].y += rr.y; a[h].z += rr.z; a[h].w += rr.w;
-                }
+                if (res) rr[h] = reinterpret_cast<const float4*>(res)[i];
             }
+        }
+        if (res && gamma1) {       // the shortcut is LN(res) (two-pass, as the block kernel's prologue)
+            float sm = ((rr[0].x + rr[0].y) + (rr[0].z + rr[0].w)) + ((rr[1].x + rr[1].y) + (rr[1].z + rr[1].w));
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) sm += __shfl_xor(sm, d);
+            const float mean = sm / C;
+            float q = 0.f;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                if (on[h]) {
+                    rr[h].x -= mean; rr[h].y -= mean; rr[h].z -= mean; rr[h].w -= mean;
+                    q += rr[h].x * rr[h].x + rr[h].y * rr[h].y + rr[h].z * rr[h].z + rr[h].w * rr[h].w;
+                }
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) q += __shfl_xor(q, d);
+            const float rstd = rsqrtf(q / C + eps1);
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                if (on[h]) {
+                    const float4 g1 = *reinterpret_cast<const float4*>(gamma1 + 4 * (lane + 64 * h));
+                    const float4 e1 = *reinterpret_cast<const float4*>(beta1 + 4 * (lane + 64 * h));
+                    rr[h].x = fmaf(rr[h].x * rstd, g1.x, e1.x); rr[h].y = fmaf(rr[h].y * rstd, g1.y, e1.y);
+                    rr[h].z = fmaf(rr[h].z * rstd, g1.z, e1.z); rr[h].w = fmaf(rr[h].w * rstd, g1.w, e1.w);
+                }
+        }
+        if (res) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) { a[h].x += rr[h].x; a[h].y += rr[h].y; a[h].z += rr[h].z; a[h].w += rr[h].w; }
         }
         if (gamma2) {
             if (out_sum) {
@@ -521,7 +559,7 @@ struct Args {
     float* out;
     float* out_sum;
     long M;
-    int F, nrg, nfs;
+    int F, nrg, nfs, res_ln;
     hipStream_t st;
 };
 
@@ -539,7 +577,7 @@ int launch(const Args& a) {
     }
     hipLaunchKernelGGL((mlp_split_kernel<C, ACT, HAS_LN, NW, RT, NSLOT, SB, STAG, PF, DBG>), dim3((unsigned)(a.nrg * a.nfs)),
                        dim3(NW * 64), lds, a.st, a.x, a.img, a.b1, a.b2, a.gamma, a.beta, a.eps, a.res, a.gamma2, a.beta2, a.eps2,
-                       a.out, a.out_sum, a.M, a.F, a.nrg, a.nfs);
+                       a.out, a.out_sum, a.M, a.F, a.nrg, a.nfs, a.res_ln);
     return soc_check_launch();
 }
 
@@ -667,12 +705,13 @@ extern "C" size_t soc_mlp_split_workspace_bytes(long M, int C, int F) {
 extern "C" int soc_mlp_split_variant_f32(const float* x, const void* packed, const float* b1, const float* b2,
                                          const float* ln_gamma, const float* ln_beta, float ln_eps, const float* residual,
                                          const float* post_gamma, const float* post_beta, float post_eps, float* out,
-                                         float* out_sum, float* workspace, long M, int C, int F, int act, int nrg, int nfs,
-                                         int variant, void* stream) {
+                                         float* out_sum, float* workspace, long M, int C, int F, int act, int residual_ln,
+                                         int nrg, int nfs, int variant, void* stream) {
     if (M < 0 || F <= 0) return SOC_EINVAL;
     if (M == 0) return SOC_OK;
     if (!x || !packed || !b1 || !b2 || !out || (ln_gamma == nullptr) != (ln_beta == nullptr) ||
-        (post_gamma == nullptr) != (post_beta == nullptr) || (out_sum && !post_gamma))
+        (post_gamma == nullptr) != (post_beta == nullptr) || (out_sum && !post_gamma) ||
+        (residual_ln && (!residual || !ln_gamma)))
         return SOC_EINVAL;
     if (!width_ok(C) || F % 32 != 0 || (act != 1 && act != 2)) return SOC_EUNSUPPORTED;
     if ((((uintptr_t)x | (uintptr_t)packed | (uintptr_t)b1 | (uintptr_t)b2 | (uintptr_t)residual | (uintptr_t)out |
@@ -684,7 +723,7 @@ extern "C" int soc_mlp_split_variant_f32(const float* x, const void* packed, con
     hipStream_t st = (hipStream_t)stream;
     Args a{x, b1, b2, ln_gamma, ln_beta, nfs > 1 ? nullptr : residual, nfs > 1 ? nullptr : post_gamma,
            nfs > 1 ? nullptr : post_beta, post_eps, reinterpret_cast<const u32x4*>(packed), ln_eps,
-           nfs > 1 ? workspace : out, nfs > 1 ? nullptr : out_sum, M, F, nrg, nfs, st};
+           nfs > 1 ? workspace : out, nfs > 1 ? nullptr : out_sum, M, F, nrg, nfs, residual_ln, st};
     int rc;
     switch (C) {
         case 96: rc = launch_c<96>(a, act, variant); break;
@@ -695,15 +734,16 @@ extern "C" int soc_mlp_split_variant_f32(const float* x, const void* packed, con
     }
     if (rc != SOC_OK || nfs == 1) return rc;
     const int blocks = (int)((M + 3) / 4 > 8192 ? 8192 : (M + 3) / 4);
-    hipLaunchKernelGGL(mlp_reduce_kernel, dim3(blocks), dim3(256), 0, st, workspace, nfs, b2, residual, post_gamma, post_beta,
-                       post_eps, out, out_sum, M, C);
+    hipLaunchKernelGGL(mlp_reduce_kernel, dim3(blocks), dim3(256), 0, st, workspace, nfs, b2, residual,
+                       residual_ln ? ln_gamma : nullptr, residual_ln ? ln_beta : nullptr, ln_eps, post_gamma, post_beta, post_eps,
+                       out, out_sum, M, C);
     return soc_check_launch();
 }
 
 extern "C" int soc_mlp_split_f32(const float* x, const void* packed, const float* b1, const float* b2, const float* ln_gamma,
                                  const float* ln_beta, float ln_eps, const float* residual, const float* post_gamma,
                                  const float* post_beta, float post_eps, float* out, float* out_sum, float* workspace,
-                                 size_t workspace_bytes, long M, int C, int F, int act, void* stream) {
+                                 size_t workspace_bytes, long M, int C, int F, int act, int residual_ln, void* stream) {
     if (M < 0 || F <= 0) return SOC_EINVAL;
     if (M == 0) return SOC_OK;
     if (!width_ok(C) || F % 32 != 0) return SOC_EUNSUPPORTED;
@@ -713,14 +753,15 @@ extern "C" int soc_mlp_split_f32(const float* x, const void* packed, const float
     int nrg = 0, nfs = 0;
     if (m0 < M) {       // whole rounds first, then the tail over split hidden ranges
         const int rc = soc_mlp_split_variant_f32(x, packed, b1, b2, ln_gamma, ln_beta, ln_eps, residual, post_gamma, post_beta,
-                                                 post_eps, out, out_sum, nullptr, m0, C, F, act, cus, 1, 0, stream);
+                                                 post_eps, out, out_sum, nullptr, m0, C, F, act, residual_ln, cus, 1, 0, stream);
         if (rc != SOC_OK) return rc;
         plan_rows(M - m0, C, F, cus, &nrg, &nfs);
         return soc_mlp_split_variant_f32(x + m0 * C, packed, b1, b2, ln_gamma, ln_beta, ln_eps,
                                          residual ? residual + m0 * C : nullptr, post_gamma, post_beta, post_eps, out + m0 * C,
-                                         out_sum ? out_sum + m0 * C : nullptr, workspace, M - m0, C, F, act, nrg, nfs, 0, stream);
+                                         out_sum ? out_sum + m0 * C : nullptr, workspace, M - m0, C, F, act, residual_ln, nrg, nfs, 0,
+                                         stream);
     }
     plan_rows(M, C, F, cus, &nrg, &nfs);
     return soc_mlp_split_variant_f32(x, packed, b1, b2, ln_gamma, ln_beta, ln_eps, residual, post_gamma, post_beta, post_eps, out,
-                                     out_sum, workspace, M, C, F, act, nrg, nfs, 0, stream);
+                                     out_sum, workspace, M, C, F, act, residual_ln, nrg, nfs, 0, stream);
 }

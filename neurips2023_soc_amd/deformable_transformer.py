@@ -29,13 +29,17 @@ class DeformableTransformerEncoderLayer(nn.Module):
 
     def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None,
                 pad_flag=None):
+        if fused.mlp_ok(src, self.linear1, self.linear2):
+            # the shortcut rides in output_proj's epilogue; norm1, linear1 + ReLU + linear2, the shortcut norm1(.) and norm2 are ONE
+            # K23 launch (whole rounds of the chip + a split tail): no LayerNorm pass in the layer
+            s1, _, _ = self.self_attn(src, reference_points, src, spatial_shapes, level_start_index, padding_mask,
+                                      pad_flag=pad_flag, return_sampling=False, query_pos=pos, residual=src)
+            return hot_ops.mlp_split(s1, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias, "relu",
+                                     ln=(self.norm1.weight, self.norm1.bias, self.norm1.eps), residual=s1, residual_ln=True,
+                                     post_ln=(self.norm2.weight, self.norm2.bias, self.norm2.eps))
         a, _, _ = self.self_attn(src, reference_points, src, spatial_shapes, level_start_index, padding_mask,
                                  pad_flag=pad_flag, return_sampling=False, query_pos=pos)
         src = _add_norm(src, a, self.norm1)
-        if fused.mlp_ok(src, self.linear1, self.linear2):
-            # K23: linear1 + ReLU + linear2 + residual + norm2 in one launch (whole rounds of the chip + a split tail)
-            return hot_ops.mlp_split(src, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias, "relu",
-                                     residual=src, post_ln=(self.norm2.weight, self.norm2.bias, self.norm2.eps))
         return _add_norm(src, fused.ffn_relu(src, self.linear1, self.linear2), self.norm2)
 
 

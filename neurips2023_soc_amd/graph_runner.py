@@ -153,7 +153,10 @@ class PipelinedClipGraph:
     def _tail(self, sb, fork: bool):
         # the tail runs beside another clip's head, which pays for the tail's CU time and not for its launch count: the
         # query chain keeps K7's small workgroups here (hot_ops.row_chain_fusion)
-        prev, hot_ops.row_chain_fusion = hot_ops.row_chain_fusion, False
+        import os
+        prev, hot_ops.row_chain_fusion = hot_ops.row_chain_fusion, os.environ.get("SOC_TAIL_ROW_FUSION", "0") == "1"
+        if os.environ.get("SOC_TAIL_NO_FORK", "0") == "1":
+            fork = False
         try:
             out = self.model.forward_tail(sb, self.targets, fork=fork)
         finally:

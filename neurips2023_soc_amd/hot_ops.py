@@ -1119,9 +1119,11 @@ def _mlp_packed(w1: Tensor, w2: Tensor) -> Tensor:
 def mlp_split(x: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor, act: str = "gelu",
               ln: Optional[Tuple[Tensor, Tensor, float]] = None, residual: Optional[Tensor] = None,
               out: Optional[Tensor] = None, cut: Optional[Tuple[int, int]] = None, variant: int = 0,
-              post_ln: Optional[Tuple[Tensor, Tensor, float]] = None, return_sum: bool = False):
+              post_ln: Optional[Tuple[Tensor, Tensor, float]] = None, return_sum: bool = False, residual_ln: bool = False):
     """K23: LN2(act(LN(x) @ w1.T + b1) @ w2.T + b2 + residual) in one launch, the hidden layer in registers; ln / post_ln =
-    (gamma, beta, eps) or None, act "relu" | "gelu".  With post_ln and return_sum the result is (sum in front of LN2, LN2(sum)).  `cut` = (workgroup rows, hidden ranges) forces one launch with that decomposition
+    (gamma, beta, eps) or None, act "relu" | "gelu".  With post_ln and return_sum the result is (sum in front of LN2, LN2(sum)).
+    residual_ln: the shortcut is LN(residual) -- the LayerNorm `ln` -- instead of residual itself (the encoder's norm1, whose result
+    is both the block's input and its shortcut).  `cut` = (workgroup rows, hidden ranges) forces one launch with that decomposition
     (tests, probes); by default the library plans whole rounds + a split tail."""
     _need_gpu(x, w1, b1, w2, b2, residual, *(ln[:2] if ln else ()), *(post_ln[:2] if post_ln else ()))
     lib = _lib.load()
@@ -1149,17 +1151,19 @@ def mlp_split(x: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor, act: st
     b1c, b2c = _f32c(b1), _f32c(b2)
     if return_sum and post_ln is None:
         raise _lib.SocHipError("mlp_split: return_sum needs post_ln (without it the result is the sum)")
+    if residual_ln and (ln is None or residual is None):
+        raise _lib.SocHipError("mlp_split: residual_ln needs both ln and residual")
     osum = torch.empty_like(x) if return_sum else None
     if _k23_calls is not None:
         _k23_calls.append(dict(x=x, w1=w1, b1=b1, w2=w2, b2=b2, act=act, ln=ln, residual=residual, post_ln=post_ln, cut=cut,
-                               return_sum=return_sum))
+                               return_sum=return_sum, residual_ln=residual_ln))
     if cut is None:
         nbytes = lib.soc_mlp_split_workspace_bytes(M, C_, F_)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
         with _timed("mlp_split", 4.0 * M * F_ * C_):
             rc = lib.soc_mlp_split_f32(x.data_ptr(), packed.data_ptr(), b1c.data_ptr(), b2c.data_ptr(), ptr(g), ptr(be), eps,
                                        ptr(residual), ptr(g2), ptr(be2), eps2, out.data_ptr(), ptr(osum), ptr(ws), nbytes, M, C_,
-                                       F_, _MLP_ACT[act], _stream())
+                                       F_, _MLP_ACT[act], int(residual_ln), _stream())
         _lib.check(rc, "soc_mlp_split_f32")
         return (osum, out) if return_sum else out
     nrg, nfs = cut
@@ -1167,7 +1171,7 @@ def mlp_split(x: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor, act: st
     with _timed("mlp_split", 4.0 * M * F_ * C_):
         rc = lib.soc_mlp_split_variant_f32(x.data_ptr(), packed.data_ptr(), b1c.data_ptr(), b2c.data_ptr(), ptr(g), ptr(be), eps,
                                            ptr(residual), ptr(g2), ptr(be2), eps2, out.data_ptr(), ptr(osum), ptr(ws), M, C_, F_,
-                                           _MLP_ACT[act], int(nrg), int(nfs), int(variant), _stream())
+                                           _MLP_ACT[act], int(residual_ln), int(nrg), int(nfs), int(variant), _stream())
     _lib.check(rc, "soc_mlp_split_variant_f32")
     return (osum, out) if return_sum else out
 

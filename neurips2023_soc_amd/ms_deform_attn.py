@@ -88,10 +88,11 @@ class MSDeformAttn(nn.Module):
 
     def forward(self, query, reference_points, input_flatten, input_spatial_shapes,
                 input_level_start_index, input_padding_mask=None, pad_flag=None, return_sampling=True,
-                query_pos=None, value=None):
+                query_pos=None, value=None, residual=None):
         """Reference signature plus optional arguments used by this package's own layers
         (``query_pos``: added to ``query`` inside the offset / weight projections; ``value``: the already
         projected ``value_proj(input_flatten)`` when the caller computed it ahead of time):
+        ``residual``: added to the result in the output projection's epilogue (the encoder layer's shortcut);
         ``return_sampling=False`` (SOC never reads the sampling locations / weights) allows the fused
         kernel, which needs ``pad_flag`` = int32[1] device tensor "the padding mask has any True"."""
         N, Lq, _ = query.shape
@@ -109,7 +110,7 @@ class MSDeformAttn(nn.Module):
                 value.view(N, S, M, 32), input_spatial_shapes, input_level_start_index, reference_points,
                 offsets_raw.view(N, Lq, M, L, P, 2), logits_raw.view(N, Lq, M, L * P), input_padding_mask,
                 pad_flag)
-            return fused.apply(self.output_proj, out), None, None
+            return fused.linear(out, self.output_proj.weight, self.output_proj.bias, residual=residual), None, None
         if input_padding_mask is not None:
             value = value.masked_fill(input_padding_mask[..., None], 0.0)
         value = value.view(N, S, M, self.d_model // M)
@@ -125,4 +126,5 @@ class MSDeformAttn(nn.Module):
             raise ValueError(f"Last dim of reference_points must be 2 or 4, but get {reference_points.shape[-1]} instead.")
         out = MSDeformAttnFunction.apply(value.contiguous(), input_spatial_shapes, input_level_start_index,
                                          loc.contiguous(), weights.contiguous(), self.im2col_step)
-        return self.output_proj(out), loc, weights
+        out = self.output_proj(out)
+        return (out if residual is None else out + residual), loc, weights

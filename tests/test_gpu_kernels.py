@@ -1359,3 +1359,27 @@ def test_xs_linear_vs_f64(ops, M, N, K, act, ln, res):
         assert torch.equal(got, ops.xs_linear(x, w, b, lnp, r, act, cut=cut)), cut
     w.mul_(0.5)
     assert float((ops.xs_linear(x, w, b, lnp, r, act).double() - ref(torch.float64)).abs().max()) < 1e-5 * scale
+
+
+@pytest.mark.parametrize("M,cut", [(38560, None), (5792, (46, 4)), (5792, (100, 1)), (33, None)])
+def test_mlp_split_residual_layernorm(ops, M, cut):
+    """The encoder layer around its feed-forward block in one K23 launch (reference models/deformable_transformer.py:247-263):
+    n1 = norm1(s1), out = norm2(n1 + linear2(relu(linear1(n1)))) -- norm1 is both the block's input and its shortcut
+    (`residual_ln`), recomputed on the output layout from the row statistics kept by the prologue (block kernel) or by the reduce
+    kernel (split hidden ranges)."""
+    x, w1, b1, w2, b2, _ = _mlp_case(M, 256, 2048, "relu", False, 3 * M)
+    g = torch.Generator().manual_seed(9)
+    g1, e1 = (torch.rand(256, generator=g) + 0.5).cuda(), (torch.randn(256, generator=g) * 0.1).cuda()
+    g2, e2 = (torch.rand(256, generator=g) + 0.5).cuda(), (torch.randn(256, generator=g) * 0.1).cuda()
+    got = ops.mlp_split(x, w1, b1, w2, b2, "relu", ln=(g1, e1, 1e-5), residual=x, residual_ln=True, post_ln=(g2, e2, 1e-5), cut=cut)
+    n1 = torch.nn.functional.layer_norm(x.double(), (256,), g1.double(), e1.double(), 1e-5)
+    y = torch.nn.functional.linear(torch.nn.functional.linear(n1, w1.double(), b1.double()).relu(), w2.double(), b2.double())
+    want = torch.nn.functional.layer_norm(n1 + y, (256,), g2.double(), e2.double(), 1e-5)
+    n1f = torch.nn.functional.layer_norm(x, (256,), g1, e1, 1e-5)
+    lib = torch.nn.functional.layer_norm(n1f + torch.nn.functional.linear(torch.nn.functional.linear(n1f, w1, b1).relu(), w2, b2),
+                                         (256,), g2, e2, 1e-5)
+    e_k, e_lib = float((got.double() - want).abs().max()), float((lib.double() - want).abs().max())
+    print(f"K23 norm1 + FFN + norm2, M = {M}: split {e_k:.2e}  library f32 {e_lib:.2e}")
+    assert e_k < 2e-5 and e_k <= 1.5 * e_lib + 1e-6, (e_k, e_lib)
+    assert torch.equal(got, ops.mlp_split(x, w1, b1, w2, b2, "relu", ln=(g1, e1, 1e-5), residual=x, residual_ln=True,
+                                           post_ln=(g2, e2, 1e-5), cut=cut))

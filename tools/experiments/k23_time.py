@@ -39,7 +39,7 @@ lib.soc_mlp_split_packed_bytes.restype = C.c_size_t
 lib.soc_mlp_split_packed_bytes.argtypes = [i, i]
 lib.soc_mlp_split_pack_f32.argtypes = [p, p, p, i, i, p]
 lib.soc_mlp_split_plan.argtypes = [C.c_long, i, i, C.POINTER(i), C.POINTER(i)]
-lib.soc_mlp_split_variant_f32.argtypes = [p, p, p, p, p, p, f, p, p, p, f, p, p, p, C.c_long, i, i, i, i, i, i, p]
+lib.soc_mlp_split_variant_f32.argtypes = [p, p, p, p, p, p, f, p, p, p, f, p, p, p, C.c_long, i, i, i, i, i, i, i, p]
 g = torch.Generator().manual_seed(0)
 quick = "--quick" in sys.argv
 
@@ -95,7 +95,7 @@ def case(name, M, Cw, F, act, ln, res, cuts, variants):
             def run():
                 return lib.soc_mlp_split_variant_f32(x.data_ptr(), packed.data_ptr(), b1.data_ptr(), b2.data_ptr(), ptr(gam),
                                                      ptr(bet), 1e-5, ptr(r), None, None, 0.0, out.data_ptr(), None, ptr(ws), M, Cw, F,
-                                                     1 if act == "relu" else 2, nrg, nfs, v, st)
+                                                     1 if act == "relu" else 2, 0, nrg, nfs, v, st)
             out.zero_()
             rc = run()
             if rc != 0:
