@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SOC_HIP_ABI_VERSION 14
+#define SOC_HIP_ABI_VERSION 15
 
 #define SOC_OK 0
 #define SOC_EINVAL (-1)       /* null pointer / non-positive dimension */
@@ -300,6 +300,17 @@ int soc_xs_linear_plan(long M, int N, int K, int* nrg, int* ncr, int* nct);
 int soc_xs_linear_f32(const float* x, const void* packed, const float* bias, const float* ln_gamma, const float* ln_beta,
                       float ln_eps, const float* residual, float* out, long M, int N, int K, int act, int nrg, int ncr,
                       void* stream);
+
+/*
+ * K25 -- multi-head self-attention core for short sequences: softmax(q k^T * scale + mask) v per (batch, head), L <= 64 tokens,
+ * head dim 32 or 64.  Replaces torch.nn.functional.scaled_dot_product_attention as HuggingFace's RobertaSelfAttention calls it
+ * inside the text encoder SOC.forward_text runs per clip (models/soc.py:167-181) -- PyTorch's AOTriton kernel on ROCm.
+ *   q, k, v, out [B, L, H * D] token-major (heads are D-wide column blocks: what the q / k / v projections write),
+ *   mask additive float (e.g. -inf on padding) addressed mask[b * mask_batch_stride + i * mask_query_stride + j] (query stride 0
+ *   for a key-padding mask broadcast over queries) or NULL; a fully masked row yields zeros.
+ */
+int soc_small_attn_f32(const float* q, const float* k, const float* v, const float* mask, float* out, int B, int L, int H, int D,
+                       float scale, long mask_batch_stride, long mask_query_stride, void* stream);
 
 /*
  * K21 -- Video-Swin patch embedding: the (1,4,4) / stride (1,4,4) convolution + LayerNorm(C) in one pass.  Replaces

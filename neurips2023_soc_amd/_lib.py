@@ -24,8 +24,8 @@ EXPORTS = ("soc_hip_abi_version", "soc_hip_error_string", "soc_msda_fwd_f32", "s
            "soc_win_attn3d_get_split", "soc_mlp_split_packed_bytes", "soc_mlp_split_pack_f32",
            "soc_mlp_split_workspace_bytes", "soc_mlp_split_plan", "soc_mlp_split_f32", "soc_mlp_split_variant_f32",
            "soc_xs_linear_packed_bytes", "soc_xs_linear_pack_f32", "soc_xs_linear_plan", "soc_xs_linear_f32",
-           "soc_set_reserved_cus", "soc_get_reserved_cus")
-ABI_VERSION = 14
+           "soc_set_reserved_cus", "soc_get_reserved_cus", "soc_small_attn_f32")
+ABI_VERSION = 15
 SOC_EUNSUPPORTED = -2      # include/soc_hip.h: shape outside what the kernel is built for
 
 _lib = None
@@ -154,6 +154,8 @@ def load() -> C.CDLL:
     lib.soc_row_stats_f32.argtypes = [p, p, C.c_long, i, f, p]
     lib.soc_linear_split_f32.restype = i
     lib.soc_linear_split_f32.argtypes = [p] * 10 + [i, C.c_long, i, i, i, i, p]
+    lib.soc_small_attn_f32.restype = i
+    lib.soc_small_attn_f32.argtypes = [p, p, p, p, p, i, i, i, i, f, C.c_long, C.c_long, p]
     lib.soc_set_reserved_cus.restype = None
     lib.soc_set_reserved_cus.argtypes = [i]
     lib.soc_get_reserved_cus.restype = i

@@ -1011,6 +1011,43 @@ def split_tile_for(M: int, N: int, K: int) -> int:
     return cfg
 
 
+def small_attention_supported(q: Tensor, n_heads: int, mask: Optional[Tensor]) -> bool:
+    """K25 takes softmax(q k^T * scale + mask) v of a [B, L, E] self-attention: CUDA fp32, L <= 64, head dim 32 / 64, mask None or
+    additive float [B, 1, 1 | L, L]."""
+    if not (q.is_cuda and q.dtype == torch.float32 and q.dim() == 3 and q.shape[-1] % n_heads == 0):
+        return False
+    B, L, E = q.shape
+    if L > 64 or E // n_heads not in (32, 64):
+        return False
+    return mask is None or (mask.dtype == torch.float32 and mask.dim() == 4 and mask.shape[0] in (1, B) and mask.shape[1] == 1
+                            and mask.shape[2] in (1, L) and mask.shape[3] == L)
+
+
+def small_attention(q: Tensor, k: Tensor, v: Tensor, n_heads: int, mask: Optional[Tensor] = None,
+                    scale: Optional[float] = None) -> Tensor:
+    """K25: multi-head self-attention core on token-major [B, L, E] tensors (heads = E / n_heads wide column blocks), additive
+    float mask [B | 1, 1, L | 1, L] or None -> [B, L, E].  Same result as F.scaled_dot_product_attention on the
+    [B, H, L, D] views."""
+    _need_gpu(q, k, v, mask)
+    lib = _lib.load()
+    q, k, v = _f32c(q), _f32c(k), _f32c(v)
+    B, L, E = q.shape
+    D = E // n_heads
+    out = torch.empty_like(q)
+    mb = mq = 0
+    mp = None
+    if mask is not None:
+        mask = _f32c(mask)
+        mp = mask.data_ptr()
+        mb = mask.stride(0) if mask.shape[0] > 1 else 0
+        mq = mask.stride(2) if mask.shape[2] > 1 else 0
+    with _timed("small_attn", 4.0 * B * n_heads * L * L * D):
+        rc = lib.soc_small_attn_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), mp, out.data_ptr(), B, L, n_heads, D,
+                                    float(scale) if scale is not None else D ** -0.5, mb, mq, _stream())
+    _lib.check(rc, "soc_small_attn_f32")
+    return out
+
+
 XS_LINEAR_K = (192, 256, 384, 768)      # input widths K24 is built for
 _XS_NCT = (18, 16, 12, 8, 6, 4)         # column tiles per range it is built for
 _xs_cache = DerivedCache()

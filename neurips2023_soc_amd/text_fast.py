@@ -85,10 +85,14 @@ def _layer_forward(self, hidden_states, attention_mask=None, *args, **kwargs):
     q, k, v = fused.linear_multi(hidden_states, [(att.query.weight, att.query.bias, False),
                                                  (att.key.weight, att.key.bias, False),
                                                  (att.value.weight, att.value.bias, False)])
-    q, k, v = (t.view(B, L, nh, E // nh).transpose(1, 2) for t in (q, k, v))
-    ctx = F.scaled_dot_product_attention(q, k, v, attn_mask=_additive_mask(attention_mask, q.dtype),
-                                         scale=getattr(att, "scaling", None))
-    ctx = ctx.transpose(1, 2).reshape(B, L, E)
+    amask = _additive_mask(attention_mask, q.dtype)
+    if hot_ops.small_attention_supported(q, nh, amask):
+        # K25: one workgroup per (batch, head) on the token-major projections (no transposes, no Triton-compiled kernel)
+        ctx = hot_ops.small_attention(q, k, v, nh, amask, getattr(att, "scaling", None))
+    else:
+        q, k, v = (t.view(B, L, nh, E // nh).transpose(1, 2) for t in (q, k, v))
+        ctx = F.scaled_dot_product_attention(q, k, v, attn_mask=amask, scale=getattr(att, "scaling", None))
+        ctx = ctx.transpose(1, 2).reshape(B, L, E)
     h = hot_ops.add_layernorm(hidden_states, fused.linear(ctx, att_out.dense.weight, att_out.dense.bias),
                               att_out.LayerNorm.weight, att_out.LayerNorm.bias, att_out.LayerNorm.eps, return_sum=False)[1]
     mid = hot_ops.linear_small(h, inter.dense.weight, inter.dense.bias, None, "gelu")

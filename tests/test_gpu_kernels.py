@@ -1383,3 +1383,33 @@ def test_mlp_split_residual_layernorm(ops, M, cut):
     assert e_k < 2e-5 and e_k <= 1.5 * e_lib + 1e-6, (e_k, e_lib)
     assert torch.equal(got, ops.mlp_split(x, w1, b1, w2, b2, "relu", ln=(g1, e1, 1e-5), residual=x, residual_ln=True,
                                            post_ln=(g2, e2, 1e-5), cut=cut))
+
+
+@pytest.mark.parametrize("B,L,H,D,mask_kind", [(1, 10, 12, 64, "none"), (2, 32, 12, 64, "keypad"), (3, 17, 8, 32, "full"),
+                                                (1, 64, 12, 64, "keypad"), (2, 7, 12, 64, "allmasked")])
+def test_small_attention_vs_sdpa(ops, B, L, H, D, mask_kind):
+    """K25 (the text encoder's self-attention core) against torch's scaled_dot_product_attention in f64 on the [B, H, L, D]
+    views: no mask, a key-padding mask broadcast over queries, a full [B, 1, L, L] additive mask, a fully masked row."""
+    g = torch.Generator().manual_seed(B * 100 + L)
+    E = H * D
+    q, k, v = (torch.randn(B, L, E, generator=g).cuda() for _ in range(3))
+    mask = None
+    if mask_kind in ("keypad", "allmasked"):
+        pad = torch.zeros(B, L, dtype=torch.bool)
+        pad[:, L - max(1, L // 4):] = True
+        if mask_kind == "allmasked":
+            pad[-1, :] = True
+        mask = torch.zeros(B, 1, 1, L).masked_fill_(pad[:, None, None, :], float("-inf")).cuda()
+    elif mask_kind == "full":
+        mask = (torch.randn(B, 1, L, L, generator=g) * 2).cuda()
+    assert ops.small_attention_supported(q, H, mask)
+    got = ops.small_attention(q, k, v, H, mask)
+    qd, kd, vd = (t.double().view(B, L, H, D).transpose(1, 2) for t in (q, k, v))
+    s = qd @ kd.transpose(-1, -2) * D ** -0.5
+    if mask is not None:
+        s = s + mask.double()
+    p = torch.softmax(s, -1)
+    p = torch.nan_to_num(p, nan=0.0)                        # fully masked rows: zeros (SDPA gives NaN there; HF never reads them)
+    want = (p @ vd).transpose(1, 2).reshape(B, L, E)
+    assert float((got.double() - want).abs().max()) < 2e-6 * max(1.0, float(want.abs().max()))
+    assert torch.equal(got, ops.small_attention(q, k, v, H, mask))

@@ -200,7 +200,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     assert declared == set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.soc_hip_abi_version() == _lib.ABI_VERSION == 14
+    assert lib.soc_hip_abi_version() == _lib.ABI_VERSION == 15
     assert lib.soc_xattn_workspace_bytes(240, 10, 1, 8, 32) == 0
     assert lib.soc_xattn_workspace_bytes(10, 1920, 1, 8, 32) == 0
 
