@@ -124,7 +124,11 @@ class PipelinedClipGraph:
             self.sb = [self._clone(sb), self._clone(sb)]
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
-        self._pc = torch.cuda.Stream(device=dev)
+        # The tail branch is captured from a HIGH-priority stream: its short launches are taken first whenever a CU frees up
+        # beside the head's chip-filling kernels (measured on one box, alternating: 6.31 -> 6.24 ms per clip;
+        # SOC_TAIL_PRIORITY=0 restores the default-priority branch)
+        import os
+        self._pc = torch.cuda.Stream(device=dev, priority=0 if os.environ.get("SOC_TAIL_PRIORITY", "1") == "0" else -1)
 
         def capture(body):
             g = torch.cuda.CUDAGraph()

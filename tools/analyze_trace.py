@@ -19,7 +19,7 @@ def cat(n):
                             "upsample_threshold", "upsample_merge", "upsample_add_nchw", "resize_", "gemm_nt_kernel", "gn_stats", "gn_apply",
                             "patch_merge", "ws_linear", "dec_cross_attn", "row_mlp", "groupnorm_nchw", "conv3x3_tokens",
                             "linear_split_kernel", "row_stats_kernel", "patch_embed", "split_pack_kernel", 
-                            "mlp_split_kernel", "mlp_reduce_kernel", "mlp_pack_kernel", "xs_linear_kernel", "xs_pack_kernel")):
+                            "mlp_split_kernel", "mlp_reduce_kernel", "mlp_pack_kernel", "xs_linear_kernel", "xs_pack_kernel", "small_attn_kernel")):
         return "soc_hip kernels"
     if n.startswith("Cijk"):
         return "GEMM (hipBLASLt/rocBLAS)"
