@@ -57,6 +57,10 @@ def time_ms(g):
 with torch.no_grad():
     g_b, sa = capture(backbone)
     print(f"backbone (text || Video-Swin)      {time_ms(g_b):7.3f} ms")
+    g_v, _ = capture(lambda: model.backbone(NestedTensor(clip.clone(), pad.clone(), unpadded=True)))
+    print(f"  Video-Swin alone                 {time_ms(g_v):7.3f} ms")
+    g_x, _ = capture(lambda: model.forward_text({"input_ids": ids, "attention_mask": attn}, ids.device))
+    print(f"  text encoder alone               {time_ms(g_x):7.3f} ms")
     g_f, sb = capture(lambda: model.forward_fuse_encode(sa))
     print(f"fusion + deformable encoder        {time_ms(g_f):7.3f} ms")
     g_h, _ = capture(lambda: model.forward_fuse_encode(backbone()))
