@@ -454,6 +454,26 @@ def main():
             t_c = sum(sh["launches"] * max(sh["flop"] / mf, sh["bytes"] / (HBM_ACHIEVABLE_GBS * 1e9)) for sh in shapes)
             return t_c, t_m, t_h, mf / 1e12
 
+        def vector_share(fam):
+            """VALU cycles per matrix-pipe cycle of the family's kernels, from the committed rocprofv3 counter passes
+            (SQ_INSTS_VALU x 2 clk / (SQ_INSTS_MFMA x 16.7 clk); v_exp and packed forms counted as one instruction).  On a
+            gfx950 SIMD the two do not overlap (tools/microbench/mfma_valu_roles.hip), so 1 / (1 + share) bounds the kernel
+            below the 417 TFLOP/s ceiling before any LDS / barrier stall."""
+            src = {"win_attn3d": ("r03_k1_pmc.json", lambda d: d["counters"]["k1_stage0_split"]),
+                   "mlp_split": ("r04_k23enc_counters.json", lambda d: d["k23enc"])}.get(fam)
+            if src is None:
+                return None
+            try:
+                with open(os.path.join(ROOT, "profiles", src[0])) as fh:
+                    c = src[1](json.load(fh))
+                return {"valu_cycles_per_mfma_cycle": round(2.0 * c["SQ_INSTS_VALU"]["mean_per_launch"]
+                                                            / (16.7 * c["SQ_INSTS_MFMA"]["mean_per_launch"]), 3),
+                        "source": "profiles/" + src[0],
+                        "note": "matrix-pipe and vector-ALU time add on a gfx950 SIMD (DESIGN.md section 3, "
+                                "tools/microbench/mfma_valu_roles.hip): 1 / (1 + this) bounds frac_of_ceiling"}
+            except (OSError, KeyError, ValueError):
+                return None
+
         blocks = {}
         for fam, f in families.items():
             flop = sum(sh["launches"] * sh["flop"] for sh in f["shapes"])
@@ -479,6 +499,7 @@ def main():
                               "the f32-input MFMA peak, 157.3 TFLOP/s"),
                 "ceiling_ms_per_clip": 1e3 * t_c, "mfma_ms_at_peak": 1e3 * t_m, "hbm_ms_at_6_3_TBs": 1e3 * t_h,
                 "vs_f32_mfma_peak": flop / sec / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                "vector_share": vector_share(fam) if split_on[fam] else None,
                 "algorithmic_tflops": flop / sec / 1e12, "algorithmic_gbs": byts / sec / 1e9,
                 "traffic": traffic.get(fam) if default_cfg else None,
                 "traffic_unit": f"HBM bytes per clip ({f['launches']} launches), rocprofv3 PMC, {traffic_file}",
