@@ -25,7 +25,8 @@
 // Every row is taken: a workgroup owns a balanced contiguous share of the row tiles and deals the tiles of a part-filled pass
 // round-robin over its waves (one per SIMD first); for few rows the hidden dimension is split over `nfs` workgroup columns
 // that write partial sums, which a reduce kernel adds in a fixed order (deterministic) together with b2 / residual / LN2.
-// C <= 256: eight 256-register waves (two per SIMD); C = 384: four 512-register waves, blocks travel as half-block pieces.
+// C <= 256: eight 256-register waves (two per SIMD); C = 384 / 512 (Swin-B stage 2): four 512-register waves, blocks travel as
+// half-block pieces.
 // Measured null and kept as diagnostic variants only (SOC_K23_VARIANTS): waves 4..7 one piece behind waves 0..3, the
 // activation at raised wave priority, deeper fragment prefetch, four-wave forms for C <= 256 (tools/experiments/README.md).
 // Co-residence rule: the whole register file is claimed, waves retire behind a barrier, packed f32 code
@@ -627,7 +628,7 @@ int launch_c(const Args& a, int act, int variant) {
     return SOC_EUNSUPPORTED;
 }
 
-bool width_ok(int C) { return C == 96 || C == 128 || C == 192 || C == 256 || C == 384; }
+bool width_ok(int C) { return C == 96 || C == 128 || C == 192 || C == 256 || C == 384 || C == 512; }
 
 template <int C> size_t packed_bytes(int F) { return (size_t)(F / 32) * 2 * Geo<C>::BLKP_U4 * 16; }
 
@@ -640,7 +641,8 @@ extern "C" size_t soc_mlp_split_packed_bytes(int C, int F) {
         case 128: return packed_bytes<128>(F);
         case 192: return packed_bytes<192>(F);
         case 256: return packed_bytes<256>(F);
-        default: return packed_bytes<384>(F);
+        case 384: return packed_bytes<384>(F);
+        default: return packed_bytes<512>(F);
     }
 }
 
@@ -656,7 +658,8 @@ extern "C" int soc_mlp_split_pack_f32(const float* w1, const float* w2, void* pa
         case 128: hipLaunchKernelGGL(mlp_pack_kernel<128>, dim3(blocks), dim3(256), 0, st, w1, w2, img, F); break;
         case 192: hipLaunchKernelGGL(mlp_pack_kernel<192>, dim3(blocks), dim3(256), 0, st, w1, w2, img, F); break;
         case 256: hipLaunchKernelGGL(mlp_pack_kernel<256>, dim3(blocks), dim3(256), 0, st, w1, w2, img, F); break;
-        default: hipLaunchKernelGGL(mlp_pack_kernel<384>, dim3(blocks), dim3(256), 0, st, w1, w2, img, F); break;
+        case 384: hipLaunchKernelGGL(mlp_pack_kernel<384>, dim3(blocks), dim3(256), 0, st, w1, w2, img, F); break;
+        default: hipLaunchKernelGGL(mlp_pack_kernel<512>, dim3(blocks), dim3(256), 0, st, w1, w2, img, F); break;
     }
     return soc_check_launch();
 }
@@ -730,7 +733,8 @@ extern "C" int soc_mlp_split_variant_f32(const float* x, const void* packed, con
         case 128: rc = launch_c<128>(a, act, variant); break;
         case 192: rc = launch_c<192>(a, act, variant); break;
         case 256: rc = launch_c<256>(a, act, variant); break;
-        default: rc = launch_c<384>(a, act, variant); break;
+        case 384: rc = launch_c<384>(a, act, variant); break;
+        default: rc = launch_c<512>(a, act, variant); break;
     }
     if (rc != SOC_OK || nfs == 1) return rc;
     const int blocks = (int)((M + 3) / 4 > 8192 ? 8192 : (M + 3) / 4);

@@ -3,7 +3,7 @@
 //
 //   out[M, N] = act(LN(x)[M, K] . W[N, K]^T + b) + residual                                          (f32 in, f32 out)
 //
-// Replaces the pixel-sized nn.Linear calls of widths K = 192 / 256 / 384 / 768 that K13b (weights stationary in LDS, rows
+// Replaces the pixel-sized nn.Linear calls of widths K = 192 / 256 / 384 / 512 / 768 / 1024 that K13b (weights stationary in LDS, rows
 // streamed and split again for every column range) ran at 0.3 of their ceiling: Video-Swin qkv / proj of stages 1-3 (reference
 // models/video_swin_transformer.py:144-166, with norm1 :219 in front and the shortcut :254-259 behind), the patch-merging
 // reduction into stage 2 (:277-312), the deformable encoder's value_proj / output_proj (models/ops/modules/ms_deform_attn.py:
@@ -15,294 +15,16 @@
 // [16 columns x 16 rows] accumulate in registers for the whole range (NCT tiles) and leave once, behind bias / activation /
 // residual, as 16-B stores.  A launch is cut into `nrg` workgroup rows x `ncr` column ranges (no partial sums: a range owns
 // its columns), so that short inputs still fill the chip; blocks b and b + 8 share an XCD, which then streams one range.
-// K <= 384: eight 256-register waves; K = 768: four 512-register waves, a column tile travels as two half-K pieces.
+// K <= 384: eight 256-register waves; K = 512 / 768 / 1024 (xs_linear_split_wide.hip): four 512-register waves, a column tile
+// travels as two (four at K = 1024) partial-K pieces.
 // Co-residence rule as K23: whole register file, final barrier, VGPR operands in packed f32 code.
-#include "soc_common.h"
-#include "split_math.h"
-#include <atomic>
-#include <type_traits>
+#include "xs_linear_split.h"
 
 namespace {
 
-using namespace soc_split;
-constexpr int MAX_THREADS = 512;
-
-template <int K>
-struct Geo {
-    static constexpr int KS = K / 32;                                   // k-steps of 32
-    static constexpr int NW = K > 384 ? 4 : 8;                          // waves per workgroup
-    static constexpr int SB = K > 384 ? 2 : 1;                          // ring pieces per column tile (K split)
-    static constexpr int CTP = K <= 256 ? 2 : 1;                        // column tiles per ring piece
-    static constexpr int GROUPS = CTP * KS / SB;                        // fragment groups (16 columns x 32 k, three planes) per piece
-    static constexpr int PIECE_U4 = (GROUPS * 3 * 64 + MAX_THREADS - 1) / MAX_THREADS * MAX_THREADS;   // whole DMA rounds
-    static constexpr int NSLOT = (160 * 1024 - 8 * K - 2048) / (PIECE_U4 * 16) >= 4 ? 4 : 3;
-    static_assert(KS % SB == 0 && (160 * 1024 - 8 * K - 2048) / (PIECE_U4 * 16) >= 3, "three ring slots at least");
-};
-
-template <int N_>
-__device__ __forceinline__ void handoff() {        // my part of the next piece has landed; everyone is done with this one
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N_) : "memory");
-}
-
-// NCT column tiles per range (compile time: the accumulators are registers)
-template <int K, int ACT, bool HAS_LN, int NCT>
-__global__ __launch_bounds__(Geo<K>::NW * 64, Geo<K>::NW / 4) void xs_linear_kernel(
-    const float* __restrict__ x, const u32x4* __restrict__ img, const float* __restrict__ bias,
-    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, const float* __restrict__ res,
-    float* __restrict__ out, long M, int N, int nrg, int ncr) {
-    using G = Geo<K>;
-    constexpr int NW = G::NW, THREADS = NW * 64, KS = G::KS, SB = G::SB, CTP = G::CTP, NSLOT = G::NSLOT;
-    constexpr int SLOT = G::PIECE_U4, P = SLOT / THREADS, D = NSLOT - 1, NQ = NCT * SB / CTP, KSP = KS / SB;
-    static_assert(NCT % CTP == 0 && (D - 1) * P < 64, "whole pieces");
-    extern __shared__ __attribute__((aligned(16))) u32x4 lds[];
-    u32x4* slots = lds;
-    float* gs = reinterpret_cast<float*>(lds + NSLOT * SLOT);           // gamma [K], beta [K]
-    float* bs = gs + K;
-    asm volatile("v_mov_b32 v255, 0" ::: "v255");                       // own the CU
-    if (NW == 4) asm volatile("v_accvgpr_write_b32 a255, 0" ::: "a255");
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 15, kq = lane >> 4;
-    const int cr = blockIdx.x % ncr, g = blockIdx.x / ncr;
-    const int n0 = cr * NCT * 16;                                       // first column of this range
-    const long ntiles = (M + 15) >> 4;
-    const long t0 = (long)g * ntiles / nrg, t1 = (long)(g + 1) * ntiles / nrg;
-    if (HAS_LN)
-        for (int i = tid; i < K; i += THREADS) { gs[i] = gamma[i]; bs[i] = beta[i]; }
-    // LDS-DMA from inline assembly, as K23 (mlp_split.hip): the compiler must not see an LDS-DMA in flight
-    const char* ibase = reinterpret_cast<const char*>(img + (long)cr * NQ * SLOT);
-    const unsigned voff = (unsigned)tid * 16u;
-    const unsigned lds_slots = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)slots + (unsigned)wave * 1024u;
-    auto dma = [&](int piece, int slot) {
-        const char* src = ibase + (long)piece * (SLOT * 16);
-        const unsigned dst = lds_slots + (unsigned)slot * (SLOT * 16);
-#pragma unroll
-        for (int u = 0; u < P; ++u)
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
-                         ::"s"(dst + u * (THREADS * 16)), "v"(voff), "s"(src + u * (THREADS * 16)) : "memory");
-    };
-    __syncthreads();
-    auto pass = [&](auto act_c, long pt) {
-        constexpr bool ACTIVE = decltype(act_c)::value;                 // this wave has a row tile in the pass
-        bf16x8 xb[KS][3];
-        {
-            float4 xn[KS][2];
-            const long m = min((pt + wave) * 16 + r, M - 1);
-            const float4* xp = reinterpret_cast<const float4*>(x + m * K + 8 * kq);
-            if (ACTIVE) {
-#pragma unroll
-                for (int s = 0; s < KS; ++s) { xn[s][0] = xp[8 * s]; xn[s][1] = xp[8 * s + 1]; }
-            }
-#pragma unroll
-            for (int b = 0; b < D; ++b)
-                if (b < NQ) dma(b, b);
-            if (ACTIVE) {
-                float v[KS][8];
-#pragma unroll
-                for (int s = 0; s < KS; ++s) {
-                    v[s][0] = xn[s][0].x; v[s][1] = xn[s][0].y; v[s][2] = xn[s][0].z; v[s][3] = xn[s][0].w;
-                    v[s][4] = xn[s][1].x; v[s][5] = xn[s][1].y; v[s][6] = xn[s][1].z; v[s][7] = xn[s][1].w;
-                }
-                if (HAS_LN) {   // as nn.LayerNorm: two-pass mean / variance over the row, which lives in lanes (r, kq = 0..3)
-                    const float inv_k = in_vgpr(1.0f / K), eps_v = in_vgpr(eps);
-                    float sm = 0.f;
-#pragma unroll
-                    for (int s = 0; s < KS; ++s)
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) sm += v[s][i];
-                    sm += __shfl_xor(sm, 16);
-                    sm += __shfl_xor(sm, 32);
-                    const float mean = sm * inv_k;
-                    float q = 0.f;
-#pragma unroll
-                    for (int s = 0; s < KS; ++s)
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) { v[s][i] -= mean; q = fmaf(v[s][i], v[s][i], q); }
-                    q += __shfl_xor(q, 16);
-                    q += __shfl_xor(q, 32);
-                    const float rstd = rsqrtf(fmaf(q, inv_k, eps_v));
-#pragma unroll
-                    for (int s = 0; s < KS; ++s) {
-                        const float4* gp = reinterpret_cast<const float4*>(gs + 32 * s + 8 * kq);
-                        const float4* ep = reinterpret_cast<const float4*>(bs + 32 * s + 8 * kq);
-                        const float4 ga = gp[0], gb = gp[1], ea = ep[0], eb = ep[1];
-                        const float gg[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
-                        const float bb[8] = {ea.x, ea.y, ea.z, ea.w, eb.x, eb.y, eb.z, eb.w};
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) v[s][i] = fmaf(v[s][i] * rstd, gg[i], bb[i]);
-                    }
-                }
-#pragma unroll
-                for (int s = 0; s < KS; ++s) split8(v[s], xb[s][0], xb[s][1], xb[s][2]);
-            }
-        }
-        f32x4 acc[NCT];
-#pragma unroll
-        for (int j = 0; j < NCT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (NQ >= D) handoff<(D - 1) * P>(); else handoff<0>();         // piece 0 has landed
-        // ---- the ring: piece q = column tiles [CTP (q / SB), + CTP) x k-steps [KSP (q % SB), + KSP); fully unrolled (the
-        // accumulators are registers), fragment groups read one ahead of the MFMAs that consume them
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            constexpr int dummy = 0; (void)dummy;
-            if (q + D < NQ) dma(q + D, (q + D) % NSLOT);
-            if (ACTIVE) {
-                const u32x4* wl = slots + (q % NSLOT) * SLOT + lane;
-                constexpr int NGP = CTP * KSP;                          // fragment groups of the piece, column tile major
-                bf16x8 wf[2][3];
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) wf[0][pl] = __builtin_bit_cast(bf16x8, wl[pl * 64]);
-#pragma unroll
-                for (int gi = 0; gi < NGP; ++gi) {
-                    if (gi + 1 < NGP) {
-#pragma unroll
-                        for (int pl = 0; pl < 3; ++pl)
-                            wf[(gi + 1) & 1][pl] = __builtin_bit_cast(bf16x8, wl[((gi + 1) * 3 + pl) * 64]);
-                    }
-                    const int j = CTP * (q / SB) + gi / KSP, s = KSP * (q % SB) + gi % KSP;
-                    mfma6(acc[j], wf[gi & 1], xb[s][0], xb[s][1], xb[s][2]);
-                    if (gi + 1 < NGP) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            if (q + 1 < NQ) {
-                if (q + D < NQ) handoff<(D - 1) * P>(); else handoff<0>();
-            }
-        }
-        // ---- lane (r, kq) holds out[m][n0 + 16 j + 4 kq .. + 3]: bias, activation, residual, 16-B stores
-        const long m = (pt + wave) * 16 + r;
-        if (ACTIVE && m < M) {
-            long mo = m * N + n0 + 4 * kq;
-            asm volatile("" : "+v"(mo));
-            f32x4 bq[NCT];
-#pragma unroll
-            for (int j = 0; j < NCT; ++j)
-                bq[j] = bias ? *reinterpret_cast<const f32x4*>(bias + n0 + 16 * j + 4 * kq) : (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int j = 0; j < NCT; ++j) acc[j] += bq[j];
-            if (ACT == 1) {
-#pragma unroll
-                for (int j = 0; j < NCT; ++j)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[j][i] = fmaxf(acc[j][i], 0.f);
-            } else if (ACT == 2) {
-                const GeluK gk = gelu_k();
-#pragma unroll
-                for (int j = 0; j < NCT; ++j)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[j][i] = gelu_erf(acc[j][i], gk);
-            }
-            if (res) {
-                f32x4 rr[NCT];
-#pragma unroll
-                for (int j = 0; j < NCT; ++j) rr[j] = *reinterpret_cast<const f32x4*>(res + mo + 16 * j);
-#pragma unroll
-                for (int j = 0; j < NCT; ++j) acc[j] += rr[j];
-            }
-#pragma unroll
-            for (int j = 0; j < NCT; ++j) *reinterpret_cast<f32x4*>(out + mo + 16 * j) = acc[j];
-        }
-    };
-    for (long pt = t0; pt < t1; pt += NW) {
-        if (pt != t0) handoff<0>();                 // nobody still reads the slots the next pass's prologue refills
-        if (pt + wave < t1) pass(std::true_type{}, pt);
-        else pass(std::false_type{}, pt);
-    }
-    __syncthreads();        // the waves retire together
-}
-
-// item = (piece, group, lane): one 16-B piece per plane = 8 weights split three ways.  Image: [N / 16 / CTP x SB pieces][PIECE_U4]
-template <int K>
-__global__ __launch_bounds__(256) void xs_pack_kernel(const float* __restrict__ w, u32x4* __restrict__ img, int N) {
-    using G = Geo<K>;
-    constexpr int KSP = G::KS / G::SB, NGP = G::GROUPS;
-    const long npieces = (long)(N / 16 / G::CTP) * G::SB;
-    const long total = npieces * NGP * 64;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int lane = (int)(idx & 63);
-        long rest = idx >> 6;
-        const int gi = (int)(rest % NGP);
-        const long q = rest / NGP;
-        const int j = G::CTP * (int)(q / G::SB) + gi / KSP, s = KSP * (int)(q % G::SB) + gi % KSP;
-        const int n = lane & 15, kq = lane >> 4;
-        const float* src = w + (long)(16 * j + n) * K + 32 * s + 8 * kq;
-        float v[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = src[i];
-        bf16x8 h0, h1, h2;
-        split8(v, h0, h1, h2);
-        u32x4* dst = img + q * G::PIECE_U4 + (gi * 3) * 64 + lane;
-        dst[0] = __builtin_bit_cast(u32x4, h0);
-        dst[64] = __builtin_bit_cast(u32x4, h1);
-        dst[128] = __builtin_bit_cast(u32x4, h2);
-    }
-}
-
-int num_cus() { return soc_num_cus(); }      // device CUs minus the host's reserve (soc_capi.hip)
-
-struct Args {
-    const float *x, *bias, *gamma, *beta, *res;
-    const u32x4* img;
-    float eps;
-    float* out;
-    long M;
-    int N, nrg, ncr;
-    hipStream_t st;
-};
-
-template <int K, int ACT, bool HAS_LN, int NCT>
-int launch(const Args& a) {
-    using G = Geo<K>;
-    const void* fn = reinterpret_cast<const void*>(xs_linear_kernel<K, ACT, HAS_LN, NCT>);
-    const size_t lds = (size_t)G::NSLOT * G::PIECE_U4 * 16 + 8 * K;
-    static std::atomic<bool> attr_set[SOC_MAX_DEVICES];
-    const int dev = soc_current_device();
-    if (dev < 0) return SOC_ELAUNCH;
-    if (!attr_set[dev].load(std::memory_order_acquire)) {
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return SOC_ELAUNCH;
-        attr_set[dev].store(true, std::memory_order_release);
-    }
-    hipLaunchKernelGGL((xs_linear_kernel<K, ACT, HAS_LN, NCT>), dim3((unsigned)(a.nrg * a.ncr)), dim3(G::NW * 64), lds, a.st,
-                       a.x, a.img, a.bias, a.gamma, a.beta, a.eps, a.res, a.out, a.M, a.N, a.nrg, a.ncr);
-    return soc_check_launch();
-}
-
-// column tiles per range the kernels are built for (the accumulators are registers: 4 per tile; K = 384 has room for 18,
-// K = 768 in 512 registers likewise)
-constexpr int NCTS[] = {18, 16, 12, 8, 6, 4};
-
-template <int K, int ACT, bool HAS_LN>
-int launch_nct(const Args& a, int nct) {
-    switch (nct) {
-        case 18: return launch<K, ACT, HAS_LN, 18>(a);
-        case 16: return launch<K, ACT, HAS_LN, 16>(a);
-        case 12: return launch<K, ACT, HAS_LN, 12>(a);
-        case 8: return launch<K, ACT, HAS_LN, 8>(a);
-        case 6: return launch<K, ACT, HAS_LN, 6>(a);
-        case 4: return launch<K, ACT, HAS_LN, 4>(a);
-        default: return SOC_EUNSUPPORTED;
-    }
-}
-
-template <int K>
-int launch_k(const Args& a, int act, int nct) {
-    if (a.gamma) {
-        if (act == 0) return launch_nct<K, 0, true>(a, nct);
-        if (act == 2) return launch_nct<K, 2, true>(a, nct);
-        return SOC_EUNSUPPORTED;
-    }
-    if (act == 0) return launch_nct<K, 0, false>(a, nct);
-    if (act == 1) return launch_nct<K, 1, false>(a, nct);
-    if (act == 2) return launch_nct<K, 2, false>(a, nct);
-    return SOC_EUNSUPPORTED;
-}
-
-bool width_ok(int K) { return K == 192 || K == 256 || K == 384 || K == 768; }
+bool width_ok(int K) { return K == 192 || K == 256 || K == 384 || K == 512 || K == 768 || K == 1024; }
 int waves_of(int K) { return K > 384 ? 4 : 8; }
 int ctp_of(int K) { return K <= 256 ? 2 : 1; }
-
-template <int K> size_t packed_bytes(int N) { return (size_t)(N / 16 / Geo<K>::CTP) * Geo<K>::SB * Geo<K>::PIECE_U4 * 16; }
 
 // The cut of M rows x N columns: nrg workgroup rows (NW row tiles per pass each) x ncr column ranges of one of the built
 // widths.  Cost model (tools/experiments/k24_time.py): a workgroup pass costs a fixed part (row loads, LayerNorm, split, ring
@@ -315,7 +37,7 @@ bool plan(long M, int N, int K, int cus, int* nrg_out, int* ncr_out, int* nct_ou
     int best_nct = 0;
     long best_cost = 0, best_nrg = 0;
     for (int nct : NCTS) {
-        if (nct_all % nct != 0 || nct % ctp_of(K) != 0) continue;
+        if (nct_all % nct != 0 || nct % ctp_of(K) != 0 || nct > max_nct(K)) continue;
         const long ncr = nct_all / nct;
         long nrg = cus / ncr > 0 ? cus / ncr : 1;
         if (nrg > groups) nrg = groups;
@@ -340,7 +62,7 @@ extern "C" size_t soc_xs_linear_packed_bytes(int N, int K) {
         case 192: return packed_bytes<192>(N);
         case 256: return packed_bytes<256>(N);
         case 384: return packed_bytes<384>(N);
-        default: return packed_bytes<768>(N);
+        default: return soc_xs::packed_bytes_wide(K, N);
     }
 }
 
@@ -355,7 +77,7 @@ extern "C" int soc_xs_linear_pack_f32(const float* w, void* packed, int N, int K
         case 192: hipLaunchKernelGGL(xs_pack_kernel<192>, dim3(blocks), dim3(256), 0, st, w, img, N); break;
         case 256: hipLaunchKernelGGL(xs_pack_kernel<256>, dim3(blocks), dim3(256), 0, st, w, img, N); break;
         case 384: hipLaunchKernelGGL(xs_pack_kernel<384>, dim3(blocks), dim3(256), 0, st, w, img, N); break;
-        default: hipLaunchKernelGGL(xs_pack_kernel<768>, dim3(blocks), dim3(256), 0, st, w, img, N); break;
+        default: soc_xs::pack_wide(K, w, packed, N, blocks, st); break;
     }
     return soc_check_launch();
 }
@@ -383,12 +105,13 @@ extern "C" int soc_xs_linear_f32(const float* x, const void* packed, const float
         nct = N / 16 / ncr;
     }
     if (nrg > (M + 15) / 16 || nct % ctp_of(K) != 0) return SOC_EINVAL;
+    if (nct > max_nct(K)) return SOC_EUNSUPPORTED;
     Args a{x, bias, ln_gamma, ln_beta, residual, reinterpret_cast<const u32x4*>(packed), ln_eps, out, M, N, nrg, ncr,
            (hipStream_t)stream};
     switch (K) {
         case 192: return launch_k<192>(a, act, nct);
         case 256: return launch_k<256>(a, act, nct);
         case 384: return launch_k<384>(a, act, nct);
-        default: return launch_k<768>(a, act, nct);
+        default: return soc_xs::launch_wide(K, a, act, nct);
     }
 }

@@ -34,7 +34,7 @@ def ffn_relu(x: torch.Tensor, lin1: nn.Linear, lin2: nn.Linear) -> torch.Tensor:
 
 def mlp_ok(x: torch.Tensor, lin1: nn.Linear, lin2: nn.Linear) -> bool:
     """K23 takes the whole two-layer block lin2(act(lin1(LN(x)))) (+ residual, + LayerNorm behind it): pixel-sized inputs of
-    width 96 / 128 / 192 / 256 (Video-Swin stages 0-1, the deformable encoder's feed-forward block)."""
+    width 96 / 128 / 192 / 256 / 384 / 512 (Video-Swin stages 0-2, the deformable encoder's feed-forward block)."""
     return (lin1.bias is not None and lin2.bias is not None and x.numel() // x.shape[-1] >= 4096
             and hot_ops.mlp_split_supported(x, lin1.weight, lin2.weight))
 
@@ -65,12 +65,12 @@ def _split_ok(x: torch.Tensor, weight: torch.Tensor, fused_passes: int, site: st
 
 def xs_ok(x, weight) -> bool:
     """K24 (x split once per row tile, weights streamed) where it measured faster than K13b / K20 / the library
-    (tools/experiments/k24_time.py): input widths 384 and 768 on pixel-sized inputs (Video-Swin stage 2 / 3 qkv, proj, fc1, the
+    (tools/experiments/k24_time.py): input widths 384 / 768 (512 / 1024 for Swin-B) on pixel-sized inputs (Video-Swin stage 2 / 3 qkv, proj, fc1, the
     patch-merging reduction into stage 2), and width 256 up to one pass of the chip (the fusion blocks' query projection; the
     encoder's 38 560-row projections stay on K13b)."""
     K = x.shape[-1]
     rows = x.numel() // K
-    return (rows * weight.shape[0] >= 2_000_000 and (K in (384, 768) or (K == 256 and 16384 <= rows <= 32768))
+    return (rows * weight.shape[0] >= 2_000_000 and (K in (384, 512, 768, 1024) or (K == 256 and 16384 <= rows <= 32768))
             and hot_ops.xs_linear_supported(x, weight))       # (narrow outputs on few rows: the library's small tiles win)
 
 

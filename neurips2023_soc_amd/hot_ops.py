@@ -1048,7 +1048,7 @@ def small_attention(q: Tensor, k: Tensor, v: Tensor, n_heads: int, mask: Optiona
     return out
 
 
-XS_LINEAR_K = (192, 256, 384, 768)      # input widths K24 is built for
+XS_LINEAR_K = (192, 256, 384, 512, 768, 1024)      # input widths K24 is built for
 _XS_NCT = (18, 16, 12, 8, 6, 4)         # column tiles per range it is built for
 _xs_cache = DerivedCache()
 _k24_calls = None  # bench.py: when a list, xs_linear appends its arguments
@@ -1065,13 +1065,14 @@ def record_xs_linear_calls(on: bool):
 
 
 def xs_linear_supported(x, weight) -> bool:
-    """K24 takes act(LN(x) weight^T + bias) + residual: CUDA fp32, input width 192 / 256 / 384 / 768, an output width whose 16-
+    """K24 takes act(LN(x) weight^T + bias) + residual: CUDA fp32, input width 192 / 256 / 384 / 512 / 768 / 1024, an output width whose 16-
     column tiles divide into ranges of a built size, split arithmetic on (SOC_SPLIT_OFF=k24 switches it off)."""
     N, K = weight.shape
     ctp = 2 if K <= 256 else 1
+    top = 8 if K > 768 else 18              # K = 1024 keeps 384 registers of x fragments: ranges of at most 8 column tiles
     return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and split_enabled()
             and "k24" not in _SPLIT_OFF and x.shape[-1] == K and K in XS_LINEAR_K and N % 32 == 0
-            and any((N // 16) % n == 0 and n % ctp == 0 for n in _XS_NCT))
+            and any((N // 16) % n == 0 and n % ctp == 0 and n <= top for n in _XS_NCT))
 
 
 def _xs_packed(weight: Tensor) -> Tensor:
@@ -1125,13 +1126,13 @@ def xs_linear_plan(M: int, N: int, K: int) -> Tuple[int, int, int]:
     return a.value, b.value, c.value
 
 
-MLP_SPLIT_C = (96, 128, 192, 256, 384)  # model widths K23 is built for
+MLP_SPLIT_C = (96, 128, 192, 256, 384, 512)  # model widths K23 is built for
 _MLP_ACT = {"relu": 1, "gelu": 2}
 _mlp_cache = DerivedCache()
 
 
 def mlp_split_supported(x: Tensor, w1: Tensor, w2: Tensor) -> bool:
-    """K23 takes act(LN(x) w1^T + b1) w2^T + b2 (+ residual): CUDA fp32, model width 96 / 128 / 192 / 256 / 384, hidden width a
+    """K23 takes act(LN(x) w1^T + b1) w2^T + b2 (+ residual): CUDA fp32, model width 96 / 128 / 192 / 256 / 384 / 512, hidden width a
     multiple of 32, split arithmetic on (SOC_SPLIT_OFF=mlp switches it off)."""
     Cw = x.shape[-1]
     return (x.is_cuda and x.dtype == torch.float32 and split_enabled() and "mlp" not in _SPLIT_OFF and Cw in MLP_SPLIT_C

@@ -188,9 +188,9 @@ class BasicLayer(nn.Module):
         "k20" every layer on K20, LayerNorm folded into the packed weights (tall stages wider than that: Swin-B stage 1, and
               stage 1 of the others with SOC_SPLIT_OFF=k13);
         "k23" one LayerNorm pass at the stage's entry, then per block qkv | K1 | proj + shortcut | K23 (norm2 + MLP + shortcut +
-              norm1 of the next block): stage 2 of Swin-T / -S (C = 384);
+              norm1 of the next block): stage 2 of Swin-T / -S (C = 384) and of Swin-B (C = 512);
         "k24" norm1 + qkv | K1 | proj + shortcut | norm2 + fc1 + GELU as K24 launches (LayerNorm in their prologues), fc2 + shortcut
-              through fused.linear: stage 3 of Swin-T / -S (C = 768; the hidden width 3072 is beyond K24);
+              through fused.linear: stage 3 (C = 768, Swin-B 1024; the hidden width 4 C is beyond K24);
         "k5"  every shortcut add fused with the LayerNorm that consumes it (K5), GEMMs per fused.route_*: the rest."""
         blk = self.blocks[0]
         # stage 1 (C = 192) in the split arithmetic: K13b beats K20 on qkv / proj / fc1 (49 / 24 / 71 against 60 / 30 / 74 us,
@@ -202,7 +202,7 @@ class BasicLayer(nn.Module):
             return "ws"
         if fused.mlp_ok(x, blk.mlp.fc1, blk.mlp.fc2):
             return "k23"
-        if (x.shape[-1] == 768 and x.numel() // 768 >= 1024
+        if (x.shape[-1] in (768, 1024) and x.numel() // x.shape[-1] >= 1024
                 and all(hot_ops.xs_linear_supported(x, w) for w in (blk.attn.qkv.weight, blk.attn.proj.weight, blk.mlp.fc1.weight))):
             return "k24"
         return "k5"

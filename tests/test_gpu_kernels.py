@@ -1244,6 +1244,8 @@ def _mlp_f32(x, w1, b1, w2, b2, act, lnp):
     (38560, 256, 2048, "relu", False),      # the deformable encoder's feed-forward block: whole round + tail over 4 hidden ranges
     (7360, 384, 1536, "gelu", True),        # stage 2: four waves of 512 registers, two hidden ranges, half-block ring pieces
     (29440, 384, 1536, "gelu", True),       # ... at 720p
+    (7360, 512, 2048, "gelu", True),        # Swin-B stage 2: 98-KB weight blocks, three half-block ring slots
+    (1000, 512, 2048, "relu", False),
     (4099, 256, 2048, "relu", False), (17, 256, 2048, "relu", False), (1000, 192, 768, "gelu", True), (33, 96, 384, "relu", True),
     (5000, 96, 64, "gelu", False)])
 def test_mlp_split_vs_f64(ops, M, Cw, F, act, ln):
@@ -1327,6 +1329,14 @@ def test_mlp_split_emits_sum_and_next_layernorm(ops, M, Cw, F):
     (1920, 768, 768, "none", False, True),      # stage-3 proj + shortcut
     (1920, 3072, 768, "gelu", True, False),     # stage-3 norm2 + fc1 + GELU
     (28800, 256, 192, "none", False, False),    # input_proj of level 1
+    (7360, 1536, 512, "none", False, False),    # Swin-B stage-2 qkv (K = 512: four 512-register waves)
+    (7360, 512, 512, "none", False, True),      # ... proj + shortcut
+    (28800, 256, 512, "none", True, False),     # Swin-B patch merging into stage 1 (LayerNorm in front)
+    (1920, 3072, 1024, "none", True, False),    # Swin-B stage-3 norm1 + qkv (K = 1024: ranges of 8 column tiles, quarter-K pieces)
+    (1920, 1024, 1024, "none", False, True),    # ... proj + shortcut
+    (1920, 4096, 1024, "gelu", True, False),    # ... norm2 + fc1 + GELU
+    (7360, 512, 1024, "none", True, False),     # Swin-B patch merging into stage 2
+    (50, 96, 1024, "relu", False, True),
     (33, 64, 192, "relu", False, True), (4099, 1152, 384, "gelu", True, True), (17, 576, 256, "none", True, False)])
 def test_xs_linear_vs_f64(ops, M, N, K, act, ln, res):
     """K24 (x-stationary linear layer, weights streamed through the LDS ring, bf16 matrix cores with the exact split) against f64

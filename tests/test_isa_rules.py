@@ -23,13 +23,29 @@ BF16_MFMA_SRC = re.compile(r"__builtin_amdgcn_mfma_f32_\d+x\d+x\d+_?bf16|mfma6\(
 BF16_MFMA_ISA = re.compile(r"\bv_mfma_f32_\d+x\d+x\d+_bf16\b")
 
 
+def _text_with_local_includes(path, seen=None):
+    """The text of a source file followed by that of the csrc/ headers it includes (kernel templates live in headers when
+    two translation units share them: xs_linear_split.h)."""
+    seen = set() if seen is None else seen
+    if path in seen or not os.path.exists(path):
+        return ""
+    seen.add(path)
+    with open(path) as f:
+        text = f.read()
+    for inc in re.findall(r'#include\s+"([^"]+)"', text):
+        text += _text_with_local_includes(os.path.join(CSRC, inc), seen)
+    return text
+
+
 def bf16_mfma_sources():
-    """csrc/*.hip that issue bf16 MFMAs, directly or through split_math.h's mfma6()."""
+    """csrc/*.hip that issue bf16 MFMAs: directly, through split_math.h's mfma6(), or through a kernel header they include."""
     out = []
     for path in sorted(glob.glob(os.path.join(CSRC, "*.hip"))):
-        with open(path) as f:
-            if BF16_MFMA_SRC.search(f.read()):
-                out.append(os.path.basename(path))
+        own = open(path).read()
+        body = own + "".join(_text_with_local_includes(os.path.join(CSRC, inc)) for inc in re.findall(r'#include\s+"([^"]+)"', own)
+                             if inc != "split_math.h")
+        if BF16_MFMA_SRC.search(body):
+            out.append(os.path.basename(path))
     return out
 
 
@@ -37,7 +53,8 @@ SOURCES = bf16_mfma_sources()
 
 
 def test_every_known_bf16_mfma_kernel_file_is_discovered():
-    assert {"linear_split.hip", "win_attn3d.hip", "ws_linear_split.hip", "mlp_split.hip", "xs_linear_split.hip"} <= set(SOURCES), SOURCES
+    assert {"linear_split.hip", "win_attn3d.hip", "ws_linear_split.hip", "mlp_split.hip", "xs_linear_split.hip",
+            "xs_linear_split_wide.hip"} <= set(SOURCES), SOURCES
 
 
 @pytest.fixture(scope="module", params=SOURCES)
@@ -105,7 +122,7 @@ def test_k23_k24_ring_discipline(unit):
     reads) and paces the ring with its own counted vmcnt in front of every barrier: m0 is written inside those statements
     only and every hand-off barrier follows its own counted s_waitcnt vmcnt."""
     src, kernels, _ = unit
-    if src not in ("mlp_split.hip", "xs_linear_split.hip"):
+    if src not in ("mlp_split.hip", "xs_linear_split.hip", "xs_linear_split_wide.hip"):
         pytest.skip("K23 / K24 only")
     for name, body in kernels.items():
         n_dma = n_handoff = 0
