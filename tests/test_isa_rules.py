@@ -57,14 +57,28 @@ def test_every_known_bf16_mfma_kernel_file_is_discovered():
             "xs_linear_split_wide.hip"} <= set(SOURCES), SOURCES
 
 
-@pytest.fixture(scope="module", params=SOURCES)
-def unit(request, tmp_path_factory):
+@pytest.fixture(scope="module")
+def assembly(tmp_path_factory):
+    """gfx950 assembly of every discovered source, compiled side by side (the template-heavy files take over a minute each)."""
     if not os.path.exists(HIPCC):
         pytest.skip("hipcc not available")
+    from concurrent.futures import ThreadPoolExecutor
+    outdir = tmp_path_factory.mktemp("isa")
+
+    def compile_one(src):
+        out = outdir / (src + ".s")
+        subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-I", CSRC,
+                        "--cuda-device-only", "-S", "-o", str(out), os.path.join(CSRC, src)], check=True)
+        return src, out
+
+    with ThreadPoolExecutor(max_workers=min(8, len(SOURCES), len(os.sched_getaffinity(0)))) as pool:
+        return dict(pool.map(compile_one, SOURCES))
+
+
+@pytest.fixture(scope="module", params=SOURCES)
+def unit(request, assembly):
     src = request.param
-    out = tmp_path_factory.mktemp("isa") / (src + ".s")
-    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-I", CSRC,
-                    "--cuda-device-only", "-S", "-o", str(out), os.path.join(CSRC, src)], check=True)
+    out = assembly[src]
     asm = out.read_text()
     bodies = {m.group(1): m.group(2) for m in re.finditer(r"^(_Z\w+):[^\n]*\n(.*?)s_endpgm", asm, re.S | re.M)}
     meta = {}
