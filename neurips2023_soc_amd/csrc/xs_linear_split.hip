@@ -28,7 +28,8 @@ int ctp_of(int K) { return K <= 256 ? 2 : 1; }
 
 // The cut of M rows x N columns: nrg workgroup rows (NW row tiles per pass each) x ncr column ranges of one of the built
 // widths.  Cost model (tools/experiments/k24_time.py): a workgroup pass costs a fixed part (row loads, LayerNorm, split, ring
-// fill: about six column tiles' worth of MFMA time) plus its column tiles; a launch costs the passes of its busiest
+// fill: about ten column tiles' worth of MFMA time -- tools/experiments/k24_main_tail.py: 38 560 x 256 x 256 takes 41 us as
+// (256, 1) and 48 us as (128, 2)) plus its column tiles; a launch costs the passes of its busiest
 // workgroup.  Fewest passes x (tiles + fixed) wins, ties go to the wider range (x is split once per range).
 bool plan(long M, int N, int K, int cus, int* nrg_out, int* ncr_out, int* nct_out) {
     const long ntiles = (M + 15) >> 4;
@@ -44,7 +45,7 @@ bool plan(long M, int N, int K, int cus, int* nrg_out, int* ncr_out, int* nct_ou
         const long tiles_per_wg = (ntiles + nrg - 1) / nrg;
         const long passes = (tiles_per_wg + nw - 1) / nw;
         const long rounds = (nrg * ncr + cus - 1) / cus;
-        const long cost = passes * rounds * (nct + 6);
+        const long cost = passes * rounds * (nct + 10);
         if (best_nct == 0 || cost < best_cost) { best_nct = nct; best_cost = cost; best_nrg = nrg; }
     }
     if (best_nct == 0) return false;

@@ -66,11 +66,11 @@ def _split_ok(x: torch.Tensor, weight: torch.Tensor, fused_passes: int, site: st
 def xs_ok(x, weight) -> bool:
     """K24 (x split once per row tile, weights streamed) where it measured faster than K13b / K20 / the library
     (tools/experiments/k24_time.py): input widths 384 / 768 (512 / 1024 for Swin-B) on pixel-sized inputs (Video-Swin stage 2 / 3 qkv, proj, fc1, the
-    patch-merging reduction into stage 2), and width 256 up to one pass of the chip (the fusion blocks' query projection; the
-    encoder's 38 560-row projections stay on K13b)."""
+    patch-merging reduction into stage 2), and width 256 up to 40 960 rows (the fusion blocks' query projection, the encoder's
+    value_proj / output_proj at 38 560 rows: 41 us against K13b's 47, tools/experiments/k24_main_tail.py)."""
     K = x.shape[-1]
     rows = x.numel() // K
-    return (rows * weight.shape[0] >= 2_000_000 and (K in (384, 512, 768, 1024) or (K == 256 and 16384 <= rows <= 32768))
+    return (rows * weight.shape[0] >= 2_000_000 and (K in (384, 512, 768, 1024) or (K == 256 and 16384 <= rows <= 40960))
             and hot_ops.xs_linear_supported(x, weight))       # (narrow outputs on few rows: the library's small tiles win)
 
 

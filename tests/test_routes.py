@@ -76,6 +76,7 @@ def test_recorded_launches_are_the_ones_the_table_names():
     for s, C in ((2, 384), (3, 768)):
         assert (rows[s], 3 * C, C) in k24 and (rows[s], C, C) in k24, (s, sorted(k24))
     enc = T * (45 * 80 + 23 * 40 + 12 * 20 + 6 * 10)
-    assert (enc, 256, 2048) in k23 and (enc, 256, 256) in k13 and (enc, 384, 256) in k20
+    assert (enc, 256, 2048) in k23 and (enc, 256, 256) in k24 and (enc, 384, 256) in k20      # FFN, value / output proj, offsets | weights
+    assert t["encoder.value_proj"] == t["encoder.output_proj"] == "k24"
     assert (rows[1], 192, 384) in k24 and (rows[2], 384, 768) in k24      # merge0, merge1
     assert t["swin3.fc1"] == "k24" and (rows[3], 3072, 768) in k24
