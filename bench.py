@@ -33,6 +33,7 @@ HBM_ACHIEVABLE_GBS = 6300.0    # MI355X_MICROARCH.md: measured float4 copy rate 
 PEAK_BF16_MFMA_TFLOPS = 2500.0 # MI355X_MICROARCH.md: dense bf16 MFMA peak (spec; the clock held on random data is lower)
 _REL_LATE = os.environ.get('BENCH_REL_LATE', '0') == '1'
 _NO_RECORD_COPY = os.environ.get('BENCH_NO_RECORD_COPY', '0') == '1'
+_STREAM_MODE = os.environ.get('BENCH_STREAM_MODE', 'full')     # diagnostics of the streamed pass: nowait | d2d
 _FEED_DEPTH = int(os.environ.get('BENCH_FEED_DEPTH', '2'))     # device slots of the streamed pass's feeder
 WEIGHT_SEED = 2023
 
@@ -225,6 +226,10 @@ def main():
                 return clips[i % n_pool]
             if i + 1 < n:
                 feeder.submit(host[(i + 1) % len(host)])
+            if _STREAM_MODE == "nowait":        # diagnostic: the copies run, the compute stream neither waits for them nor reads them
+                feeder._ready[feeder._acquired % feeder.depth] = None
+                feeder.acquire()
+                return clips[i % n_pool]
             return feeder.acquire()
 
         done = 0
@@ -277,6 +282,8 @@ def main():
         n_host = min(a.steps, 24)                        # distinct host clips (22 MB pinned each), cycled beyond that
         host = [clips_cpu[i] if i < n_pool else W.synthetic_clip(1 + 1000 * rank + i, T, H, Wd) for i in range(n_host)]
         host = [h.pin_memory() for h in host]
+        if _STREAM_MODE == "d2d":               # diagnostic: the same feeder and events, device-resident sources (no PCIe)
+            host = [h.to(dev) for h in host]
         feeder = DoubleBufferedH2D((T, 3, H, Wd), torch.float32, dev, depth=_FEED_DEPTH)
         # A driver recycles a few pinned buffers (clip_io.PinnedPool), so every buffer it copies from has been through the
         # DMA engine before; the first transfer out of a fresh pinned allocation is several times slower than the 0.41 ms
