@@ -259,7 +259,7 @@ int soc_patch_merge_layernorm_f32(const float* x, const float* gamma, const floa
  * partial sums a second kernel adds in a fixed order (deterministic).
  *   x [M, C], w1 [F, C], b1 [F], w2 [C, F], b2 [C], ln_gamma / ln_beta [C] or both NULL, residual [M, C] or NULL,
  *   post_gamma / post_beta [C] or both NULL, out [M, C], out_sum [M, C] or NULL (with LN2: the sum in front of it, i.e. the
- *   shortcut the next Video-Swin block needs beside norm1 of it); C in {96, 128, 192, 256, 384}, F % 32 == 0; every pointer 16-byte aligned.
+ *   shortcut the next Video-Swin block needs beside norm1 of it); C in {96, 128, 192, 256, 384, 512}, F % 32 == 0; every pointer 16-byte aligned.
  *   soc_mlp_split_packed_bytes / soc_mlp_split_pack_f32: split and lay out both weights ONCE (opaque image `packed`);
  *   re-pack after the weights change.  soc_mlp_split_workspace_bytes: scratch for the partial sums (0 when none are needed).
  *   soc_mlp_split_plan: the (workgroup rows, hidden ranges) cut chosen for M rows taken as ONE launch.
@@ -282,14 +282,15 @@ int soc_mlp_split_variant_f32(const float* x, const void* packed, const float* b
 /*
  * K24 -- an x-stationary linear layer on the bf16 matrix cores (exact three-way operand split, f32-grade results -- see
  * soc_linear_split_f32): out = act(LN(x) W^T + bias) + residual, act 0 = none, 1 = ReLU, 2 = exact (erf) GELU; LN, bias,
- * residual optional.  Replaces the pixel-sized nn.Linear calls of input widths 192 / 256 / 384 / 768: qkv / proj of
+ * residual optional.  Replaces the pixel-sized nn.Linear calls of input widths 192 / 256 / 384 / 512 / 768 / 1024: qkv / proj of
  * WindowAttention3D in Video-Swin stages 1-3 (models/video_swin_transformer.py:144-166, norm1 :219 in front, the shortcut
  * :254-259 behind), the PatchMerging reduction into stage 2 (:277-312), value_proj / output_proj of MSDeformAttn
  * (models/ops/modules/ms_deform_attn.py:95,114), the query projection of the fusion blocks (models/vla.py:18-24) and
  * input_proj of level 1 (models/soc.py:226-230).  A wave keeps its 16 rows as split MFMA fragments (split once); the weights
  * stream through an LDS ring; a launch is cut into `nrg` workgroup rows x `ncr` column ranges (0, 0: the library plans it).
  *   x [M, K], w [N, K] (nn.Linear.weight layout), bias [N] or NULL, ln_gamma / ln_beta [K] or both NULL, residual [M, N] or
- *   NULL, out [M, N]; K in {192, 256, 384, 768}, N % 32 == 0 and N / 16 divisible into ranges of 4 / 6 / 8 / 12 / 16 / 18
+ *   NULL, out [M, N]; K in {192, 256, 384, 512, 768, 1024}, N % 32 == 0 and N / 16 divisible into ranges of 4 / 6 / 8 / 12 / 16 / 18
+ *   (K = 1024: 4 / 6 / 8)
  *   column tiles (soc_xs_linear_plan says whether and how); every pointer 16-byte aligned.
  *   soc_xs_linear_packed_bytes / soc_xs_linear_pack_f32: split and lay out the weights ONCE (opaque image); re-pack after a
  *   weight update.
