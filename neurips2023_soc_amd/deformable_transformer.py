@@ -28,7 +28,7 @@ class DeformableTransformerEncoderLayer(nn.Module):
         self.norm2 = nn.LayerNorm(d_model)
 
     def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None,
-                pad_flag=None):
+                pad_flag=None, out_tag=None):
         if fused.mlp_ok(src, self.linear1, self.linear2):
             # the shortcut rides in output_proj's epilogue; norm1, linear1 + ReLU + linear2, the shortcut norm1(.) and norm2 are ONE
             # K23 launch (whole rounds of the chip + a split tail): no LayerNorm pass in the layer
@@ -36,7 +36,8 @@ class DeformableTransformerEncoderLayer(nn.Module):
                                       pad_flag=pad_flag, return_sampling=False, query_pos=pos, residual=src)
             return hot_ops.mlp_split(s1, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias, "relu",
                                      ln=(self.norm1.weight, self.norm1.bias, self.norm1.eps), residual=s1, residual_ln=True,
-                                     post_ln=(self.norm2.weight, self.norm2.bias, self.norm2.eps))
+                                     post_ln=(self.norm2.weight, self.norm2.bias, self.norm2.eps),
+                                     out=hot_ops.placed(out_tag, s1))
         a, _, _ = self.self_attn(src, reference_points, src, spatial_shapes, level_start_index, padding_mask,
                                  pad_flag=pad_flag, return_sampling=False, query_pos=pos)
         src = _add_norm(src, a, self.norm1)
@@ -71,8 +72,9 @@ class DeformableTransformerEncoder(nn.Module):
         if ref is None:
             ref = self.get_reference_points(shapes_list if shapes_list is not None else spatial_shapes,
                                             valid_ratios, src.device)
-        for layer in self.layers:
-            src = layer(src, pos, ref, spatial_shapes, level_start_index, padding_mask, pad_flag)
+        for layer in self.layers:       # the last layer's K23 launch writes into a placed buffer when the caller set one
+            src = layer(src, pos, ref, spatial_shapes, level_start_index, padding_mask, pad_flag,
+                        out_tag="encoder_memory" if layer is self.layers[-1] else None)
         return src
 
 

@@ -141,7 +141,7 @@ class PipelinedClipGraph:
             self._pc.wait_stream(cur)
             with torch.cuda.stream(self._pc):
                 self._tail(self.sb[1 - k], fork=False)          # clip i-1
-            self._store(self._head(fork=True), self.sb[k])      # clip i
+            self._store(self._placed_head(self.sb[k]), self.sb[k])      # clip i
             cur.wait_stream(self._pc)
 
         self.steady = [capture(lambda k=k: tail_beside_head(k)) for k in (0, 1)]
@@ -153,6 +153,25 @@ class PipelinedClipGraph:
         samples = NestedTensor(self.clip, self.pad, unpadded=True)
         sa = self.model.forward_backbone(samples, None, {"input_ids": self.ids, "attention_mask": self.attn})
         return self.model.forward_fuse_encode(sa, fork=fork)
+
+    def _placed_head(self, dst):
+        """The head with its two largest hand-over tensors -- the stage-0 token map (44 MB at the BASELINE size) and the encoder
+        memory (40 MB) -- produced IN the static state `dst` (hot_ops.place_output) instead of copied there behind the head."""
+        f0, mem = dst["feats0"], dst["ctx"][0]
+        n, c, h, w = f0.shape
+        tok = f0.permute(0, 2, 3, 1)                     # '(b t) h w c': the layout the stage writes
+        import os
+        if os.environ.get("SOC_NO_PLACE", "0") == "1":  # diagnostic: the copies of round 3
+            return self._head(fork=True)
+        try:
+            if tok.is_contiguous():
+                hot_ops.place_output("swin0", tok.view(n // self.T, self.T, h, w, c))
+            if mem.is_contiguous():
+                hot_ops.place_output("encoder_memory", mem)
+            return self._head(fork=True)
+        finally:
+            hot_ops.place_output("swin0", None)
+            hot_ops.place_output("encoder_memory", None)
 
     def _tail(self, sb, fork: bool):
         # the tail runs beside another clip's head, which pays for the tail's CU time and not for its launch count: the
@@ -189,15 +208,19 @@ class PipelinedClipGraph:
         return new
 
     def _store(self, st, dst):
+        def put(d, t):
+            if d.data_ptr() != t.data_ptr():             # already produced in place (_placed_head)
+                d.copy_(t)
+
         for k in self._VARY:
             v = st[k]
             if k == "ctx":
-                dst[k][0].copy_(v[0])
+                put(dst[k][0], v[0])
             elif isinstance(v, (list, tuple)):
                 for d, t in zip(dst[k], v):
-                    d.copy_(t)
+                    put(d, t)
             else:
-                dst[k].copy_(v)
+                put(dst[k], v)
 
     # -- driving -----------------------------------------------------------------------------------------
     def run(self, clip: torch.Tensor, ids: Optional[torch.Tensor] = None, attn: Optional[torch.Tensor] = None):

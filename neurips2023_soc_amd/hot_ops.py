@@ -1126,6 +1126,27 @@ def xs_linear_plan(M: int, N: int, K: int) -> Tuple[int, int, int]:
     return a.value, b.value, c.value
 
 
+# Output placement: graph_runner.PipelinedClipGraph hands the head two of its static buffers (the stage-0 token map and the
+# encoder memory, 44 + 40 MB) so that the kernels producing them write there directly instead of being copied there afterwards.
+_placed: dict = {}
+
+
+def place_output(tag: str, tensor: Optional[Tensor]) -> None:
+    """Ask the producer of `tag` ("swin0": last block of Video-Swin stage 0; "encoder_memory": last encoder layer) to write its
+    result into `tensor` (contiguous fp32, the result's shape); None withdraws the request."""
+    if tensor is None:
+        _placed.pop(tag, None)
+    else:
+        _placed[tag] = tensor
+
+
+def placed(tag: Optional[str], like: Tensor) -> Optional[Tensor]:
+    t = _placed.get(tag) if tag is not None else None
+    if t is None or t.shape != like.shape or t.dtype != like.dtype or t.device != like.device or not t.is_contiguous():
+        return None
+    return t
+
+
 MLP_SPLIT_C = (96, 128, 192, 256, 384, 512)  # model widths K23 is built for
 _MLP_ACT = {"relu": 1, "gelu": 2}
 _mlp_cache = DerivedCache()

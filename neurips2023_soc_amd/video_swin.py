@@ -99,6 +99,7 @@ class BasicLayer(nn.Module):
             SwinTransformerBlock3D(dim, num_heads, window_size, (0, 0, 0) if i % 2 == 0 else shift)
             for i in range(depth)])
         self.downsample = None
+        self.out_tag = None     # "swin<stage>": the stage's last K23 launch writes into hot_ops.placed(out_tag) when one is set
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:  # [B,D,H,W,C] token-major throughout
         """Tall stages with a short channel width (stages 0-1 of every Video-Swin variant) run each block as four
@@ -119,7 +120,8 @@ class BasicLayer(nn.Module):
                 x = hot_ops.linear_split(o, a.proj.weight, a.proj.bias, residual=x)
                 if fused.mlp_ok(x, m.fc1, m.fc2):      # C = 256 (Swin-B stage 1): norm2 + fc1 + GELU + fc2 + shortcut in one K23 launch
                     x = hot_ops.mlp_split(x, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias, "gelu",
-                                          ln=(blk.norm2.weight, blk.norm2.bias, blk.norm2.eps), residual=x)
+                                          ln=(blk.norm2.weight, blk.norm2.bias, blk.norm2.eps), residual=x,
+                                          out=hot_ops.placed(self.out_tag, x) if blk is blocks[-1] else None)
                     continue
                 h = hot_ops.linear_split(x, m.fc1.weight, m.fc1.bias, ln=(blk.norm2.weight, blk.norm2.bias, blk.norm2.eps),
                                          act="gelu")
@@ -138,7 +140,8 @@ class BasicLayer(nn.Module):
                 if fused.mlp_ok(x, blk.mlp.fc1, blk.mlp.fc2):
                     # K23: norm2 + fc1 + GELU + fc2 + residual in one launch, the hidden layer never leaves the registers
                     x = hot_ops.mlp_split(x, blk.mlp.fc1.weight, blk.mlp.fc1.bias, blk.mlp.fc2.weight, blk.mlp.fc2.bias, "gelu",
-                                          ln=(blk.norm2.weight, blk.norm2.bias, blk.norm2.eps), residual=x)
+                                          ln=(blk.norm2.weight, blk.norm2.bias, blk.norm2.eps), residual=x,
+                                          out=hot_ops.placed(self.out_tag, x) if blk is blocks[-1] else None)
                     continue
                 h = hot_ops.ws_linear(x, blk.mlp.fc1.weight, blk.mlp.fc1.bias,
                                       ln=(blk.norm2.weight, blk.norm2.bias, blk.norm2.eps), act="gelu")
@@ -294,6 +297,8 @@ class VideoSwinTransformerBackbone(nn.Module):
         self.patch_embed = PatchEmbed3D(d)
         self.layers = nn.ModuleList([BasicLayer(d * 2 ** i, cfg["depths"][i], cfg["num_heads"][i], WINDOW)
                                      for i in range(4)])
+        for i, layer in enumerate(self.layers):
+            layer.out_tag = f"swin{i}"
         self.downsamples = nn.ModuleList([PatchMerging(d * 2 ** i) for i in range(3)] + [None])
         self.layer_output_channels = [d * 2 ** i for i in range(4)]
 
