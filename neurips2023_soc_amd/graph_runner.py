@@ -208,9 +208,11 @@ class PipelinedClipGraph:
         return new
 
     def _store(self, st, dst):
+        pairs = []
+
         def put(d, t):
-            if d.data_ptr() != t.data_ptr():             # already produced in place (_placed_head)
-                d.copy_(t)
+            if d.data_ptr() != t.data_ptr():             # else: already produced in place (_placed_head)
+                pairs.append((d, t))
 
         for k in self._VARY:
             v = st[k]
@@ -221,6 +223,16 @@ class PipelinedClipGraph:
                     put(d, t)
             else:
                 put(dst[k], v)
+        # what is left are a few small tensors (the words' features, their padding mask, the sentence feature): one multi-tensor
+        # launch per dtype instead of a copy launch each at the very end of the head
+        groups = {}
+        for d, t in pairs:
+            if d.dtype == t.dtype and d.shape == t.shape:
+                groups.setdefault(d.dtype, []).append((d, t))
+            else:
+                d.copy_(t)
+        for group in groups.values():
+            torch._foreach_copy_([d for d, _ in group], [t for _, t in group])
 
     # -- driving -----------------------------------------------------------------------------------------
     def run(self, clip: torch.Tensor, ids: Optional[torch.Tensor] = None, attn: Optional[torch.Tensor] = None):
