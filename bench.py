@@ -466,8 +466,9 @@ def main():
             (SQ_INSTS_VALU x 2 clk / (SQ_INSTS_MFMA x 16.7 clk); v_exp and packed forms counted as one instruction).  On a
             gfx950 SIMD the two do not overlap (tools/microbench/mfma_valu_roles.hip), so 1 / (1 + share) bounds the kernel
             below the 417 TFLOP/s ceiling before any LDS / barrier stall."""
-            src = {"win_attn3d": ("r03_k1_pmc.json", lambda d: d["counters"]["k1_stage0_split"]),
-                   "mlp_split": ("r04_k23enc_counters.json", lambda d: d["k23enc"])}.get(fam)
+            src = {"win_attn3d": ("r04_k1_pmc.json", lambda d: d["counters"]["k1_stage0_split"]),
+                   "mlp_split": ("r04_k23enc_counters.json", lambda d: d["k23enc"]),
+                   "xs_linear": ("r04_k24_counters.json", lambda d: d["counters"]["k24qkv2"])}.get(fam)
             if src is None:
                 return None
             try:

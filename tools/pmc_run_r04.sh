@@ -1,13 +1,13 @@
 #!/bin/bash
 # Round-4 evidence run on the MI355X box (gpurun): everything lands under gpurun_out/r04/, the summaries are then copied
 # into profiles/.  Counters are collected in their own passes (--pmc with --kernel-trace only), the program directly after
-# `--`.  Parts: trace | traffic | k23 | rest (default: all).
+# `--`.  Parts: trace | traffic | k23 | k1k24 | rest (default: all).
 set -x
 cd "$GRAFT_REPO_ROOT"
 export TMPDIR=/tmp
 P=gpurun_out/r04
 mkdir -p $P
-PARTS=${1:-trace traffic k23 rest}
+PARTS=${1:-trace traffic k23 k1k24 rest}
 for part in $PARTS; do
 case $part in
 trace)
@@ -33,6 +33,19 @@ k23)
     rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY -d $P/${site}_sq -- python3 tools/run_kernel.py $site 12 > $P/${site}_sq.log 2>&1
     rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_COEXEC_CYCLES GRBM_GUI_ACTIVE -d $P/${site}_lds -- python3 tools/run_kernel.py $site 12 > $P/${site}_lds.log 2>&1
     python3 tools/pmc_agg.py --kernels "${site}=mlp_split_kernel" -- $P/${site}_sq $P/${site}_lds > $P/${site}_counters.json
+  done
+  ;;
+k1k24)
+  # ---- (c2) K1 per stage (split form) and K24 at four call sites: the same two counter passes
+  for st in 0 1 2 3; do
+    rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY -d $P/k1s${st}_sq -- python3 tools/run_kernel.py k1s$st 12 > $P/k1s${st}_sq.log 2>&1
+    rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_COEXEC_CYCLES GRBM_GUI_ACTIVE -d $P/k1s${st}_lds -- python3 tools/run_kernel.py k1s$st 12 > $P/k1s${st}_lds.log 2>&1
+    python3 tools/pmc_agg.py --kernels "k1_stage${st}_split=win_attn3d_" -- $P/k1s${st}_sq $P/k1s${st}_lds > $P/k1s${st}_counters.json
+  done
+  for site in k24qkv2 k24enc k24qkv3 k24vlf; do
+    rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY -d $P/${site}_sq -- python3 tools/run_kernel.py $site 12 > $P/${site}_sq.log 2>&1
+    rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_COEXEC_CYCLES GRBM_GUI_ACTIVE -d $P/${site}_lds -- python3 tools/run_kernel.py $site 12 > $P/${site}_lds.log 2>&1
+    python3 tools/pmc_agg.py --kernels "${site}=xs_linear_kernel" -- $P/${site}_sq $P/${site}_lds > $P/${site}_counters.json
   done
   ;;
 rest)

@@ -63,6 +63,15 @@ elif which.startswith("k23"):
     w2, b2 = (torch.randn(Cw, F, generator=g) / F ** 0.5).to(dev), torch.randn(Cw, generator=g).to(dev)
     ln = ((torch.rand(Cw, generator=g) + 0.5).to(dev), torch.randn(Cw, generator=g).to(dev), 1e-5)
     fn = lambda: hot_ops.mlp_split(x, w1, b1, w2, b2, act, ln if use_ln else None, x, post_ln=None if use_ln else ln)  # noqa: E731
+elif which.startswith("k24"):
+    # K24 at four of its call sites: stage-2 qkv, the encoder's value_proj, stage-3 norm1 + qkv, the fusion query projection
+    M, N, K, use_ln = {"k24qkv2": (7360, 1152, 384, False), "k24enc": (38560, 256, 256, False),
+                       "k24qkv3": (1920, 2304, 768, True), "k24vlf": (28800, 256, 256, False)}[which]
+    x = torch.randn(M, K, generator=g).to(dev)
+    wt = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
+    b = torch.randn(N, generator=g).to(dev)
+    ln = ((torch.rand(K, generator=g) + 0.5).to(dev), torch.randn(K, generator=g).to(dev), 1e-5) if use_ln else None
+    fn = lambda: hot_ops.xs_linear(x, wt, b, ln, None, "none")  # noqa: E731
 elif which.startswith("ln"):
     rows, C = {"ln0": (115200, 96), "ln1": (28800, 192), "lnenc": (38560, 256), "ln2": (7360, 384)}[which]
     x = torch.randn(rows, C, generator=g).to(dev)
