@@ -23,13 +23,13 @@ def test_route_table_matches_the_golden():
 
 def test_headline_config_keeps_its_hand_written_kernels():
     """The BASELINE headline (Swin-T, T = 8, 360 x 640): every MLP of stages 0-2 and the encoder's feed-forward block on K23,
-    qkv / proj of stages 0-1 and the encoder's projections on K13b, of stages 2-3 on K24; what is left to the library is the
+    qkv / proj of stages 0-1 on K13b, of stages 2-3 and the encoder's value / output projections on K24; what is left to the library is the
     list below (hidden width 3072 of stage 3, the K = 1536 reduction, the coarse levels' narrow projections)."""
     t = routes.table("video-swin-t", 8, 360, 640)
     assert [t[f"swin{s}.mlp"] for s in range(3)] == ["k23"] * 3 and t["encoder.ffn"] == "k23"
     assert all(t[f"swin{s}.{n}"] == "k13b" for s in range(2) for n in ("qkv", "proj"))
     assert all(t[f"swin{s}.{n}"] == "k24" for s in (2, 3) for n in ("qkv", "proj")) and t["swin3.fc1"] == "k24"
-    assert t["encoder.value_proj"] == t["encoder.output_proj"] == "k13b" and t["encoder.offsets|weights"] == "k20"
+    assert t["encoder.value_proj"] == t["encoder.output_proj"] == "k24" and t["encoder.offsets|weights"] == "k20"
     library = sorted(k for k, v in t.items() if v == "library")
     assert library == ["input_proj3", "merge2", "swin3.fc2", "vlf2.out*tgt", "vlf2.q", "vlf3.out*tgt", "vlf3.q"], library
 
