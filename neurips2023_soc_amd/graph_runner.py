@@ -75,9 +75,12 @@ class ClipGraph:
         if ids is not None:
             self.ids.copy_(ids.view(self.ids.shape), non_blocking=True)
             if attn is None:
-                self.attn.fill_(1)
+                if not getattr(self, "_attn_ones", True):   # the static mask is all ones until a caller stages another one
+                    self.attn.fill_(1)
+                    self._attn_ones = True
             else:
                 self.attn.copy_(attn.view(self.attn.shape), non_blocking=True)
+                self._attn_ones = False
 
     def replay(self) -> Dict[str, torch.Tensor]:
         self.graph.replay()
