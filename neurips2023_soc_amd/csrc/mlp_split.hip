@@ -609,6 +609,7 @@ int launch_variant(const Args& a, int variant) {
         V(2, 0, 0, 1, 0) V(3, 0, 0, 1, 0) V(4, 1, 0, 1, 0) V(3, 1, 0, 1, 0)
         V(3, 0, 1, 1, 0) V(3, 0, 3, 1, 0) V(3, 0, 2, 1, 0) V(3, 0, 4, 1, 0) V(4, 0, 4, 1, 0) V(4, 1, 4, 1, 0) V(2, 0, 4, 1, 0)
         V(3, 0, 0, 1, 1) V(3, 0, 0, 1, 2) V(3, 0, 0, 1, 13) V(4, 1, 0, 1, 1) V(4, 1, 0, 1, 2) V(4, 1, 0, 1, 13)
+        V(3, 1, 0, 1, 1) V(3, 1, 0, 1, 2) V(3, 1, 0, 1, 13) V(3, 1, 0, 1, 4) V(3, 1, 0, 1, 8) V(6, 2, 0, 1, 0) V(5, 2, 0, 1, 0) V(4, 2, 0, 1, 0)
         default: break;
     }
 #undef V

@@ -121,3 +121,6 @@ case("enc", 32768, 256, 2048, "relu", False, True, [(256, 1)], V)
 case("s0", 115200, 96, 384, "gelu", True, True, [(256, 1)], [0, vr(3), vr(3, stag=4), vr(4, stag=4)])
 case("s1", 28800, 192, 768, "gelu", True, True, [None], V)
 case("s2", 7360, 384, 1536, "gelu", True, True, [None], [0, vr(4, 1), vr(4, 1, stag=4)])
+# Swin-B stage 2 (C = 512): the shipped form (three half-block slots), its ceilings, quarter-block pieces through 4 / 5 / 6 slots
+case("s2b", 7360, 512, 2048, "gelu", True, True, [None, (115, 1), (115, 4)],
+     [0, vr(3, 1), vr(3, 1, dbg=1), vr(3, 1, dbg=2), vr(3, 1, dbg=4), vr(3, 1, dbg=8), vr(3, 1, dbg=13), vr(4, 2), vr(5, 2), vr(6, 2)])
