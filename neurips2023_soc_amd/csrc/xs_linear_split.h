@@ -41,6 +41,17 @@ __device__ __forceinline__ void handoff() {        // my part of the next piece 
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N_) : "memory");
 }
 
+#ifdef SOC_K24_STAMPS       // diagnostic build only (tools/experiments/k24_stamps.py): s_memtime at phase boundaries, [block][wave][8]
+__device__ unsigned long long* g_xs_dbg = nullptr;
+#define XS_STAMP(slot)                                                                                         \
+    do {                                                                                                       \
+        if (g_xs_dbg && (threadIdx.x & 63) == 0 && blockIdx.x < 4096)                                          \
+            g_xs_dbg[((long)blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define XS_STAMP(slot) do {} while (0)
+#endif
+
 // NCT column tiles per range (compile time: the accumulators are registers)
 template <int K, int ACT, bool HAS_LN, int NCT>
 __global__ __launch_bounds__(Geo<K>::NW * 64, Geo<K>::NW / 4) void xs_linear_kernel(
@@ -82,6 +93,7 @@ __global__ __launch_bounds__(Geo<K>::NW * 64, Geo<K>::NW / 4) void xs_linear_ker
     auto pass = [&](auto act_c, long pt) {
         constexpr bool ACTIVE = decltype(act_c)::value;                 // this wave has a row tile in the pass
         bf16x8 xb[KS][3];
+        XS_STAMP(0);
         {
             float4 xn[KS][2];
             const long m = min((pt + wave) * 16 + r, M - 1);
@@ -93,6 +105,7 @@ __global__ __launch_bounds__(Geo<K>::NW * 64, Geo<K>::NW / 4) void xs_linear_ker
 #pragma unroll
             for (int b = 0; b < D; ++b)
                 if (b < NQ) dma(b, b);
+            XS_STAMP(1);
             if (ACTIVE) {
                 float v[KS][8];
 #pragma unroll
@@ -136,7 +149,9 @@ __global__ __launch_bounds__(Geo<K>::NW * 64, Geo<K>::NW / 4) void xs_linear_ker
         f32x4 acc[NCT];
 #pragma unroll
         for (int j = 0; j < NCT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        XS_STAMP(2);
         if (NQ >= D) handoff<(D - 1) * P>(); else handoff<0>();         // piece 0 has landed
+        XS_STAMP(3);
         // ---- the ring: piece q = column tiles [CTP (q / SB), + CTP) x k-steps [KSP (q % SB), + KSP); fully unrolled (the
         // accumulators are registers), fragment groups read one ahead of the MFMAs that consume them
 #pragma unroll
@@ -168,6 +183,7 @@ __global__ __launch_bounds__(Geo<K>::NW * 64, Geo<K>::NW / 4) void xs_linear_ker
             }
         }
         // ---- lane (r, kq) holds out[m][n0 + 16 j + 4 kq .. + 3]: bias, activation, residual, 16-B stores
+        XS_STAMP(4);
         const long m = (pt + wave) * 16 + r;
         if (ACTIVE && m < M) {
             long mo = m * N + n0 + 4 * kq;
@@ -200,6 +216,7 @@ __global__ __launch_bounds__(Geo<K>::NW * 64, Geo<K>::NW / 4) void xs_linear_ker
 #pragma unroll
             for (int j = 0; j < NCT; ++j) *reinterpret_cast<f32x4*>(out + mo + 16 * j) = acc[j];
         }
+        XS_STAMP(5);
     };
     for (long pt = t0; pt < t1; pt += NW) {
         if (pt != t0) handoff<0>();                 // nobody still reads the slots the next pass's prologue refills
@@ -207,6 +224,7 @@ __global__ __launch_bounds__(Geo<K>::NW * 64, Geo<K>::NW / 4) void xs_linear_ker
         else pass(std::false_type{}, pt);
     }
     __syncthreads();        // the waves retire together
+    XS_STAMP(6);
 }
 
 // item = (piece, group, lane): one 16-B piece per plane = 8 weights split three ways.  Image: [N / 16 / CTP x SB pieces][PIECE_U4]

@@ -57,6 +57,13 @@ bool plan(long M, int N, int K, int cus, int* nrg_out, int* ncr_out, int* nct_ou
 
 }  // namespace
 
+#ifdef SOC_K24_STAMPS
+extern "C" int soc_xs_debug_set_buffer(void* ptr) {
+    unsigned long long* p = (unsigned long long*)ptr;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_xs_dbg), &p, sizeof(p)) == hipSuccess ? 0 : -1;
+}
+#endif
+
 extern "C" size_t soc_xs_linear_packed_bytes(int N, int K) {
     if (!width_ok(K) || N <= 0 || N % 32 != 0) return 0;
     switch (K) {
