@@ -64,8 +64,9 @@ __global__ __launch_bounds__(Geo<K>::NW * 64, Geo<K>::NW / 4) void xs_linear_ker
     static_assert(NCT % CTP == 0 && (D - 1) * P < 64, "whole pieces");
     extern __shared__ __attribute__((aligned(16))) u32x4 lds[];
     u32x4* slots = lds;
-    float* gs = reinterpret_cast<float*>(lds + NSLOT * SLOT);           // gamma [K], beta [K]
+    float* gs = reinterpret_cast<float*>(lds + NSLOT * SLOT);           // gamma [K], beta [K], this range's bias [16 NCT]
     float* bs = gs + K;
+    float* bias_s = bs + K;
     asm volatile("v_mov_b32 v255, 0" ::: "v255");                       // own the CU
     if (NW == 4) asm volatile("v_accvgpr_write_b32 a255, 0" ::: "a255");
     const int tid = threadIdx.x, lane = tid & 63;
@@ -77,6 +78,9 @@ __global__ __launch_bounds__(Geo<K>::NW * 64, Geo<K>::NW / 4) void xs_linear_ker
     const long t0 = (long)g * ntiles / nrg, t1 = (long)(g + 1) * ntiles / nrg;
     if (HAS_LN)
         for (int i = tid; i < K; i += THREADS) { gs[i] = gamma[i]; bs[i] = beta[i]; }
+    // the bias of the column range waits in LDS: read from global memory in the epilogue it was a dependent load in front of
+    // the stores of every wave (tools/experiments/k24_stamps.py)
+    for (int i = tid; i < NCT * 16; i += THREADS) bias_s[i] = bias ? bias[n0 + i] : 0.f;
     // LDS-DMA from inline assembly, as K23 (mlp_split.hip): the compiler must not see an LDS-DMA in flight
     const char* ibase = reinterpret_cast<const char*>(img + (long)cr * NQ * SLOT);
     const unsigned voff = (unsigned)tid * 16u;
@@ -188,12 +192,8 @@ __global__ __launch_bounds__(Geo<K>::NW * 64, Geo<K>::NW / 4) void xs_linear_ker
         if (ACTIVE && m < M) {
             long mo = m * N + n0 + 4 * kq;
             asm volatile("" : "+v"(mo));
-            f32x4 bq[NCT];
 #pragma unroll
-            for (int j = 0; j < NCT; ++j)
-                bq[j] = bias ? *reinterpret_cast<const f32x4*>(bias + n0 + 16 * j + 4 * kq) : (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int j = 0; j < NCT; ++j) acc[j] += bq[j];
+            for (int j = 0; j < NCT; ++j) acc[j] += *reinterpret_cast<const f32x4*>(bias_s + 16 * j + 4 * kq);
             if (ACT == 1) {
 #pragma unroll
                 for (int j = 0; j < NCT; ++j)
@@ -262,7 +262,7 @@ template <int K, int ACT, bool HAS_LN, int NCT>
 int launch(const Args& a) {
     using G = Geo<K>;
     const void* fn = reinterpret_cast<const void*>(xs_linear_kernel<K, ACT, HAS_LN, NCT>);
-    const size_t lds = (size_t)G::NSLOT * G::PIECE_U4 * 16 + 8 * K;
+    const size_t lds = (size_t)G::NSLOT * G::PIECE_U4 * 16 + 8 * K + 64 * NCT;
     static std::atomic<bool> attr_set[SOC_MAX_DEVICES];
     const int dev = soc_current_device();
     if (dev < 0) return SOC_ELAUNCH;
