@@ -12,8 +12,9 @@ from tests.golden_utils import sub, t
 pytestmark = pytest.mark.gpu
 
 # A thresholded pixel may differ from the reference only where the REFERENCE logit is this close to zero
-# (the reference's own 1-vs-8-thread noise is 6e-5 at the BASELINE logit scale).
-FLIP_WINDOW = 1e-4
+# (the reference's own 1-vs-8-thread noise is 6e-5 at the BASELINE logit scale): "bit-exact masks" holds
+# everywhere except for pixels whose reference logit lies inside the reference's own thread-count noise.
+FLIP_WINDOW = 6e-5
 
 
 def maxdiff(a, b):
@@ -63,7 +64,7 @@ def test_full_config_matches_reference(gpu_model, golden):
     print("full: max|dlogit| selected", d, "all(sub)", dsub, "of", g["pred_masks_stats"][2])
     assert d < 1e-3 and dsub < 1e-3
     # thresholded masks: bit-exact except at the decision boundary itself -- a pixel may only
-    # differ if the REFERENCE logit is within fp32 noise of zero (|logit| < 1e-4 on a scale of
+    # differ if the REFERENCE logit is within fp32 noise of zero (|logit| < FLIP_WINDOW on a scale of
     # 37; the reference's own 1-vs-8-thread noise is 1.6e-6 relative = 6e-5 here)
     ours = (out["pred_masks"] > 0).cpu().numpy().reshape(-1)
     ref_bits = np.unpackbits(g["pred_masks_signbits"])[:ours.size].astype(bool)
