@@ -144,6 +144,30 @@ class ClipInferencer:
         return res
 
 
+def load_checkpoint(model, path: str):
+    """The reference's on-disk contract (infer_refytb.py:143-156): `torch.load(path)["model_state_dict"]`, strict=False,
+    the profiler's `total_params` / `total_ops` buffers ignored, anything else missing or unexpected printed.
+    Returns (missing, unexpected) after that filter."""
+    state = torch.load(path, map_location="cpu")["model_state_dict"]
+    missing, unexpected = model.load_state_dict(state, strict=False)
+    unexpected = [k for k in unexpected if not k.endswith(("total_params", "total_ops"))]
+    if missing or unexpected:
+        print(f"Missing Keys: {missing}\nUnexpected Keys: {unexpected}")
+    return missing, unexpected
+
+
+def load_tokenizer(path: str):
+    """`RobertaTokenizerFast.from_pretrained(DIR)` (models/soc.py:104) -> tokenize(expression) -> int64 [1,L], encoded the
+    way SOC.forward_text does it (padding='longest' over a batch of one = no padding)."""
+    from .soc import encode_expressions, load_roberta_tokenizer
+    hf = load_roberta_tokenizer(path)
+
+    def tokenize(text):
+        return encode_expressions(hf, [text])[0]
+    tokenize.hf = hf
+    return tokenize
+
+
 def _run_dataset(a):
     """infer_refytb.py / infer_davis.py `main`: one process per GPU over a static split of the videos
     (reference infer_refytb.py:84-109), no collective -- every rank writes its own PNGs."""
@@ -166,19 +190,11 @@ def _run_dataset(a):
         time.sleep(0.2)
     model, _, _ = build_model(default_args(a.backbone, text_encoder_random_init=a.checkpoint is None))
     if a.checkpoint:
-        state = torch.load(a.checkpoint, map_location="cpu")["model_state_dict"]
-        missing, unexpected = model.load_state_dict(state, strict=False)        # reference :137-150
-        unexpected = [k for k in unexpected if not k.endswith(("total_params", "total_ops"))]
-        if missing or unexpected:
-            print(f"Missing Keys: {missing}\nUnexpected Keys: {unexpected}")
+        load_checkpoint(model, a.checkpoint)
     else:
         W.load_synthetic(model, 2023)
     if a.tokenizer:
-        from transformers import RobertaTokenizerFast
-        hf = RobertaTokenizerFast.from_pretrained(a.tokenizer)
-
-        def tokenize(text):
-            return hf(text, return_tensors="pt")["input_ids"]
+        tokenize = load_tokenizer(a.tokenizer)
     else:
         tokenize = synthetic_dataset.HashTokenizer()
     driver = infer_refytb if a.dataset == "refytb" else infer_davis

@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import copy
 import math
+import os
 
 import torch
 import torch.nn.functional as F
@@ -76,14 +77,39 @@ def _load_text_stack(config):
     name = config.text_encoder_type
     try:
         enc = RobertaModel.from_pretrained(name, local_files_only=True)
-        tok = RobertaTokenizerFast.from_pretrained(name, local_files_only=True)
-        return enc, tok
+        return enc, load_roberta_tokenizer(name)
     except Exception as exc:  # no files / no network
         if not getattr(config, "text_encoder_random_init", False):
             raise RuntimeError(
                 f"cannot load text encoder {name!r} offline ({type(exc).__name__}); pass "
                 "text_encoder_random_init=True for synthetic-weight runs") from exc
         return RobertaModel(roberta_base_config()), None
+
+
+def load_roberta_tokenizer(name_or_dir):
+    """`RobertaTokenizerFast.from_pretrained(name_or_dir)` (models/soc.py:104), offline.  A directory that holds a
+    `tokenizer.json` is loaded from that file: transformers 5.x's `from_pretrained` rebuilds the backend from vocab /
+    merges there and comes back WITHOUT the byte-level pre-tokenizer (spaces vanish, no merge applies) -- so the result is
+    checked, and a tokenizer that would split text differently from RoBERTa's is an error, not a silent change of ids."""
+    import json
+    from transformers import RobertaTokenizerFast
+    tok_file = os.path.join(str(name_or_dir), "tokenizer.json")
+    if os.path.isfile(tok_file):
+        tok = RobertaTokenizerFast(tokenizer_file=tok_file)
+    else:
+        tok = RobertaTokenizerFast.from_pretrained(name_or_dir, local_files_only=True)
+    pre = json.loads(tok.backend_tokenizer.to_str()).get("pre_tokenizer") or {}
+    if pre.get("type") != "ByteLevel":
+        raise RuntimeError(f"tokenizer from {name_or_dir!r} has pre-tokenizer {pre.get('type')!r}, RoBERTa's is ByteLevel")
+    return tok
+
+
+def encode_expressions(tokenizer, text_queries):
+    """The reference's `tokenizer.batch_encode_plus(text_queries, padding='longest', return_tensors='pt')`
+    (models/soc.py:104-106,168-169) -> (input_ids, attention_mask) int64 [B,L].  Spelled as the tokenizer's `__call__`,
+    which is the same method in transformers 4.x and the only one left in 5.x (`batch_encode_plus` is gone there)."""
+    tok = tokenizer(list(text_queries), padding="longest", return_tensors="pt")
+    return tok["input_ids"], tok["attention_mask"]
 
 
 class SOC(nn.Module):
@@ -173,8 +199,7 @@ class SOC(nn.Module):
             if self.tokenizer is None:
                 raise RuntimeError("no tokenizer files available offline: pass pre-tokenised "
                                    "{'input_ids', 'attention_mask'} tensors instead of strings")
-            tok = self.tokenizer.batch_encode_plus(list(text_queries), padding="longest", return_tensors="pt")
-            ids, attn = tok["input_ids"], tok["attention_mask"]
+            ids, attn = encode_expressions(self.tokenizer, text_queries)
         else:
             ids, attn = text_queries["input_ids"], text_queries["attention_mask"]
         ids, attn = ids.to(device), attn.to(device)

@@ -32,6 +32,46 @@ class HashTokenizer:
         return torch.tensor([ids], dtype=torch.long)
 
 
+def write_synthetic_roberta_tokenizer(path: str, words: Sequence[str] = WORDS) -> str:
+    """A directory `RobertaTokenizerFast.from_pretrained` loads offline: byte-level BPE with RoBERTa's special tokens
+    (<s> 0, <pad> 1, </s> 2, <unk> 3), RoBERTa's `<s> ... </s>` post-processing, and merges that build every word of
+    `words` (with its leading-space form) left to right.  The real roberta-base vocabulary cannot be fetched here; this one
+    exercises the same code path (models/soc.py:104-106,167-169) with ids of a different vocabulary."""
+    from tokenizers import Tokenizer, decoders, models, pre_tokenizers, processors
+    vocab = {"<s>": 0, "<pad>": 1, "</s>": 2, "<unk>": 3}
+    for ch in sorted(pre_tokenizers.ByteLevel.alphabet()):
+        vocab[ch] = len(vocab)
+    merges = []
+
+    def merge(a, b):
+        if (a, b) not in merges:
+            merges.append((a, b))
+            vocab.setdefault(a + b, len(vocab))
+    for word in words:
+        left = word[0]
+        for ch in word[1:]:
+            merge(left, ch)
+            left += ch
+    for word in words:                                  # "\u0120" is the byte-level image of the space in front of a word
+        merge("\u0120", word)
+    vocab["<mask>"] = len(vocab)
+    tk = Tokenizer(models.BPE(vocab=vocab, merges=merges, unk_token="<unk>"))
+    tk.pre_tokenizer = pre_tokenizers.ByteLevel(add_prefix_space=False)
+    tk.decoder = decoders.ByteLevel()
+    tk.post_processor = processors.RobertaProcessing(sep=("</s>", 2), cls=("<s>", 0), trim_offsets=True, add_prefix_space=False)
+    os.makedirs(path, exist_ok=True)
+    tk.save(os.path.join(path, "tokenizer.json"))
+    with open(os.path.join(path, "vocab.json"), "w") as f:
+        json.dump(vocab, f)
+    with open(os.path.join(path, "merges.txt"), "w") as f:
+        f.write("#version: 0.2\n" + "\n".join(a + " " + b for a, b in merges) + "\n")
+    with open(os.path.join(path, "tokenizer_config.json"), "w") as f:
+        json.dump({"tokenizer_class": "RobertaTokenizerFast", "bos_token": "<s>", "eos_token": "</s>", "pad_token": "<pad>",
+                   "unk_token": "<unk>", "cls_token": "<s>", "sep_token": "</s>", "mask_token": "<mask>",
+                   "model_max_length": 512}, f)
+    return path
+
+
 def _frame(rng, h, w, t):
     """blocky moving pattern + noise: compresses like a natural JPEG, differs per frame"""
     cells = rng.integers(0, 256, (h // 16 + 5, w // 16 + 10, 3))      # margin for t <= 64

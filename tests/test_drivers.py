@@ -153,3 +153,117 @@ def test_png_writers_formats(tmp_path):
     png = Image.open(tmp_path / "l.png")
     assert png.mode == "P" and np.array_equal(np.array(png), labels)
     assert png.getpalette()[:9] == [0, 0, 0, 128, 0, 0, 0, 128, 0]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The two seams of the reference's drivers that need files which cannot be fetched here: the RoBERTa tokenizer
+# (models/soc.py:104-106,167-181) and the on-disk checkpoint (infer_refytb.py:143-156).  Both are exercised with files the
+# tests write themselves.
+
+def test_roberta_tokenizer_from_synthetic_files(tmp_path):
+    """RobertaTokenizerFast from a vocab / merges the test writes: `<s> ... </s>` framing, padding='longest' with
+    <pad> = 1, attention_mask -> `ne(1)` pad mask as in SOC.forward_text."""
+    from neurips2023_soc_amd.infer import load_tokenizer
+    from neurips2023_soc_amd.soc import encode_expressions
+    tok_dir = SD.write_synthetic_roberta_tokenizer(str(tmp_path / "tok"))
+    assert {"tokenizer.json", "vocab.json", "merges.txt"} <= set(os.listdir(tok_dir))
+    tokenize = load_tokenizer(tok_dir)
+    short, long_ = "the dog", "a person riding the white car"
+    a, b = tokenize(short), tokenize(long_)
+    assert a.dtype == torch.long and a.shape == (1, 4) and b.shape[1] >= 8           # >= one id per word + <s> </s>
+    assert a[0, 0] == 0 and a[0, -1] == 2 and b[0, 0] == 0 and b[0, -1] == 2
+    assert tokenize.hf.convert_ids_to_tokens(a[0].tolist()) == ["<s>", "the", "Ġdog", "</s>"]
+    ids, attn = encode_expressions(tokenize.hf, [short, long_])
+    L = b.shape[1]
+    assert ids.shape == attn.shape == (2, L)
+    assert torch.equal(ids[1:], b) and torch.equal(ids[0, :4], a[0]) and bool((ids[0, 4:] == 1).all())
+    assert attn[0].tolist() == [1] * 4 + [0] * (L - 4) and attn.ne(1)[0, 4:].all() and not attn.ne(1)[1].any()
+    # a word outside the merges still encodes (byte-level pieces), nothing maps to <unk>
+    assert 3 not in tokenize("zebra crossing")[0].tolist()
+
+
+def test_reference_checkpoint_file_contract(tmp_path, synthetic_sd):
+    """torch.save({"model_state_dict": sd, ...}) with the profiler's total_params / total_ops buffers inside, loaded the
+    way the reference's drivers do (strict=False, those keys ignored): every parameter arrives, nothing else is reported."""
+    import neurips2023_soc_amd as S
+    from neurips2023_soc_amd.infer import load_checkpoint
+    src, _, _ = S.build_model(S.default_args(text_encoder_random_init=True))
+    src.load_state_dict(synthetic_sd, strict=False)
+    state = dict(src.state_dict())          # parameters + buffers (relative_position_index), as a trained checkpoint holds them
+    state["total_ops"] = torch.zeros(1, dtype=torch.float64)
+    state["backbone.0.total_params"] = torch.zeros(1, dtype=torch.float64)
+    path = str(tmp_path / "soc.pth")
+    torch.save({"model_state_dict": state, "epoch": 3, "optimizer_state_dict": {}}, path)
+    model, _, _ = S.build_model(S.default_args(text_encoder_random_init=True))
+    missing, unexpected = load_checkpoint(model, path)
+    assert missing == [] and unexpected == []
+    got = model.state_dict()
+    assert all(torch.equal(got[k], v) for k, v in src.state_dict().items())
+    # a real gap is still reported
+    del state["class_embed.0.bias"]
+    state["not_a_key"] = torch.zeros(1)
+    torch.save({"model_state_dict": state}, path)
+    model2, _, _ = S.build_model(S.default_args(text_encoder_random_init=True))
+    missing, unexpected = load_checkpoint(model2, path)
+    assert "class_embed.0.bias" in missing and unexpected == ["not_a_key"]
+
+
+@pytest.mark.gpu
+def test_forward_text_strings_equal_pretokenised_ids(gpu_model, tmp_path):
+    """SOC.forward_text on strings of different length (the tokenizer pads the batch) == the same ids fed directly."""
+    from neurips2023_soc_amd.soc import encode_expressions, load_roberta_tokenizer
+    model, _ = gpu_model
+    hf = load_roberta_tokenizer(SD.write_synthetic_roberta_tokenizer(str(tmp_path / "tok")))
+    texts = ["the dog", "a person riding the white car"]
+    old = model.tokenizer
+    model.tokenizer = hf
+    try:
+        words, sentence = model.forward_text(texts, "cuda")
+    finally:
+        model.tokenizer = old
+    ids, attn = encode_expressions(hf, texts)
+    words2, sentence2 = model.forward_text({"input_ids": ids, "attention_mask": attn}, "cuda")
+    assert words.tensors.shape == (ids.shape[1], 2, 256) and torch.equal(words.mask.cpu(), attn.ne(1))
+    assert torch.equal(words.tensors, words2.tensors) and torch.equal(sentence, sentence2)
+    # the padded short expression == that expression alone, on its own tokens (the mask keeps the pad out)
+    alone, s_alone = model.forward_text({"input_ids": ids[:1, :4], "attention_mask": attn[:1, :4]}, "cuda")
+    assert float((alone.tensors[:, 0] - words.tensors[:4, 0]).abs().max()) < 1e-4
+    assert float((s_alone[0] - sentence[0]).abs().max()) < 1e-4
+
+
+@pytest.mark.gpu
+def test_infer_cli_with_tokenizer_dir_and_checkpoint_file(gpu_model, tmp_path, monkeypatch, capsys):
+    """`python -m neurips2023_soc_amd.infer --dataset refytb --tokenizer DIR --checkpoint FILE` (the reference's
+    infer_refytb.py with its two file inputs) writes the same PNGs as the driver called with the synthetic weights loaded
+    in memory and the same token ids fed directly."""
+    from neurips2023_soc_amd import infer, infer_refytb
+    model, sd = gpu_model
+    root = SD.make_dataset(str(tmp_path / "data"), videos=2, frames=3, height=144, width=256, expressions=3, seed=11)
+    tok_dir = SD.write_synthetic_roberta_tokenizer(str(tmp_path / "tok"))
+    ckpt = str(tmp_path / "soc.pth")
+    state = dict(model.state_dict())
+    state["total_ops"] = torch.zeros(1, dtype=torch.float64)
+    state["total_params"] = torch.zeros(1, dtype=torch.float64)
+    torch.save({"model_state_dict": state}, ckpt)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    out_cli = str(tmp_path / "out_cli")
+    infer.main(["--dataset", "refytb", "--root", root, "--out", out_cli, "--tokenizer", tok_dir, "--checkpoint", ckpt])
+    printed = capsys.readouterr().out
+    assert "Missing Keys" not in printed and '"expressions": 6' in printed
+    # the same ids, computed here and handed over as tensors; expressions differ in length (3..8 words)
+    tokenize = infer.load_tokenizer(tok_dir)
+    _, data = infer_refytb.load_meta(root)
+    table = {e["exp"]: tokenize(e["exp"]) for item in data.values() for e in item["expressions"].values()}
+    assert len({v.shape[1] for v in table.values()}) > 1
+    out_ids = str(tmp_path / "out_ids")
+    infer_refytb.run(model, lambda text: table[text].clone(), root, out_ids)
+    n = 0
+    for video, item in data.items():
+        for exp_id in item["expressions"]:
+            for name in item["frames"]:
+                with open(os.path.join(out_cli, video, exp_id, name + ".png"), "rb") as f1, \
+                        open(os.path.join(out_ids, video, exp_id, name + ".png"), "rb") as f2:
+                    assert f1.read() == f2.read(), (video, exp_id, name)
+                n += 1
+    assert n == 18
