@@ -391,7 +391,7 @@ def main():
     f32_pass = None
     if graph is not None and not a.no_f32_pass and hot_ops.split_enabled():
         from neurips2023_soc_amd.graph_runner import ClipGraph, PipelinedClipGraph
-        hot_ops.MATMUL_MODE = "f32"
+        model.matmul_mode = "f32"        # a property of the model (thread-local inside its forward, a launch argument below)
         try:
             g32 = (PipelinedClipGraph if pipelined else ClipGraph)(model, T, H, Wd, L, dev)
             main_graph, graph = graph, g32
@@ -403,7 +403,7 @@ def main():
             graph = main_graph
             del g32
         finally:
-            hot_ops.MATMUL_MODE = "split"
+            model.matmul_mode = None
 
     # The dominant kernel families: replay the launches of ONE forward back to back between one HIP-event pair on the launch
     # stream (per-launch event pairs add host / queue latency to 30-400 us kernels), with the forward's own tensors.  Every

@@ -7,7 +7,11 @@
  *   - plain C, no torch types; every pointer is a DEVICE pointer unless stated otherwise;
  *   - inputs are borrowed, outputs are caller-allocated and fully overwritten;
  *   - asynchronous on `stream` (a hipStream_t passed as void*; NULL = the null stream);
- *   - stateless / thread-safe; forward only (the reference's backward is training-only);
+ *   - stateless / thread-safe: no entry point sets or reads caller-visible process state -- every mode (e.g. the `split`
+ *     arithmetic switch of K1 / K13) is an argument of the launch it applies to (ABI 16; ABI <= 15 had three process-wide
+ *     setters).  What the library caches internally (CU count, kernel attributes, launch plans per geometry) is keyed per
+ *     device and guarded;
+ *   - forward only, except soc_msda_bwd_* (the reference's other backward paths are training-only);
  *   - return 0 on success, a negative SOC_E* code otherwise (soc_hip_error_string()).
  *
  * Each function cites the reference interface it replaces (paths relative to the reference repo).
@@ -22,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SOC_HIP_ABI_VERSION 15
+#define SOC_HIP_ABI_VERSION 16
 
 #define SOC_OK 0
 #define SOC_EINVAL (-1)       /* null pointer / non-positive dimension */
@@ -32,14 +36,6 @@ extern "C" {
 
 int soc_hip_abi_version(void);
 
-/*
- * CUs left free by the persistent kernels (one workgroup per CU for a whole launch: K13 / K13b, K20, K23, K24): their grids
- * are sized for the device's CU count minus this reserve, so that the short launches of a concurrent stream -- the query
- * chain of the previous clip and the text branch in the software pipeline of graph_runner.PipelinedClipGraph -- find a CU at
- * once.  Process-wide, read at launch time; 0 (default) = every CU.  At most half the chip can be reserved.
- */
-void soc_set_reserved_cus(int n);
-int soc_get_reserved_cus(void);
 const char* soc_hip_error_string(int code);
 
 /*
@@ -120,11 +116,14 @@ int soc_msda_fused_fwd_f32(const float* value, const uint8_t* value_pad_mask, co
  * tab_* is the module's nominal window (8,7,7) that sizes the bias table and defines the
  * `relative_position_index[:N,:N]` slicing rule (:151).  head_dim = C / n_heads must be 32;
  * win_d*win_h*win_w <= 400.  Shift mask value is -100 (:328), not -inf.
+ * split: arithmetic of THIS launch (full 8x7x7 windows only, ignored otherwise): != 0 = scores and P.V on the bf16 matrix
+ * cores with every f32 operand split exactly into three bf16 terms (six products, f32 accumulation: f32-level error, see
+ * K20 below); 0 = the f32-input MFMA form.  Same results to f32 rounding.
  */
 int soc_win_attn3d_f32(const float* qkv, const float* qkv_bias, const float* bias_table,
                        float* out, int B, int D, int H, int W, int C, int n_heads, int win_d,
                        int win_h, int win_w, int shift_d, int shift_h, int shift_w, int tab_d,
-                       int tab_h, int tab_w, void* stream);
+                       int tab_h, int tab_w, int split, void* stream);
 
 /*
  * K3 -- multi-head attention core softmax(q k^T / sqrt(d)) v on already-projected tensors,
@@ -248,7 +247,8 @@ int soc_patch_merge_layernorm_f32(const float* x, const float* gamma, const floa
  * K23 -- a two-layer perceptron block in one launch, on the bf16 matrix cores (exact three-way operand split, f32-grade
  * results -- see soc_linear_split_f32):
  *     out = LN2(act(LN(x) W1^T + b1) W2^T + b2 + residual),   act 1 = ReLU, 2 = exact (erf) GELU;  LN, LN2, residual optional;
- *     with residual_ln != 0 the shortcut is LN(residual) (the same LayerNorm as in front of W1) instead of residual itself.
+ *     with residual_ln != 0 the shortcut is LN(x) (the same LayerNorm as in front of W1) instead of x itself: `residual` must
+ *     then be x (the same pointer), anything else is SOC_EINVAL.
  * Replaces  x + mlp(norm2(x))  of SwinTransformerBlock3D.forward_part2 (models/video_swin_transformer.py:262-272 with
  * Mlp.forward :24-37: norm2, fc1, nn.GELU, fc2, the residual add) and linear1 -> ReLU -> linear2 of
  * DeformableTransformerEncoderLayer.forward_ffn (models/deformable_transformer.py:253-263) with the residual add and norm2
@@ -274,6 +274,9 @@ int soc_mlp_split_f32(const float* x, const void* packed, const float* b1, const
                       const float* ln_beta, float ln_eps, const float* residual, const float* post_gamma,
                       const float* post_beta, float post_eps, float* out, float* out_sum, float* workspace,
                       size_t workspace_bytes, long M, int C, int F, int act, int residual_ln, void* stream);
+/* Largest hidden width F soc_mlp_split_f32 takes at model width C (the b1 range of a workgroup shares the 160 KB of LDS with
+ * the weight ring); 0 for a width K23 is not built for.  Pure function of C.  F beyond it: SOC_EUNSUPPORTED at launch. */
+int soc_mlp_split_max_hidden(int C);
 int soc_mlp_split_variant_f32(const float* x, const void* packed, const float* b1, const float* b2, const float* ln_gamma,
                               const float* ln_beta, float ln_eps, const float* residual, const float* post_gamma,
                               const float* post_beta, float post_eps, float* out, float* out_sum, float* workspace, long M,
@@ -393,14 +396,12 @@ int soc_box_refine_f32(const float* delta, const float* ref, int ref_dim, const 
  * 2 exact (erf) GELU as nn.GELU().  The weights are staged once per workgroup in LDS and the rows of x stream
  * through in MFMA operand layout.  K in {96, 128, 192, 256, 384, 512} (LayerNorm: K <= 256), N % 16 == 0, 16-byte
  * aligned pointers; otherwise SOC_EUNSUPPORTED (use the library GEMM).  out may alias residual.
+ * split: arithmetic of THIS launch: != 0 = the widths K13b covers (K = 96 / 128 / 192 / 256 ...) run on the bf16 matrix cores
+ * with the exact three-way operand split (f32-grade results, see soc_linear_split_f32); 0 = f32-input MFMA for every width.
  */
 int soc_ws_linear_f32(const float* x, const float* ln_gamma, const float* ln_beta, float ln_eps, const float* w,
-                      const float* bias, const float* residual, float* out, long M, int N, int K, int act,
+                      const float* bias, const float* residual, float* out, long M, int N, int K, int act, int split,
                       void* stream);
-/* Process-wide switch for K13's arithmetic: 1 (default) = K = 96 / 128 layers run on the bf16 matrix cores with the exact
- * three-way operand split (K13b, f32-grade results, see soc_linear_split_f32); 0 = f32-input MFMA for every width. */
-void soc_ws_linear_set_split(int on);
-int soc_ws_linear_get_split(void);
 
 /*
  * K15 -- the cross-attention block of a deformable-decoder layer in one launch (reference
@@ -482,14 +483,6 @@ int soc_upsample_add_tokens_f32(const float* lateral, const float* bias, const f
  */
 int soc_conv3x3_tokens_f32(const float* in, long in_frame_stride, const float* w_taps, const float* bias, float* out,
                            int N, int H, int W, int Cin, int Cout, int out_nchw, int relu, void* stream);
-
-/*
- * K1 arithmetic switch (process-wide, full 8x7x7 windows only): 1 (default) = scores and P.V on the bf16 matrix cores with
- * every f32 operand split exactly into three bf16 terms (six products, f32 accumulation: f32-level error, see K20 below);
- * 0 = the f32-input MFMA form of rounds 1-2.  Same results to f32 rounding; soc_win_attn3d_f32 reads it per launch.
- */
-void soc_win_attn3d_set_split(int on);
-int soc_win_attn3d_get_split(void);
 
 /*
  * K20 -- the pixel-sized f32 linear layers on the bf16 matrix cores by EXACT operand splitting (f32 in, f32 out, f32

@@ -17,15 +17,15 @@ EXPORTS = ("soc_hip_abi_version", "soc_hip_error_string", "soc_msda_fwd_f32", "s
            "soc_upsample_merge_labels_u8", "soc_resize_workspace_bytes", "soc_resize_normalize_u8_f32",
            "soc_msda_bwd_f32", "soc_msda_bwd_f64", "soc_groupnorm_tokens_workspace_bytes",
            "soc_groupnorm_tokens_f32", "soc_patch_merge_layernorm_f32", "soc_patch_embed_layernorm_f32", "soc_linear_act_f32",
-           "soc_linear_act_multi_f32", "soc_ws_linear_f32", "soc_ws_linear_set_split", "soc_ws_linear_get_split", "soc_decoder_cross_attn_f32",
+           "soc_linear_act_multi_f32", "soc_ws_linear_f32", "soc_decoder_cross_attn_f32",
            "soc_row_mlp_f32", "soc_groupnorm_nchw_f32", "soc_upsample_add_nchw_f32",
            "soc_upsample_add_tokens_f32", "soc_conv3x3_tokens_f32", "soc_linear_split_packed_bytes",
-           "soc_linear_split_pack_f32", "soc_row_stats_f32", "soc_linear_split_f32", "soc_win_attn3d_set_split",
-           "soc_win_attn3d_get_split", "soc_mlp_split_packed_bytes", "soc_mlp_split_pack_f32",
-           "soc_mlp_split_workspace_bytes", "soc_mlp_split_plan", "soc_mlp_split_f32", "soc_mlp_split_variant_f32",
+           "soc_linear_split_pack_f32", "soc_row_stats_f32", "soc_linear_split_f32",
+           "soc_mlp_split_packed_bytes", "soc_mlp_split_pack_f32",
+           "soc_mlp_split_workspace_bytes", "soc_mlp_split_plan", "soc_mlp_split_max_hidden", "soc_mlp_split_f32", "soc_mlp_split_variant_f32",
            "soc_xs_linear_packed_bytes", "soc_xs_linear_pack_f32", "soc_xs_linear_plan", "soc_xs_linear_f32",
-           "soc_set_reserved_cus", "soc_get_reserved_cus", "soc_small_attn_f32")
-ABI_VERSION = 15
+           "soc_small_attn_f32")
+ABI_VERSION = 16
 SOC_EUNSUPPORTED = -2      # include/soc_hip.h: shape outside what the kernel is built for
 
 _lib = None
@@ -58,6 +58,8 @@ def load() -> C.CDLL:
             raise SocHipError(f"libsoc_hip.so does not export {name}")
     p, i, f = C.c_void_p, C.c_int, C.c_float
     lib.soc_hip_abi_version.restype = i
+    lib.soc_mlp_split_max_hidden.restype = i
+    lib.soc_mlp_split_max_hidden.argtypes = [i]
     lib.soc_hip_error_string.restype = C.c_char_p
     lib.soc_hip_error_string.argtypes = [i]
     for fn in (lib.soc_msda_fwd_f32, lib.soc_msda_fwd_f64):
@@ -67,7 +69,7 @@ def load() -> C.CDLL:
         fn.restype = i
         fn.argtypes = [p] * 9 + [i] * 7 + [p]
     lib.soc_win_attn3d_f32.restype = i
-    lib.soc_win_attn3d_f32.argtypes = [p, p, p, p] + [i] * 15 + [p]
+    lib.soc_win_attn3d_f32.argtypes = [p, p, p, p] + [i] * 16 + [p]      # ... tab_w, split, stream
     lib.soc_xattn_workspace_bytes.restype = C.c_size_t
     lib.soc_xattn_workspace_bytes.argtypes = [i] * 5
     lib.soc_xattn_f32.restype = i
@@ -77,11 +79,7 @@ def load() -> C.CDLL:
     lib.soc_msda_fused_fwd_f32.restype = i
     lib.soc_msda_fused_fwd_f32.argtypes = [p, p, p, p, p, p, i, p, p, p, i, i, i, i, i, i, i, p]
     lib.soc_ws_linear_f32.restype = i
-    lib.soc_ws_linear_f32.argtypes = [p, p, p, f, p, p, p, p, C.c_long, i, i, i, p]
-    lib.soc_ws_linear_set_split.restype = None
-    lib.soc_ws_linear_set_split.argtypes = [i]
-    lib.soc_ws_linear_get_split.restype = i
-    lib.soc_ws_linear_get_split.argtypes = []
+    lib.soc_ws_linear_f32.argtypes = [p, p, p, f, p, p, p, p, C.c_long, i, i, i, i, p]    # ... act, split, stream
     lib.soc_decoder_cross_attn_f32.restype = i
     lib.soc_decoder_cross_attn_f32.argtypes = [p, p, i, p, i, p, p, p, p, p] + [p] * 10 + [f, p] + [i] * 7 + [p]
     lib.soc_row_mlp_f32.restype = i
@@ -142,10 +140,6 @@ def load() -> C.CDLL:
     lib.soc_linear_act_f32.argtypes = [p, p, p, p, i, i, i, i, p]
     lib.soc_linear_act_multi_f32.restype = i
     lib.soc_linear_act_multi_f32.argtypes = [p, p, i, p, p, p, p, i, i, i, p]
-    lib.soc_win_attn3d_set_split.restype = None
-    lib.soc_win_attn3d_set_split.argtypes = [i]
-    lib.soc_win_attn3d_get_split.restype = i
-    lib.soc_win_attn3d_get_split.argtypes = []
     lib.soc_linear_split_packed_bytes.restype = C.c_size_t
     lib.soc_linear_split_packed_bytes.argtypes = [i, i]
     lib.soc_linear_split_pack_f32.restype = i
@@ -156,13 +150,8 @@ def load() -> C.CDLL:
     lib.soc_linear_split_f32.argtypes = [p] * 10 + [i, C.c_long, i, i, i, i, p]
     lib.soc_small_attn_f32.restype = i
     lib.soc_small_attn_f32.argtypes = [p, p, p, p, p, i, i, i, i, f, C.c_long, C.c_long, p]
-    lib.soc_set_reserved_cus.restype = None
-    lib.soc_set_reserved_cus.argtypes = [i]
-    lib.soc_get_reserved_cus.restype = i
-    lib.soc_get_reserved_cus.argtypes = []
     if lib.soc_hip_abi_version() != ABI_VERSION:
         raise SocHipError("libsoc_hip.so ABI version mismatch; rebuild it")
-    lib.soc_set_reserved_cus(int(os.environ.get("SOC_RESERVED_CUS", "0")))
     _lib = lib
     return lib
 

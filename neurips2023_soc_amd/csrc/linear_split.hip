@@ -493,7 +493,7 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict_
     }
 }
 
-int num_cus() { return soc_num_cus(); }      // device CUs minus the host's reserve (soc_capi.hip)
+int num_cus() { return soc_num_cus(); }      // CUs of the current device (soc_capi.hip)
 
 template <int MT, int NT, int WM, int WN>
 int launch_cfg(const SplitParams& p0, hipStream_t st) {

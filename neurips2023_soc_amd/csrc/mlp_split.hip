@@ -537,7 +537,7 @@ __global__ __launch_bounds__(256) void mlp_pack_kernel(const float* __restrict__
     }
 }
 
-int num_cus() { return soc_num_cus(); }      // device CUs minus the host's reserve (soc_capi.hip)
+int num_cus() { return soc_num_cus(); }      // CUs of the current device (soc_capi.hip)
 
 // The shipped form of a width: waves per workgroup and row tiles per wave.  256-register waves (NW = 8) hold the x fragments
 // (3 C / 8 registers per tile) and the output accumulators (C / 4 per tile) of RT tiles up to C = 256; C = 384 needs the 512
@@ -691,6 +691,26 @@ static long tail_start(long M, int C, int cus) {
     return M;
 }
 
+// Largest hidden width the one-range form (nfs == 1, what whole rounds run) holds in 160 KB of LDS beside its weight ring:
+// ring + gamma / beta + 4 bytes of b1 per hidden unit (lds_bytes above).
+template <int C>
+static int max_hidden() {
+    const size_t fixed = (size_t)form_ns<C>() * (Geo<C>::BLKP_U4 / form_sb(C)) * 16 + 8 * C;
+    return (int)((160 * 1024 - fixed) / 128) * 32;
+}
+
+extern "C" int soc_mlp_split_max_hidden(int C) {
+    switch (C) {
+        case 96: return max_hidden<96>();
+        case 128: return max_hidden<128>();
+        case 192: return max_hidden<192>();
+        case 256: return max_hidden<256>();
+        case 384: return max_hidden<384>();
+        case 512: return max_hidden<512>();
+        default: return 0;
+    }
+}
+
 extern "C" int soc_mlp_split_plan(long M, int C, int F, int* nrg_out, int* nfs_out) {
     if (!width_ok(C) || F <= 0 || F % 32 != 0 || M <= 0 || !nrg_out || !nfs_out) return SOC_EUNSUPPORTED;
     plan_rows(M, C, F, num_cus(), nrg_out, nfs_out);
@@ -717,6 +737,9 @@ extern "C" int soc_mlp_split_variant_f32(const float* x, const void* packed, con
         (post_gamma == nullptr) != (post_beta == nullptr) || (out_sum && !post_gamma) ||
         (residual_ln && (!residual || !ln_gamma)))
         return SOC_EINVAL;
+    // residual_ln: the shortcut is LN(x) -- the block kernel takes the row statistics from x, the reduce kernel from the
+    // residual rows; the two agree only for residual == x, so anything else is refused rather than plan-dependent
+    if (residual_ln && residual != x) return SOC_EINVAL;
     if (!width_ok(C) || F % 32 != 0 || (act != 1 && act != 2)) return SOC_EUNSUPPORTED;
     if ((((uintptr_t)x | (uintptr_t)packed | (uintptr_t)b1 | (uintptr_t)b2 | (uintptr_t)residual | (uintptr_t)out |
           (uintptr_t)ln_gamma | (uintptr_t)ln_beta | (uintptr_t)post_gamma | (uintptr_t)post_beta | (uintptr_t)workspace |

@@ -15,13 +15,9 @@ extern "C" const char* soc_hip_error_string(int code) {
 }
 
 // CUs the persistent kernels (one workgroup per CU for a whole launch: K13 / K13b, K20, K23, K24) size their grids for: the
-// device's count minus a reserve the host may ask for, so that the short launches of a side stream (the query chain of the
-// previous clip, the text branch) find a free CU at once instead of waiting for a 100-300 us workgroup to retire.
+// current device's count (a cache of a device attribute -- no caller-visible state).  A host-settable reserve for the side
+// stream's short launches was measured null in round 4 and left the ABI with ABI 16.
 #include <atomic>
-static std::atomic<int> g_reserved_cus{0};
-
-extern "C" void soc_set_reserved_cus(int n) { g_reserved_cus.store(n < 0 ? 0 : n, std::memory_order_relaxed); }
-extern "C" int soc_get_reserved_cus(void) { return g_reserved_cus.load(std::memory_order_relaxed); }
 
 int soc_num_cus() {
     static std::atomic<int> cached[SOC_MAX_DEVICES];      // 0 = not queried yet; per device
@@ -36,6 +32,5 @@ int soc_num_cus() {
             cached[dev].store(n, std::memory_order_relaxed);
         }
     }
-    const int r = g_reserved_cus.load(std::memory_order_relaxed);
-    return n - r >= n / 2 ? n - r : n / 2;                 // never less than half the chip
+    return n;
 }

@@ -22,5 +22,5 @@ static inline int soc_current_device() {
     return dev;
 }
 
-// defined in soc_capi.hip: the CU count persistent kernels size their grids for (device count minus soc_set_reserved_cus())
+// defined in soc_capi.hip: the CU count persistent kernels size their grids for (of the current device)
 int soc_num_cus();

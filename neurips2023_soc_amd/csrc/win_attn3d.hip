@@ -1499,13 +1499,7 @@ Plan plan_schedule(long pairs, int NT, int cus, bool shared_last, bool split) {
 int g_force_n_main = 0, g_force_qsplit = 0;
 #endif
 
-// full 8x7x7 windows: 1 = the bf16 matrix-core form (exact three-way operand split), 0 = the f32 MFMA form
-std::atomic<int> g_k1_split{1};
-
 }  // namespace
-
-extern "C" void soc_win_attn3d_set_split(int on) { g_k1_split.store(on ? 1 : 0, std::memory_order_relaxed); }
-extern "C" int soc_win_attn3d_get_split(void) { return g_k1_split.load(std::memory_order_relaxed); }
 
 #ifdef SOC_K1_TUNE
 extern "C" void soc_debug_force_k1_plan(int n_main, int qsplit) { g_force_n_main = n_main; g_force_qsplit = qsplit; }
@@ -1514,7 +1508,7 @@ extern "C" void soc_debug_force_k1_plan(int n_main, int qsplit) { g_force_n_main
 extern "C" int soc_win_attn3d_f32(const float* qkv, const float* qkv_bias, const float* bias_table,
                                   float* out, int B, int D, int H, int W, int C, int n_heads,
                                   int win_d, int win_h, int win_w, int shift_d, int shift_h,
-                                  int shift_w, int tab_d, int tab_h, int tab_w, void* stream) {
+                                  int shift_w, int tab_d, int tab_h, int tab_w, int split_arith, void* stream) {
     if (!qkv || !qkv_bias || !bias_table || !out) return SOC_EINVAL;
     if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0 || n_heads <= 0) return SOC_EINVAL;
     if (win_d <= 0 || win_h <= 0 || win_w <= 0 || tab_d <= 0 || tab_h <= 0 || tab_w <= 0) return SOC_EINVAL;
@@ -1540,7 +1534,7 @@ extern "C" int soc_win_attn3d_f32(const float* qkv, const float* qkv_bias, const
     if ((long)B * D * H * W * 3 * C >= (1L << 31)) return SOC_EUNSUPPORTED;  // int token offsets
     const long pairs = (long)B * p.nwd * p.nwh * p.nww * n_heads;
     const bool full_window = win_d == 8 && win_h == 7 && win_w == 7 && tab_d == 8 && tab_h == 7 && tab_w == 7;
-    const bool split = full_window && g_k1_split.load(std::memory_order_relaxed) != 0;
+    const bool split = full_window && split_arith != 0;     // full 8x7x7 windows only; a launch argument, not process state
     {
         const Plan pl = plan_schedule(pairs, p.NT, num_cus(), full_window, split);
         p.n_main = pl.n_main;

@@ -178,7 +178,7 @@ __global__ __launch_bounds__(THREADS, 2) void ws_linear_kernel(
     }
 }
 
-int num_cus() { return soc_num_cus(); }      // device CUs minus the host's reserve (soc_capi.hip)
+int num_cus() { return soc_num_cus(); }      // CUs of the current device (soc_capi.hip)
 
 // columns of W per workgroup: even ranges, multiples of 16, that fit the LDS; 0 if N cannot be split that way
 int split_columns(int N, int K) {
@@ -253,13 +253,10 @@ int launch_act(int act, const float* x, const float* gamma, const float* beta, f
 int soc_ws_linear_split_dispatch(const float* x, const float* ln_gamma, const float* ln_beta, float ln_eps, const float* w,
                                  const float* bias, const float* residual, float* out, long M, int N, int K, int act,
                                  hipStream_t st);
-static std::atomic<int> g_ws_split{1};
-extern "C" void soc_ws_linear_set_split(int on) { g_ws_split.store(on != 0, std::memory_order_relaxed); }
-extern "C" int soc_ws_linear_get_split(void) { return g_ws_split.load(std::memory_order_relaxed); }
 
 extern "C" int soc_ws_linear_f32(const float* x, const float* ln_gamma, const float* ln_beta, float ln_eps,
                                  const float* w, const float* bias, const float* residual, float* out, long M,
-                                 int N, int K, int act, void* stream) {
+                                 int N, int K, int act, int split_arith, void* stream) {
     if (M < 0 || N <= 0 || K <= 0 || act < 0 || act > 2) return SOC_EINVAL;
     if ((ln_gamma == nullptr) != (ln_beta == nullptr)) return SOC_EINVAL;
     if (M == 0) return SOC_OK;                        // empty input: nothing to launch (pointers may be null)
@@ -269,7 +266,7 @@ extern "C" int soc_ws_linear_f32(const float* x, const float* ln_gamma, const fl
           (uintptr_t)ln_beta) & 15) != 0)
         return SOC_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    if (g_ws_split.load(std::memory_order_relaxed)) {
+    if (split_arith != 0) {
         const int rc = soc_ws_linear_split_dispatch(x, ln_gamma, ln_beta, ln_eps, w, bias, residual, out, M, N, K, act, st);
         if (rc != SOC_EUNSUPPORTED) return rc;
     }

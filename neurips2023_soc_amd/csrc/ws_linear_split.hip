@@ -243,7 +243,7 @@ __global__ __launch_bounds__(THREADS, 2) void ws_linear_split_kernel(
     __syncthreads();        // the waves retire together: no foreign wave beside a partner that still issues MFMAs
 }
 
-int num_cus() { return soc_num_cus(); }      // device CUs minus the host's reserve (soc_capi.hip)
+int num_cus() { return soc_num_cus(); }      // CUs of the current device (soc_capi.hip)
 
 // columns of W per workgroup: even ranges, multiples of 16, whose three planes (+ bias) fit the LDS; 0 if impossible.
 // K > 256 (rows split step by step): a range is ONE group of 3, 2 or 1 column tiles.

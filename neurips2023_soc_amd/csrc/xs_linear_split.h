@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void xs_pack_kernel(const float* __restrict__ 
     }
 }
 
-int num_cus() { return soc_num_cus(); }      // device CUs minus the host's reserve (soc_capi.hip)
+int num_cus() { return soc_num_cus(); }      // CUs of the current device (soc_capi.hip)
 
 using soc_xs::Args;
 

@@ -450,10 +450,10 @@ def window_attention3d(qkv: Tensor, qkv_bias: Tensor, bias_table: Tensor, n_head
     # algorithmic FLOPs: QK^T + PV = 4 * N^2 * head_dim per (window, head)
     n_win = B * -(-D // win[0]) * -(-H // win[1]) * -(-W // win[2])
     n_tok = win[0] * win[1] * win[2]
-    lib.soc_win_attn3d_set_split(int(k1_split_enabled()))
     with _timed("win_attn3d", 4.0 * n_tok * n_tok * (C // n_heads) * n_win * n_heads):
         code = lib.soc_win_attn3d_f32(qkv.data_ptr(), qkv_bias.data_ptr(), bias_table.data_ptr(),
-                                      out.data_ptr(), B, D, H, W, C, n_heads, *win, *sh, *window, _stream())
+                                      out.data_ptr(), B, D, H, W, C, n_heads, *win, *sh, *window,
+                                      int(k1_split_enabled()), _stream())
     _lib.check(code, "soc_win_attn3d_f32")
     return out
 
@@ -855,7 +855,6 @@ def ws_linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, ln: Opti
     b = _f32c(bias) if bias is not None else None
     code = {"none": 0, "relu": 1, "gelu": 2}[act]
     work = 2.0 * M * N * K
-    lib.soc_ws_linear_set_split(int(k13_split_enabled()))          # K13b where it covers the width
     if _k13_calls is not None:
         _k13_calls.append(dict(x=x, weight=weight, bias=bias, ln=ln, residual=residual, act=act))
     with _timed("ws_linear", work):
@@ -863,7 +862,7 @@ def ws_linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, ln: Opti
                                    be.data_ptr() if be is not None else None, eps, weight.data_ptr(),
                                    b.data_ptr() if b is not None else None,
                                    residual.data_ptr() if residual is not None else None, out.data_ptr(), M, N, K, code,
-                                   _stream())
+                                   int(k13_split_enabled()), _stream())      # split: K13b where it covers the width
     _lib.check(rc, "soc_ws_linear_f32")
     return out
 
@@ -874,17 +873,48 @@ import os as _os
 
 # "split" (default): the pixel-sized linear layers listed in split_wins() run on K20; "f32": every GEMM stays on the f32
 # MFMA path (K13 / K12 / library), i.e. the round-2 arithmetic.  bench.py reports both.
-MATMUL_MODE = _os.environ.get("SOC_MATMUL", "split")
+#
+# The mode is NOT process state: it belongs to a model (SOC.matmul_mode) and reaches the ops through a thread-local that the
+# model's forward sets for its own duration (use_matmul_mode), and it reaches the C ABI as an argument of each launch.  Two
+# models with different modes can therefore run from two threads of one process (tests/test_gpu_forward.py).  The environment
+# variable only supplies the default a model is built with.
+import contextlib as _contextlib
+import threading as _threading
+
+DEFAULT_MATMUL_MODE = _os.environ.get("SOC_MATMUL", "split")
+_mode_tls = _threading.local()
+
+
+def matmul_mode() -> str:
+    """The arithmetic of the calling thread's current forward: "split" or "f32"."""
+    return getattr(_mode_tls, "mode", None) or DEFAULT_MATMUL_MODE
+
+
+@_contextlib.contextmanager
+def use_matmul_mode(mode):
+    """`with use_matmul_mode("f32"):` -- the ops called from THIS thread inside the block run in that arithmetic (None =
+    leave it as it is).  Nests; other threads are unaffected."""
+    if mode is None:
+        yield
+        return
+    if mode not in ("split", "f32"):
+        raise ValueError(f"matmul mode {mode!r}: expected 'split' or 'f32'")
+    prev = getattr(_mode_tls, "mode", None)
+    _mode_tls.mode = mode
+    try:
+        yield
+    finally:
+        _mode_tls.mode = prev
 
 
 def split_enabled() -> bool:
-    return MATMUL_MODE == "split"
+    return matmul_mode() == "split"
 
 
 def k1_split_enabled() -> bool:
     """K1 (full 8x7x7 windows) on the bf16 matrix cores with the exact three-way split; SOC_SPLIT_OFF=k1 or
     SOC_MATMUL=f32 keep the f32-input MFMA form."""
-    return MATMUL_MODE == "split" and "k1" not in _os.environ.get("SOC_SPLIT_OFF", "").split(",")
+    return split_enabled() and "k1" not in _os.environ.get("SOC_SPLIT_OFF", "").split(",")
 
 
 _SPLIT_OFF = set(filter(None, _os.environ.get("SOC_SPLIT_OFF", "").split(",")))   # debugging: sites forced back to f32
@@ -1152,12 +1182,24 @@ _MLP_ACT = {"relu": 1, "gelu": 2}
 _mlp_cache = DerivedCache()
 
 
+_mlp_max_hidden = {}
+
+
+def mlp_split_max_hidden(Cw: int) -> int:
+    """Largest hidden width K23 holds at model width Cw (its b1 range shares the 160 KB of LDS with the weight ring): beyond it
+    the launch would return SOC_EUNSUPPORTED, so the router must not send the layer there."""
+    if Cw not in _mlp_max_hidden:
+        _mlp_max_hidden[Cw] = int(_lib.load().soc_mlp_split_max_hidden(int(Cw)))
+    return _mlp_max_hidden[Cw]
+
+
 def mlp_split_supported(x: Tensor, w1: Tensor, w2: Tensor) -> bool:
     """K23 takes act(LN(x) w1^T + b1) w2^T + b2 (+ residual): CUDA fp32, model width 96 / 128 / 192 / 256 / 384 / 512, hidden width a
-    multiple of 32, split arithmetic on (SOC_SPLIT_OFF=mlp switches it off)."""
+    multiple of 32 up to mlp_split_max_hidden(width), split arithmetic on (SOC_SPLIT_OFF=mlp switches it off)."""
     Cw = x.shape[-1]
     return (x.is_cuda and x.dtype == torch.float32 and split_enabled() and "mlp" not in _SPLIT_OFF and Cw in MLP_SPLIT_C
             and tuple(w1.shape[1:]) == (Cw,) and tuple(w2.shape) == (Cw, w1.shape[0]) and w1.shape[0] % 32 == 0
+            and w1.shape[0] <= mlp_split_max_hidden(Cw)
             and w1.dtype == torch.float32 and w2.dtype == torch.float32)
 
 
@@ -1181,8 +1223,8 @@ def mlp_split(x: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor, act: st
               post_ln: Optional[Tuple[Tensor, Tensor, float]] = None, return_sum: bool = False, residual_ln: bool = False):
     """K23: LN2(act(LN(x) @ w1.T + b1) @ w2.T + b2 + residual) in one launch, the hidden layer in registers; ln / post_ln =
     (gamma, beta, eps) or None, act "relu" | "gelu".  With post_ln and return_sum the result is (sum in front of LN2, LN2(sum)).
-    residual_ln: the shortcut is LN(residual) -- the LayerNorm `ln` -- instead of residual itself (the encoder's norm1, whose result
-    is both the block's input and its shortcut).  `cut` = (workgroup rows, hidden ranges) forces one launch with that decomposition
+    residual_ln: the shortcut is LN(x) -- the LayerNorm `ln` -- instead of x itself (the encoder's norm1, whose result is both the
+    block's input and its shortcut); `residual` must then be x itself (same storage), anything else is refused.  `cut` = (workgroup rows, hidden ranges) forces one launch with that decomposition
     (tests, probes); by default the library plans whole rounds + a split tail."""
     _need_gpu(x, w1, b1, w2, b2, residual, *(ln[:2] if ln else ()), *(post_ln[:2] if post_ln else ()))
     lib = _lib.load()
@@ -1212,6 +1254,8 @@ def mlp_split(x: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor, act: st
         raise _lib.SocHipError("mlp_split: return_sum needs post_ln (without it the result is the sum)")
     if residual_ln and (ln is None or residual is None):
         raise _lib.SocHipError("mlp_split: residual_ln needs both ln and residual")
+    if residual_ln and residual.data_ptr() != x.data_ptr():
+        raise _lib.SocHipError("mlp_split: residual_ln means 'the shortcut is LN(x)': residual must be x itself")
     osum = torch.empty_like(x) if return_sum else None
     if _k23_calls is not None:
         _k23_calls.append(dict(x=x, w1=w1, b1=b1, w2=w2, b2=b2, act=act, ln=ln, residual=residual, post_ln=post_ln, cut=cut,

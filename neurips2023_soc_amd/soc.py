@@ -86,6 +86,18 @@ def _load_text_stack(config):
         return RobertaModel(roberta_base_config()), None
 
 
+def _in_model_mode(method):
+    """Run a stage of the forward in the model's own arithmetic (SOC.matmul_mode; hot_ops.use_matmul_mode is thread-local,
+    so two models with different modes can run from two threads)."""
+    import functools
+
+    @functools.wraps(method)
+    def wrapped(self, *args, **kwargs):
+        with hot_ops.use_matmul_mode(self.matmul_mode):
+            return method(self, *args, **kwargs)
+    return wrapped
+
+
 def load_roberta_tokenizer(name_or_dir):
     """`RobertaTokenizerFast.from_pretrained(name_or_dir)` (models/soc.py:104), offline.  A directory that holds a
     `tokenizer.json` is loaded from that file: transformers 5.x's `from_pretrained` rebuilds the backend from vocab /
@@ -180,6 +192,9 @@ class SOC(nn.Module):
             nn.init.zeros_(layer.bias)
             nn.init.xavier_uniform_(layer.weight)
         self.vl_loss, self.aux_loss = config.vl_loss, config.aux_loss
+        # "split" | "f32" | None (= hot_ops.DEFAULT_MATMUL_MODE, i.e. SOC_MATMUL or "split"): the arithmetic of THIS model's
+        # large products; an attribute of the model, handed to every launch as an argument (ABI 16), not process state
+        self.matmul_mode = getattr(config, "matmul_mode", None)
 
     def _side_stream(self, device):
         """One side stream per (device, calling stream): forwards issued on different streams (several
@@ -251,6 +266,7 @@ class SOC(nn.Module):
         return self.forward_fuse_encode(self.forward_backbone(samples, valid_indices, text_queries))
 
     @torch.no_grad()
+    @_in_model_mode
     def forward_backbone(self, samples: NestedTensor, valid_indices, text_queries, fork: bool = True):
         """Stage A: RoBERTa ‖ Video-Swin.  -> state for forward_fuse_encode."""
         if self.training:
@@ -282,6 +298,7 @@ class SOC(nn.Module):
                 "unpadded": bool(getattr(samples, "unpadded", False))}
 
     @torch.no_grad()
+    @_in_model_mode
     def forward_fuse_encode(self, sa, fork: bool = True):
         """Stage B: input_proj + vision-language fusion of every level, deformable encoder.  -> state for forward_tail."""
         feats, fmasks, pos = sa["feats"], sa["masks"], sa["pos"]
@@ -342,6 +359,7 @@ class SOC(nn.Module):
                 "sentence": sentence, "B": B, "T": T}
 
     @torch.no_grad()
+    @_in_model_mode
     def forward_tail(self, state, targets, fork: bool = True):
         """Second part of forward: FPN spatial decoder ‖ query decoder -> VOC -> heads, dynamic mask head.
         ``fork=False`` keeps everything on the calling stream (used when the caller already runs the tail beside

@@ -79,33 +79,26 @@ def test_full_config_matches_reference(gpu_model, golden):
     assert maxdiff(out["pred_logit"], g["pred_logit"]) < 1e-4
 
 
-def _lib_split_state():
-    from neurips2023_soc_amd import _lib
-    lib = _lib.load()
-    return lib.soc_win_attn3d_get_split(), lib.soc_ws_linear_get_split()
-
-
 def test_full_config_f32_mfma_mode_matches_reference_and_split_mode(gpu_model, golden):
-    """SOC_MATMUL=f32 (hot_ops.MATMUL_MODE): every product on the f32-input MFMA, no bf16 matrix-core kernel launched; the
+    """model.matmul_mode = "f32" (default from SOC_MATMUL): every product on the f32-input MFMA, no bf16 matrix-core kernel launched; the
     default split mode launches K20 and the split K1.  Both meet the reference, and differ from each other by f32 noise."""
     from neurips2023_soc_amd import hot_ops
     g = golden("full_forward.npz")
-    assert hot_ops.MATMUL_MODE == "split"
+    assert hot_ops.matmul_mode() == "split" and gpu_model.matmul_mode is None
     hot_ops.profile_begin()
     out_split = run_cfg(gpu_model, g["cfg"])
     prof_split = hot_ops.profile_end()
-    assert _lib_split_state() == (1, 1)                         # K1 and K13 launched in their bf16-matrix-core forms
-    hot_ops.MATMUL_MODE = "f32"
+    gpu_model.matmul_mode = "f32"
     try:
         hot_ops.profile_begin()
         out_f32 = run_cfg(gpu_model, g["cfg"])
         prof_f32 = hot_ops.profile_end()
     finally:
-        hot_ops.MATMUL_MODE = "split"
+        gpu_model.matmul_mode = None
+    assert hot_ops.matmul_mode() == "split"                     # the mode lived inside the model's forward only
     assert prof_split.get("linear_split", {}).get("launches", 0) >= 4 and "linear_split" not in prof_f32
     for fam in ("mlp_split", "xs_linear"):                      # K23 / K24 exist in the split arithmetic only
         assert prof_split.get(fam, {}).get("launches", 0) >= 6 and fam not in prof_f32, fam
-    assert _lib_split_state() == (0, 0)                         # the last K1 / K13 launches ran in f32 mode
     for out in (out_split, out_f32):
         idx, masks = P.select_trajectory(out)
         assert int(idx) == int(g["selected_query"])
@@ -114,9 +107,48 @@ def test_full_config_f32_mfma_mode_matches_reference_and_split_mode(gpu_model, g
         assert maxdiff(out["pred_cls"], g["pred_cls"]) < 1e-4
     d = maxdiff(out_split["pred_masks"], out_f32["pred_masks"].cpu())
     print("split vs f32 MFMA: max|dlogit|", d)
-    assert d < 5e-4
-    run_cfg(gpu_model, g["cfg"])                                # leaves the library switches back on "split"
-    assert _lib_split_state() == (1, 1)
+    assert 0 < d < 5e-4                                         # two different arithmetics, both f32-grade
+
+
+def test_two_models_with_different_modes_from_two_threads(gpu_model, synthetic_sd, golden):
+    """ABI 16 is stateless: the arithmetic mode is an argument of each launch and a thread-local of each forward.  A "split"
+    model and an "f32" model run concurrently from two threads (own streams), three forwards each; every result equals what
+    the same model produces alone, bit for bit, and meets the reference golden."""
+    import threading
+    g = golden("full_forward.npz")
+    other, _, _ = S.build_model(S.default_args(text_encoder_random_init=True))
+    other.load_state_dict(synthetic_sd, strict=False)
+    other = other.cuda().eval()
+    other.matmul_mode = "f32"
+    models = {"split": gpu_model, "f32": other}
+    alone = {k: run_cfg(m, g["cfg"])["pred_masks"].clone() for k, m in models.items()}
+    assert not torch.equal(alone["split"], alone["f32"])
+    results, errors = {"split": [], "f32": []}, []
+    start = threading.Barrier(2)
+
+    def worker(name):
+        try:
+            stream = torch.cuda.Stream()
+            start.wait()
+            with torch.cuda.stream(stream):
+                for _ in range(3):
+                    results[name].append(run_cfg(models[name], g["cfg"])["pred_masks"].clone())
+            stream.synchronize()
+        except BaseException as exc:        # noqa: BLE001 -- reported by the main thread
+            errors.append((name, exc))
+
+    threads = [threading.Thread(target=worker, args=(n,)) for n in models]
+    for t_ in threads:
+        t_.start()
+    for t_ in threads:
+        t_.join()
+    torch.cuda.synchronize()
+    assert not errors, errors
+    for name in models:
+        assert len(results[name]) == 3
+        for r in results[name]:
+            assert torch.equal(r, alone[name]), name
+        assert maxdiff(sub(results[name][0], 1 << 17), g["pred_masks_sub"]) < 1e-3
 
 
 @pytest.fixture(scope="module")

@@ -948,24 +948,19 @@ def test_ws_linear_split_form_is_f32_grade(ops, M, K, N, ln, res, act):
     """K13b (K = 96 / 128 on the bf16 matrix cores, exact three-way split) against the f32-MFMA form of the same entry
     point and against f64: the error of the split form is no larger than the f32 form's (plus rounding noise), both forms
     are launched (the switch is honoured), and the split form is bit-repeatable."""
-    from neurips2023_soc_amd import _lib
     g = torch.Generator().manual_seed(M + K + N)
     x = (torch.randn(M, K, generator=g) * 1.5 + 0.2).cuda()
     w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
     b = torch.randn(N, generator=g).cuda()
     lnp = ((torch.rand(K, generator=g) + 0.5).cuda(), (torch.randn(K, generator=g) * 0.1).cuda(), 1e-5) if ln else None
     r = torch.randn(M, N, generator=g).cuda() if res else None
-    assert ops.MATMUL_MODE == "split"
+    assert ops.matmul_mode() == "split"
     got = ops.ws_linear(x, w, b, lnp, r, act)
-    assert _lib.load().soc_ws_linear_get_split() == 1
     again = ops.ws_linear(x, w, b, lnp, r, act)
     assert torch.equal(got, again)
-    ops.MATMUL_MODE = "f32"
-    try:
+    with ops.use_matmul_mode("f32"):            # the switch is an argument of the launch (ABI 16), set per thread here
         f32 = ops.ws_linear(x, w, b, lnp, r, act)
-        assert _lib.load().soc_ws_linear_get_split() == 0
-    finally:
-        ops.MATMUL_MODE = "split"
+    assert ops.matmul_mode() == "split"
     h = torch.nn.functional.layer_norm(x.double(), (K,), lnp[0].double(), lnp[1].double(), 1e-5) if ln else x.double()
     y = torch.nn.functional.linear(h, w.double(), b.double())
     y = torch.nn.functional.gelu(y) if act == "gelu" else (y.relu() if act == "relu" else y)
@@ -1150,7 +1145,7 @@ def test_bf16_mfma_kernels_leave_concurrent_kernels_alone(ops, neighbour):
     else:
         qkv = torch.randn(1, 4, 48, 80, 3 * 192, generator=g).cuda()
         qb, table = torch.randn(3 * 192, generator=g).cuda(), (torch.randn(2535, 6, generator=g) * 0.1).cuda()
-        assert _lib.load().soc_win_attn3d_get_split() == 1 or ops.MATMUL_MODE != "split"
+        assert ops.k1_split_enabled()
         big = lambda: ops.window_attention3d(qkv, qb, table, 6, (8, 7, 7), (4, 3, 3))   # noqa: E731
     first = ops.dynamic_mask(feats, params, refs, (360.0, 640.0), 4).clone()
     big()
@@ -1393,6 +1388,43 @@ def test_mlp_split_residual_layernorm(ops, M, cut):
     assert e_k < 2e-5 and e_k <= 1.5 * e_lib + 1e-6, (e_k, e_lib)
     assert torch.equal(got, ops.mlp_split(x, w1, b1, w2, b2, "relu", ln=(g1, e1, 1e-5), residual=x, residual_ln=True,
                                            post_ln=(g2, e2, 1e-5), cut=cut))
+
+
+def test_mlp_split_residual_layernorm_needs_the_input_itself(ops):
+    """residual_ln means 'the shortcut is LN(x)': the block kernel takes the statistics from x, the reduce kernel from the
+    residual rows -- a residual that is not x is refused by the binding and by the C entry point (SOC_EINVAL), for every cut."""
+    from neurips2023_soc_amd import _lib
+    x, w1, b1, w2, b2, _ = _mlp_case(4099, 256, 2048, "relu", False, 5)
+    other = x.clone()
+    g1, e1 = torch.ones(256).cuda(), torch.zeros(256).cuda()
+    with pytest.raises(RuntimeError, match="residual must be x"):
+        ops.mlp_split(x, w1, b1, w2, b2, "relu", ln=(g1, e1, 1e-5), residual=other, residual_ln=True)
+    lib = _lib.load()
+    packed = ops._mlp_packed(w1, w2)
+    out = torch.empty_like(x)
+    args = lambda res: (x.data_ptr(), packed.data_ptr(), b1.data_ptr(), b2.data_ptr(), g1.data_ptr(), e1.data_ptr(), 1e-5,    # noqa: E731
+                        res.data_ptr(), None, None, 0.0, out.data_ptr(), None, None, 0, 4099, 256, 2048, 1, 1, None)
+    assert lib.soc_mlp_split_f32(*args(other)) == -1            # SOC_EINVAL
+    ws = torch.empty(lib.soc_mlp_split_workspace_bytes(4099, 256, 2048), dtype=torch.uint8, device="cuda")
+    ok = list(args(x))
+    ok[13], ok[14] = ws.data_ptr() if ws.numel() else None, ws.numel()
+    assert lib.soc_mlp_split_f32(*ok) == 0
+    torch.cuda.synchronize()
+
+
+def test_mlp_split_hidden_width_bound_routes_elsewhere(ops):
+    """A hidden width beyond what K23's LDS holds (dim_feedforward = 4096 at C = 256) is not offered to K23: the
+    router falls back to the two-GEMM path instead of raising SOC_EUNSUPPORTED at launch."""
+    from neurips2023_soc_amd import fused
+    x = torch.randn(8192, 256).cuda()
+    for F, want in ((2048, True), (3584, True), (4096, False)):
+        l1, l2 = torch.nn.Linear(256, F).cuda(), torch.nn.Linear(F, 256).cuda()
+        assert ops.mlp_split_max_hidden(256) == 3584
+        assert fused.mlp_ok(x, l1, l2) is want, F
+        if want:
+            got = ops.mlp_split(x, l1.weight, l1.bias, l2.weight, l2.bias, "relu")
+            ref = l2(l1(x).relu())
+            assert float((got - ref).abs().max()) < 1e-4
 
 
 @pytest.mark.parametrize("B,L,H,D,mask_kind", [(1, 10, 12, 64, "none"), (2, 32, 12, 64, "keypad"), (3, 17, 8, 32, "full"),

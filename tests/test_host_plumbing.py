@@ -200,7 +200,11 @@ def test_c_abi_library_exports_every_declared_symbol():
     assert declared == set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.soc_hip_abi_version() == _lib.ABI_VERSION == 15
+    assert lib.soc_hip_abi_version() == _lib.ABI_VERSION == 16
+    # ABI 16 is stateless: no entry point sets or reads process-wide state (ABI <= 15 had soc_*_set_split / soc_set_reserved_cus)
+    assert not [n for n in declared if re.search(r"_(set|get)_", n)], declared
+    assert lib.soc_mlp_split_max_hidden(512) >= 2048 and lib.soc_mlp_split_max_hidden(256) >= 2048      # the BASELINE layers
+    assert lib.soc_mlp_split_max_hidden(100) == 0
     assert lib.soc_xattn_workspace_bytes(240, 10, 1, 8, 32) == 0
     assert lib.soc_xattn_workspace_bytes(10, 1920, 1, 8, 32) == 0
 

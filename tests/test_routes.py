@@ -34,10 +34,11 @@ def test_headline_config_keeps_its_hand_written_kernels():
     assert library == ["input_proj3", "merge2", "swin3.fc2", "vlf2.out*tgt", "vlf2.q", "vlf3.out*tgt", "vlf3.q"], library
 
 
-def test_f32_mode_sends_nothing_to_the_bf16_kernels(monkeypatch):
+def test_f32_mode_sends_nothing_to_the_bf16_kernels():
     from neurips2023_soc_amd import hot_ops
-    monkeypatch.setattr(hot_ops, "MATMUL_MODE", "f32")
-    t = routes.table("video-swin-t", 8, 360, 640)
+    with hot_ops.use_matmul_mode("f32"):
+        t = routes.table("video-swin-t", 8, 360, 640)
+    assert hot_ops.matmul_mode() == "split"
     assert all(v not in ("k23", "k20", "k24") for v in t.values()), t  # ("k13b" sites run the f32-MFMA form of K13 then)
 
 

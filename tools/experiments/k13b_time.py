@@ -26,11 +26,10 @@ for name, M, K, N, ln, res, act in [("qkv", M0, 96, 288, True, False, "none"), (
     r = torch.randn(M, N, generator=g).cuda() if res else None
     out = {}
     for mode in ("split", "f32"):
-        hot_ops.MATMUL_MODE = mode
         try:
-            out[mode] = t(lambda: hot_ops.ws_linear(x, w, b, lnp, r, act))
+            with hot_ops.use_matmul_mode(mode):
+                out[mode] = t(lambda: hot_ops.ws_linear(x, w, b, lnp, r, act))
         except Exception:                      # the f32 form has no LayerNorm at K = 384
             out[mode] = float("nan")
-    hot_ops.MATMUL_MODE = "split"
     fl = 2.0 * M * N * K
     print(f"{name:5s} {M}x{N}x{K}: K13b {out['split']:.1f} us ({fl / out['split'] / 1e6:.1f} TFLOP/s)   K13 {out['f32']:.1f} us ({fl / out['f32'] / 1e6:.1f})")

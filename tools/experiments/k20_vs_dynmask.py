@@ -38,10 +38,8 @@ qkv_bias = torch.randn(3 * 192, generator=g).to(dev)
 
 
 def k1(split):
-    lib = _lib.load()
-    lib.soc_win_attn3d_set_split(int(split))
-    hot_ops.MATMUL_MODE = 'split' if split else 'f32'
-    return hot_ops.window_attention3d(qkv, qkv_bias, table, 6, (8, 7, 7), (4, 3, 3))
+    with hot_ops.use_matmul_mode('split' if split else 'f32'):
+        return hot_ops.window_attention3d(qkv, qkv_bias, table, 6, (8, 7, 7), (4, 3, 3))
 
 
 def make(mode):

@@ -38,7 +38,7 @@ def call(lib, t, st, shift):
     H, W, nH = GEO[st]
     qkv, bias, table, out = t
     args = [C.c_void_p(x.data_ptr()) for x in (qkv, bias, table, out)] + [C.c_int(v) for v in
-            (1, 8, H, W, nH * 32, nH, 8, 7, 7, *shift, 8, 7, 7)] + [C.c_void_p(torch.cuda.current_stream().cuda_stream)]
+            (1, 8, H, W, nH * 32, nH, 8, 7, 7, *shift, 8, 7, 7, int(os.environ.get('K1_SPLIT', '1')))] + [C.c_void_p(torch.cuda.current_stream().cuda_stream)]
     rc = lib.soc_win_attn3d_f32(*args)
     assert rc == 0, rc
 
