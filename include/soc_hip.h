@@ -36,6 +36,16 @@ extern "C" {
 
 int soc_hip_abi_version(void);
 
+/*
+ * CUs a launch on `stream` may use: the device's CU count, cut down to the stream's CU mask when the caller created the stream
+ * with hipExtStreamCreateWithCUMask.  The one-workgroup-per-CU kernels (K1's schedule, K13 / K13b, K20, K23, K24) size their
+ * grids and plans from it, so a host that partitions the chip between two streams -- graph_runner.PartitionedClipGraph: the
+ * head of clip i on one CU set, the tail of clip i-1 and the text encoder on the other -- gets single-round launches on both.
+ * The plan / workspace queries below take the stream of the launch they describe for the same reason.  Reads the stream; keeps
+ * nothing.
+ */
+int soc_stream_cus(void* stream);
+
 const char* soc_hip_error_string(int code);
 
 /*
@@ -268,8 +278,8 @@ int soc_patch_merge_layernorm_f32(const float* x, const float* gamma, const floa
  */
 size_t soc_mlp_split_packed_bytes(int C, int F);
 int soc_mlp_split_pack_f32(const float* w1, const float* w2, void* packed, int C, int F, void* stream);
-size_t soc_mlp_split_workspace_bytes(long M, int C, int F);
-int soc_mlp_split_plan(long M, int C, int F, int* nrg, int* nfs);
+size_t soc_mlp_split_workspace_bytes(long M, int C, int F, void* stream);
+int soc_mlp_split_plan(long M, int C, int F, int* nrg, int* nfs, void* stream);
 int soc_mlp_split_f32(const float* x, const void* packed, const float* b1, const float* b2, const float* ln_gamma,
                       const float* ln_beta, float ln_eps, const float* residual, const float* post_gamma,
                       const float* post_beta, float post_eps, float* out, float* out_sum, float* workspace,
@@ -300,7 +310,7 @@ int soc_mlp_split_variant_f32(const float* x, const void* packed, const float* b
  */
 size_t soc_xs_linear_packed_bytes(int N, int K);
 int soc_xs_linear_pack_f32(const float* w, void* packed, int N, int K, void* stream);
-int soc_xs_linear_plan(long M, int N, int K, int* nrg, int* ncr, int* nct);
+int soc_xs_linear_plan(long M, int N, int K, int* nrg, int* ncr, int* nct, void* stream);
 int soc_xs_linear_f32(const float* x, const void* packed, const float* bias, const float* ln_gamma, const float* ln_beta,
                       float ln_eps, const float* residual, float* out, long M, int N, int K, int act, int nrg, int ncr,
                       void* stream);

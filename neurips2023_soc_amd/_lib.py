@@ -10,7 +10,7 @@ import torch  # noqa: F401  -- loads the process's single HIP runtime before our
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libsoc_hip.so")
 
-EXPORTS = ("soc_hip_abi_version", "soc_hip_error_string", "soc_msda_fwd_f32", "soc_msda_fwd_f64",
+EXPORTS = ("soc_hip_abi_version", "soc_hip_error_string", "soc_stream_cus", "soc_msda_fwd_f32", "soc_msda_fwd_f64",
            "soc_win_attn3d_f32", "soc_xattn_workspace_bytes", "soc_xattn_f32", "soc_dyn_mask_f32",
            "soc_add_layernorm_f32", "soc_msda_fused_fwd_f32", "soc_upsample_threshold_u8",
            "soc_linear_small_f32", "soc_linear_small_multi_f32", "soc_box_refine_f32",
@@ -59,6 +59,8 @@ def load() -> C.CDLL:
     p, i, f = C.c_void_p, C.c_int, C.c_float
     lib.soc_hip_abi_version.restype = i
     lib.soc_mlp_split_max_hidden.restype = i
+    lib.soc_stream_cus.restype = i
+    lib.soc_stream_cus.argtypes = [p]
     lib.soc_mlp_split_max_hidden.argtypes = [i]
     lib.soc_hip_error_string.restype = C.c_char_p
     lib.soc_hip_error_string.argtypes = [i]
@@ -119,9 +121,9 @@ def load() -> C.CDLL:
     lib.soc_mlp_split_pack_f32.restype = i
     lib.soc_mlp_split_pack_f32.argtypes = [p, p, p, i, i, p]
     lib.soc_mlp_split_workspace_bytes.restype = C.c_size_t
-    lib.soc_mlp_split_workspace_bytes.argtypes = [C.c_long, i, i]
+    lib.soc_mlp_split_workspace_bytes.argtypes = [C.c_long, i, i, p]
     lib.soc_mlp_split_plan.restype = i
-    lib.soc_mlp_split_plan.argtypes = [C.c_long, i, i, C.POINTER(i), C.POINTER(i)]
+    lib.soc_mlp_split_plan.argtypes = [C.c_long, i, i, C.POINTER(i), C.POINTER(i), p]
     lib.soc_mlp_split_f32.restype = i
     lib.soc_mlp_split_f32.argtypes = [p, p, p, p, p, p, f, p, p, p, f, p, p, p, C.c_size_t, C.c_long, i, i, i, i, p]
     lib.soc_mlp_split_variant_f32.restype = i
@@ -131,7 +133,7 @@ def load() -> C.CDLL:
     lib.soc_xs_linear_pack_f32.restype = i
     lib.soc_xs_linear_pack_f32.argtypes = [p, p, i, i, p]
     lib.soc_xs_linear_plan.restype = i
-    lib.soc_xs_linear_plan.argtypes = [C.c_long, i, i, C.POINTER(i), C.POINTER(i), C.POINTER(i)]
+    lib.soc_xs_linear_plan.argtypes = [C.c_long, i, i, C.POINTER(i), C.POINTER(i), C.POINTER(i), p]
     lib.soc_xs_linear_f32.restype = i
     lib.soc_xs_linear_f32.argtypes = [p, p, p, p, p, f, p, p, C.c_long, i, i, i, i, i, p]
     lib.soc_patch_embed_layernorm_f32.restype = i

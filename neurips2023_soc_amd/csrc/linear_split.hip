@@ -493,7 +493,7 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict_
     }
 }
 
-int num_cus() { return soc_num_cus(); }      // CUs of the current device (soc_capi.hip)
+int num_cus(hipStream_t st) { return soc_num_cus(st); }      // CUs the launch stream may use (soc_capi.hip)
 
 template <int MT, int NT, int WM, int WN>
 int launch_cfg(const SplitParams& p0, hipStream_t st) {
@@ -516,7 +516,7 @@ int launch_cfg(const SplitParams& p0, hipStream_t st) {
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return SOC_ELAUNCH;
         attr_set[dev] = true;
     }
-    long blocks = num_cus();
+    long blocks = num_cus(st);
 #ifdef SOC_K20_DBG_BLOCKS_PER_CU
     blocks *= SOC_K20_DBG_BLOCKS_PER_CU;
 #endif

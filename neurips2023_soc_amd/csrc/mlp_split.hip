@@ -537,7 +537,7 @@ __global__ __launch_bounds__(256) void mlp_pack_kernel(const float* __restrict__
     }
 }
 
-int num_cus() { return soc_num_cus(); }      // CUs of the current device (soc_capi.hip)
+int num_cus(hipStream_t st) { return soc_num_cus(st); }      // CUs the launch stream may use (soc_capi.hip)
 
 // The shipped form of a width: waves per workgroup and row tiles per wave.  256-register waves (NW = 8) hold the x fragments
 // (3 C / 8 registers per tile) and the output accumulators (C / 4 per tile) of RT tiles up to C = 256; C = 384 needs the 512
@@ -711,15 +711,15 @@ extern "C" int soc_mlp_split_max_hidden(int C) {
     }
 }
 
-extern "C" int soc_mlp_split_plan(long M, int C, int F, int* nrg_out, int* nfs_out) {
+extern "C" int soc_mlp_split_plan(long M, int C, int F, int* nrg_out, int* nfs_out, void* stream) {
     if (!width_ok(C) || F <= 0 || F % 32 != 0 || M <= 0 || !nrg_out || !nfs_out) return SOC_EUNSUPPORTED;
-    plan_rows(M, C, F, num_cus(), nrg_out, nfs_out);
+    plan_rows(M, C, F, num_cus((hipStream_t)stream), nrg_out, nfs_out);
     return SOC_OK;
 }
 
-extern "C" size_t soc_mlp_split_workspace_bytes(long M, int C, int F) {
+extern "C" size_t soc_mlp_split_workspace_bytes(long M, int C, int F, void* stream) {
     if (!width_ok(C) || F <= 0 || F % 32 != 0 || M <= 0) return 0;
-    const int cus = num_cus();
+    const int cus = num_cus((hipStream_t)stream);
     const long m0 = tail_start(M, C, cus);
     int nrg = 0, nfs = 0;
     plan_rows(m0 < M ? M - m0 : M, C, F, cus, &nrg, &nfs);
@@ -775,8 +775,8 @@ extern "C" int soc_mlp_split_f32(const float* x, const void* packed, const float
     if (M < 0 || F <= 0) return SOC_EINVAL;
     if (M == 0) return SOC_OK;
     if (!width_ok(C) || F % 32 != 0) return SOC_EUNSUPPORTED;
-    if (workspace_bytes < soc_mlp_split_workspace_bytes(M, C, F)) return SOC_EWORKSPACE;
-    const int cus = num_cus();
+    if (workspace_bytes < soc_mlp_split_workspace_bytes(M, C, F, stream)) return SOC_EWORKSPACE;
+    const int cus = num_cus((hipStream_t)stream);
     const long m0 = tail_start(M, C, cus);
     int nrg = 0, nfs = 0;
     if (m0 < M) {       // whole rounds first, then the tail over split hidden ranges

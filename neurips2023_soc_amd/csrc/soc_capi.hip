@@ -19,7 +19,24 @@ extern "C" const char* soc_hip_error_string(int code) {
 // stream's short launches was measured null in round 4 and left the ABI with ABI 16.
 #include <atomic>
 
-int soc_num_cus() {
+// CUs a launch on `st` can use: the device's count, cut down to the stream's CU mask when the caller created the stream with
+// hipExtStreamCreateWithCUMask (graph_runner.PartitionedClipGraph runs the head of a clip and the tail of the previous one on
+// two disjoint CU sets).  A one-workgroup-per-CU grid sized for the whole chip on a stream that owns 240 CUs runs in two
+// rounds (measured: K23 320 -> 513 us, tools/experiments/cu_mask_probe.py), so every persistent kernel sizes itself from here.
+// The mask is a property of the stream argument -- nothing the library remembers.
+int soc_num_cus(hipStream_t st) {
+    const int n = soc_device_cus();
+    uint32_t mask[SOC_CU_MASK_WORDS] = {0};
+    if (hipExtStreamGetCUMask(st, SOC_CU_MASK_WORDS, mask) != hipSuccess) {
+        (void)hipGetLastError();               // not a launch error: leave nothing behind for soc_check_launch()
+        return n;
+    }
+    int c = 0;
+    for (int i = 0; i < SOC_CU_MASK_WORDS; ++i) c += __builtin_popcount(mask[i]);
+    return c > 0 && c < n ? c : n;
+}
+
+int soc_device_cus() {
     static std::atomic<int> cached[SOC_MAX_DEVICES];      // 0 = not queried yet; per device
     const int dev = soc_current_device();
     int n = 256;
@@ -34,3 +51,5 @@ int soc_num_cus() {
     }
     return n;
 }
+
+extern "C" int soc_stream_cus(void* stream) { return soc_num_cus((hipStream_t)stream); }

@@ -23,4 +23,6 @@ static inline int soc_current_device() {
 }
 
 // defined in soc_capi.hip: the CU count persistent kernels size their grids for (of the current device)
-int soc_num_cus();
+#define SOC_CU_MASK_WORDS 8             // 256 CU bits
+int soc_device_cus();
+int soc_num_cus(hipStream_t st);

@@ -1410,19 +1410,7 @@ int launch_nt(const float* qkv, const float* qkv_bias, const float* table, float
     return soc_check_launch();
 }
 
-int num_cus() {
-    static std::atomic<int> cached[SOC_MAX_DEVICES];      // 0 = not queried yet; per device
-    const int dev = soc_current_device();
-    if (dev < 0) return 256;
-    int n = cached[dev].load(std::memory_order_relaxed);
-    if (n == 0) {
-        n = 256;
-        int v = 0;
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
-        cached[dev].store(n, std::memory_order_relaxed);
-    }
-    return n;
-}
+int num_cus(hipStream_t st) { return soc_num_cus(st); }      // CUs the launch stream may use (soc_capi.hip)
 
 
 // ---------------------------------------------------------------------------------------------
@@ -1536,7 +1524,7 @@ extern "C" int soc_win_attn3d_f32(const float* qkv, const float* qkv_bias, const
     const bool full_window = win_d == 8 && win_h == 7 && win_w == 7 && tab_d == 8 && tab_h == 7 && tab_w == 7;
     const bool split = full_window && split_arith != 0;     // full 8x7x7 windows only; a launch argument, not process state
     {
-        const Plan pl = plan_schedule(pairs, p.NT, num_cus(), full_window, split);
+        const Plan pl = plan_schedule(pairs, p.NT, num_cus((hipStream_t)stream), full_window, split);
         p.n_main = pl.n_main;
         p.qsplit = pl.qsplit;
     }

@@ -178,7 +178,7 @@ __global__ __launch_bounds__(THREADS, 2) void ws_linear_kernel(
     }
 }
 
-int num_cus() { return soc_num_cus(); }      // CUs of the current device (soc_capi.hip)
+int num_cus(hipStream_t st) { return soc_num_cus(st); }      // CUs the launch stream may use (soc_capi.hip)
 
 // columns of W per workgroup: even ranges, multiples of 16, that fit the LDS; 0 if N cannot be split that way
 int split_columns(int N, int K) {
@@ -202,7 +202,7 @@ int launch_ct(const float* x, const float* gamma, const float* beta, float eps, 
     }
     const int nc_per_split = split_columns(N, K);
     const int nsplit = (N + nc_per_split - 1) / nc_per_split;
-    const int cus = num_cus();
+    const int cus = num_cus(st);
     const long ntiles = (M + 15) >> 4;
     long per_split = cus / nsplit > 0 ? cus / nsplit : 1;
     if (per_split * 8 > ntiles) per_split = (ntiles + 7) / 8;         // never more waves than row tiles

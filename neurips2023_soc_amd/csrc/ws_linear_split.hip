@@ -243,7 +243,7 @@ __global__ __launch_bounds__(THREADS, 2) void ws_linear_split_kernel(
     __syncthreads();        // the waves retire together: no foreign wave beside a partner that still issues MFMAs
 }
 
-int num_cus() { return soc_num_cus(); }      // CUs of the current device (soc_capi.hip)
+int num_cus(hipStream_t st) { return soc_num_cus(st); }      // CUs the launch stream may use (soc_capi.hip)
 
 // columns of W per workgroup: even ranges, multiples of 16, whose three planes (+ bias) fit the LDS; 0 if impossible.
 // K > 256 (rows split step by step): a range is ONE group of 3, 2 or 1 column tiles.
@@ -276,7 +276,7 @@ int launch_ct(const float* x, const float* gamma, const float* beta, float eps, 
     }
     const int nc_per_split = split_columns(N, K);
     const int nsplit = (N + nc_per_split - 1) / nc_per_split;
-    const int cus = num_cus();
+    const int cus = num_cus(st);
     const long ngroups = (M + 16 * RT - 1) / (16 * RT);
     long per_split = cus / nsplit > 0 ? cus / nsplit : 1;
     if (per_split * 8 > ngroups) per_split = (ngroups + 7) / 8;       // never more waves than row groups

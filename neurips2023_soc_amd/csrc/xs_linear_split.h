@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void xs_pack_kernel(const float* __restrict__ 
     }
 }
 
-int num_cus() { return soc_num_cus(); }      // CUs of the current device (soc_capi.hip)
+int num_cus(hipStream_t st) { return soc_num_cus(st); }      // CUs the launch stream may use (soc_capi.hip)
 
 using soc_xs::Args;
 

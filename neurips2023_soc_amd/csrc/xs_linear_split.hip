@@ -90,9 +90,9 @@ extern "C" int soc_xs_linear_pack_f32(const float* w, void* packed, int N, int K
     return soc_check_launch();
 }
 
-extern "C" int soc_xs_linear_plan(long M, int N, int K, int* nrg, int* ncr, int* nct) {
+extern "C" int soc_xs_linear_plan(long M, int N, int K, int* nrg, int* ncr, int* nct, void* stream) {
     if (!width_ok(K) || N <= 0 || N % 32 != 0 || M <= 0 || !nrg || !ncr || !nct) return SOC_EUNSUPPORTED;
-    return plan(M, N, K, num_cus(), nrg, ncr, nct) ? SOC_OK : SOC_EUNSUPPORTED;
+    return plan(M, N, K, num_cus((hipStream_t)stream), nrg, ncr, nct) ? SOC_OK : SOC_EUNSUPPORTED;
 }
 
 extern "C" int soc_xs_linear_f32(const float* x, const void* packed, const float* bias, const float* ln_gamma,
@@ -107,7 +107,7 @@ extern "C" int soc_xs_linear_f32(const float* x, const void* packed, const float
         return SOC_EUNSUPPORTED;
     int nct = 0;
     if (nrg <= 0 || ncr <= 0) {
-        if (!plan(M, N, K, num_cus(), &nrg, &ncr, &nct)) return SOC_EUNSUPPORTED;
+        if (!plan(M, N, K, num_cus((hipStream_t)stream), &nrg, &ncr, &nct)) return SOC_EUNSUPPORTED;
     } else {
         if ((N / 16) % ncr != 0) return SOC_EINVAL;
         nct = N / 16 / ncr;

@@ -258,3 +258,189 @@ class PipelinedClipGraph:
         self.drain[(self._n - 1) % 2].replay()       # the last head wrote sb[(n-1) % 2]
         self._n = 0
         return [self.record.clone()]
+
+
+class TwoStreamClipGraph(PipelinedClipGraph):
+    """The software pipeline across clips as SEPARATE graphs on TWO streams (round 5).
+
+        main stream:  Video-Swin(i) ------------------------> fusion + deformable encoder(i)  | Video-Swin(i+1) ...
+        aux stream:   text encoder(i) -> tail(i-1: FPN, query decoder, VOC, heads, mask head)  | text encoder(i+1) ...
+
+    PipelinedClipGraph keeps both clips inside one graph: the tail on a side branch, the text encoder on another one beside
+    Video-Swin -- two sources of short launches, each of which can take a CU away from a one-workgroup-per-CU kernel of the head
+    for its whole duration.  Here every short, latency-bound launch of a period (text encoder: ~150, tail: ~150) sits on ONE
+    auxiliary stream, one behind the other, so at most one of them is beside the head at any time, and the head itself is a
+    single-branch graph.  Measured with tools/experiments/partition_probe.py (same box, graph replays, events on the main
+    stream): 6.07-6.10 ms per clip against 6.17 with the fusion levels forked, 6.7 with the text encoder on a third stream,
+    6.96 with the tail in front of the text encoder, and 6.30 for the one-graph pipeline.  Giving the auxiliary stream its own
+    CUs (hipExtStreamCreateWithCUMask; the kernels size their grids from the stream's mask, soc_stream_cus) was measured too and
+    is slower at every split tried (8 / 16 / 24 / 32 CUs: 14.3 / 7.8 / 8.9 / 7.0 ms): Video-Swin alone takes 5.2 ms on 248 CUs
+    against 3.4 on 256.
+
+    Hand-over: Video-Swin(i) and the encoder write the double-buffered state sb[i % 2] (as in the parent); the text encoder
+    writes tx[i % 2].  Cross-stream order is carried by events recorded / awaited around the graph launches (never inside a
+    capture).  Same driving interface and the same records as the parent: run() returns the record of the clip submitted one
+    call earlier, flush() drains.
+    """
+
+    def __init__(self, model, T: int, H: int, W: int, L: int, device, warmup: int = 2):
+        self.model, self.T, self.H, self.W, self.L = model, T, H, W, L
+        dev = self.device = torch.device(device)
+        self.clip = torch.zeros(T, 1, 3, H, W, device=dev)
+        self.pad = torch.zeros(T, 1, H, W, dtype=torch.bool, device=dev)
+        self.ids = torch.ones(1, L, dtype=torch.long, device=dev)
+        self.attn = torch.ones(1, L, dtype=torch.long, device=dev)
+        self.targets = [[{"size": (H, W)}] for _ in range(T)]
+        hm, wm = -(-H // 4), -(-W // 4)
+        self.record = torch.zeros(CP.record_size(T, model.num_queries, hm, wm), device=dev)
+        assert hot_ops._prof is None, "do not capture while kernel profiling is on"
+        self.main, self.aux = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+        caller = torch.cuda.current_stream(dev)
+        self.main.wait_stream(caller)
+        with torch.cuda.stream(self.main):      # warm-up off the capture: lazy inits, algorithm finds, packed weight images
+            for _ in range(max(warmup, 1)):
+                tx = self._text()
+                sb = self._fuse(self._video(), tx)
+                self._tail(sb, fork=False)
+            self.tx = [self._clone_text(tx), self._clone_text(tx)]
+            self.sb = [self._clone(sb), self._clone(sb)]
+        self.aux.wait_stream(self.main)
+        caller.wait_stream(self.main)
+        torch.cuda.synchronize(dev)
+
+        def capture(body, stream):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=stream, capture_error_mode=CAPTURE_MODE):
+                body()
+            return g
+
+        self._vs = [None, None]
+
+        def video(k):       # Video-Swin of clip i, its stage-0 token map produced IN sb[k]
+            self._vs[k] = self._placed(lambda: self._video(), self.sb[k], "swin0")
+
+        def fuse(k):        # fusion + encoder of clip i: reads Video-Swin's static outputs and tx[k], fills sb[k]
+            st = self._placed(lambda: self._fuse(self._vs[k], self.tx[k]), self.sb[k], "encoder_memory")
+            self._store(st, self.sb[k])
+
+        def text(k):
+            self._store_text(self._text(), self.tx[k])
+
+        self.g_video = [capture(lambda k=k: video(k), self.main) for k in (0, 1)]
+        self.g_fuse = [capture(lambda k=k: fuse(k), self.main) for k in (0, 1)]
+        self.g_text = [capture(lambda k=k: text(k), self.aux) for k in (0, 1)]
+        self.g_tail = [capture(lambda k=k: self._tail(self.sb[k], fork=False), self.aux) for k in (0, 1)]
+        torch.cuda.synchronize(dev)
+        E = torch.cuda.Event
+        self._ev_staged, self._ev_clip_free, self._ev_text = E(), E(), E()
+        self._ev_head, self._ev_tail = [E(), E()], [E(), E()]
+        self._tail_pending = [False, False]      # a tail reading sb[k] has been enqueued and not yet been waited for by the head
+        self._inputs_busy = False
+        self._n = 0
+
+    # -- stages ------------------------------------------------------------------------------------------
+    _TEXT = ("words", "word_pad", "text_pos", "sentence")
+
+    def _text(self):
+        return self.model.forward_text_state({"input_ids": self.ids, "attention_mask": self.attn}, self.device)
+
+    def _video(self):
+        return self.model.forward_video(NestedTensor(self.clip, self.pad, unpadded=True))
+
+    def _fuse(self, vs, tx):
+        return self.model.forward_fuse_encode({**vs, **tx}, fork=False)
+
+    def _placed(self, body, dst, tag):
+        """`body()` with one of its large outputs produced IN the static state (hot_ops.place_output) instead of copied there."""
+        f0, mem = dst["feats0"], dst["ctx"][0]
+        try:
+            if tag == "swin0":
+                n, c, h, w = f0.shape
+                tok = f0.permute(0, 2, 3, 1)                 # '(b t) h w c': the layout the stage writes
+                if tok.is_contiguous():
+                    hot_ops.place_output("swin0", tok.view(n // self.T, self.T, h, w, c))
+            elif mem.is_contiguous():
+                hot_ops.place_output("encoder_memory", mem)
+            return body()
+        finally:
+            hot_ops.place_output(tag, None)
+
+    def _clone_text(self, tx):
+        return {k: self._like(tx[k]) for k in self._TEXT}
+
+    def _store_text(self, tx, dst):
+        torch._foreach_copy_([dst[k] for k in self._TEXT if dst[k].dtype == torch.float32],
+                             [tx[k] for k in self._TEXT if dst[k].dtype == torch.float32])
+        for k in self._TEXT:
+            if dst[k].dtype != torch.float32:
+                dst[k].copy_(tx[k])
+
+    # -- driving -----------------------------------------------------------------------------------------
+    def stage_inputs(self, clip: torch.Tensor, ids: Optional[torch.Tensor] = None,
+                     attn: Optional[torch.Tensor] = None) -> None:
+        """As ClipGraph.stage_inputs, on the caller's stream -- which first waits until Video-Swin and the text encoder of the
+        previous clip have read the static inputs."""
+        if self._inputs_busy:
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(self._ev_clip_free)
+            cur.wait_event(self._ev_text)
+        ClipGraph.stage_inputs(self, clip, ids, attn)
+
+    def replay(self):
+        dev, k = self.device, self._n % 2
+        cur = torch.cuda.current_stream(dev)
+        self._ev_staged.record(cur)
+        with torch.cuda.stream(self.aux):
+            self.aux.wait_event(self._ev_staged)
+            self.g_text[k].replay()                      # clip i: ids -> tx[k]  (tx[k] was last read by tail(i-2): this stream)
+            self._ev_text.record(self.aux)
+            if self._n >= 1:
+                self.aux.wait_event(self._ev_head[1 - k])
+                self.g_tail[1 - k].replay()              # clip i-1
+                self._ev_tail[1 - k].record(self.aux)
+                self._tail_pending[1 - k] = True
+        with torch.cuda.stream(self.main):
+            self.main.wait_event(self._ev_staged)
+            if self._tail_pending[k]:                    # sb[k] is still being read by tail(i-2) until then
+                self.main.wait_event(self._ev_tail[k])
+                self._tail_pending[k] = False
+            self.g_video[k].replay()
+            self._ev_clip_free.record(self.main)
+            self.main.wait_event(self._ev_text)
+            self.g_fuse[k].replay()
+            self._ev_head[k].record(self.main)
+        self._inputs_busy = True
+        self._n += 1
+        if self._n >= self.DEPTH:
+            cur.wait_event(self._ev_tail[1 - k])         # the caller reads self.record on its own stream
+            return self.record
+        return None
+
+    def flush(self):
+        """Drain the pipeline: [clone of the record of the clip still in flight] (empty if none)."""
+        if self._n == 0:
+            return []
+        dev, k = self.device, (self._n - 1) % 2          # the last head wrote sb[k]
+        cur = torch.cuda.current_stream(dev)
+        self._ev_staged.record(cur)                      # the caller has copied the previous record out by now
+        with torch.cuda.stream(self.aux):
+            self.aux.wait_event(self._ev_staged)
+            self.aux.wait_event(self._ev_head[k])
+            self.g_tail[k].replay()
+            self._ev_tail[k].record(self.aux)
+        cur.wait_event(self._ev_tail[k])
+        cur.wait_event(self._ev_clip_free)
+        self._tail_pending = [False, False]
+        self._inputs_busy = False
+        self._n = 0
+        return [self.record.clone()]
+
+
+PIPELINES = {"two-stream": TwoStreamClipGraph, "one-graph": PipelinedClipGraph}
+
+
+def pipeline_class(name: Optional[str] = None):
+    """The software pipeline across clips the drivers and bench.py stream through: "two-stream" (default; SOC_PIPELINE
+    overrides) or "one-graph" (rounds 1-4)."""
+    import os
+    return PIPELINES[name or os.environ.get("SOC_PIPELINE", "two-stream")]

@@ -133,6 +133,16 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream      # current device == every argument's device (_need_gpu)
 
 
+def _plan_stream():
+    """Stream argument of the plan queries (its CU mask sizes the plan); None = the null stream where there is no GPU."""
+    return _stream() if torch.cuda.is_available() else None
+
+
+def stream_cus() -> int:
+    """CUs a launch on the current stream may use (the device's count, or the stream's CU mask: soc_stream_cus)."""
+    return int(_lib.load().soc_stream_cus(_stream()))
+
+
 def _f32c(x: Tensor) -> Tensor:
     if x.dtype != torch.float32:
         raise _lib.SocHipError(f"expected float32, got {x.dtype}")
@@ -1152,7 +1162,7 @@ def xs_linear_plan(M: int, N: int, K: int) -> Tuple[int, int, int]:
     """(workgroup rows, column ranges, column tiles per range) K24 cuts an [M, K] x [N, K]^T layer into."""
     lib = _lib.load()
     a, b, c = C.c_int(0), C.c_int(0), C.c_int(0)
-    _lib.check(lib.soc_xs_linear_plan(M, N, K, C.byref(a), C.byref(b), C.byref(c)), "soc_xs_linear_plan")
+    _lib.check(lib.soc_xs_linear_plan(M, N, K, C.byref(a), C.byref(b), C.byref(c), _plan_stream()), "soc_xs_linear_plan")
     return a.value, b.value, c.value
 
 
@@ -1261,7 +1271,7 @@ def mlp_split(x: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor, act: st
         _k23_calls.append(dict(x=x, w1=w1, b1=b1, w2=w2, b2=b2, act=act, ln=ln, residual=residual, post_ln=post_ln, cut=cut,
                                return_sum=return_sum, residual_ln=residual_ln))
     if cut is None:
-        nbytes = lib.soc_mlp_split_workspace_bytes(M, C_, F_)
+        nbytes = lib.soc_mlp_split_workspace_bytes(M, C_, F_, _stream())
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
         with _timed("mlp_split", 4.0 * M * F_ * C_):
             rc = lib.soc_mlp_split_f32(x.data_ptr(), packed.data_ptr(), b1c.data_ptr(), b2c.data_ptr(), ptr(g), ptr(be), eps,
@@ -1283,7 +1293,7 @@ def mlp_split_plan(M: int, C_: int, F_: int) -> Tuple[int, int]:
     """(workgroup rows, hidden ranges) K23 would cut M rows into as ONE launch."""
     lib = _lib.load()
     nrg, nfs = C.c_int(0), C.c_int(0)
-    _lib.check(lib.soc_mlp_split_plan(M, C_, F_, C.byref(nrg), C.byref(nfs)), "soc_mlp_split_plan")
+    _lib.check(lib.soc_mlp_split_plan(M, C_, F_, C.byref(nrg), C.byref(nfs), _plan_stream()), "soc_mlp_split_plan")
     return nrg.value, nfs.value
 
 

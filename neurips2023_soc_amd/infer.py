@@ -20,7 +20,7 @@ import torch
 
 from . import clip_parallel as CP
 from . import postprocessing as P
-from .graph_runner import ClipGraph, PipelinedClipGraph
+from .graph_runner import ClipGraph, PipelinedClipGraph, pipeline_class
 from .nested_tensor import NestedTensor
 
 
@@ -92,7 +92,7 @@ class ClipInferencer:
             while len(self._pipes) >= self.max_graphs:
                 torch.cuda.synchronize(self.device)
                 self._pipes.pop(next(iter(self._pipes)))
-            self._pipes[key] = PipelinedClipGraph(self.model, T, H, W, ids.shape[-1], self.device)
+            self._pipes[key] = pipeline_class()(self.model, T, H, W, ids.shape[-1], self.device)
         pipe = self._pipes[key]
         rec = pipe.run(clip, ids, attn)
         prev = self._active
@@ -188,7 +188,10 @@ def _run_dataset(a):
         if os.path.exists(meta):
             break
         time.sleep(0.2)
-    model, _, _ = build_model(default_args(a.backbone, text_encoder_random_init=a.checkpoint is None))
+    # The text encoder's architecture comes from the config; its weights from the checkpoint (a trained SOC checkpoint holds
+    # every text_encoder.* tensor -- a gap would be printed as Missing Keys) or from the synthetic generator: no HuggingFace
+    # download is needed either way (the reference's from_pretrained at build time is overwritten by its checkpoint as well).
+    model, _, _ = build_model(default_args(a.backbone, text_encoder_random_init=True))
     if a.checkpoint:
         load_checkpoint(model, a.checkpoint)
     else:

@@ -283,19 +283,32 @@ class SOC(nn.Module):
             main = torch.cuda.current_stream(device)
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                text, sentence = self.forward_text(text_queries, device)
-                text_pos = self.text_pos(text).permute(2, 0, 1)     # ten tiny launches: on the text branch, not in front of the fusion
-            backbone_out, pos = self.backbone(samples)   # rewrites samples to '(b t)' like the reference
+                tx = self.forward_text_state(text_queries, device)
+            vs = self.forward_video(samples)
             main.wait_stream(side)
         else:
-            text, sentence = self.forward_text(text_queries, device)
-            text_pos = self.text_pos(text).permute(2, 0, 1)
-            backbone_out, pos = self.backbone(samples)
+            tx = self.forward_text_state(text_queries, device)
+            vs = self.forward_video(samples)
+        return {**vs, **tx}
+
+    @torch.no_grad()
+    @_in_model_mode
+    def forward_text_state(self, text_queries, device):
+        """The text half of stage A: RoBERTa + FeatureResizer + the words' position encoding (reference models/soc.py:167-181
+        and the `text_pos` of :232-233).  graph_runner.TwoStreamClipGraph runs it on its auxiliary stream, in front of the tail
+        of the previous clip, instead of beside Video-Swin."""
+        text, sentence = self.forward_text(text_queries, device)
+        text_pos = self.text_pos(text).permute(2, 0, 1)     # ten tiny launches: on the text branch, not in front of the fusion
         words, word_pad = text.decompose()
+        return {"words": words, "word_pad": word_pad, "text_pos": text_pos, "sentence": sentence}
+
+    @torch.no_grad()
+    @_in_model_mode
+    def forward_video(self, samples: NestedTensor):
+        """The video half of stage A: Video-Swin + position encodings (rewrites samples to '(b t)' like the reference)."""
+        backbone_out, pos = self.backbone(samples)
         return {"feats": [f.tensors for f in backbone_out], "masks": [f.mask for f in backbone_out], "pos": pos,
-                "words": words, "word_pad": word_pad, "text_pos": text_pos, "sentence": sentence,
-                "sample_mask": samples.mask,
-                "unpadded": bool(getattr(samples, "unpadded", False))}
+                "sample_mask": samples.mask, "unpadded": bool(getattr(samples, "unpadded", False))}
 
     @torch.no_grad()
     @_in_model_mode

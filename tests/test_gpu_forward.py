@@ -110,11 +110,14 @@ def test_full_config_f32_mfma_mode_matches_reference_and_split_mode(gpu_model, g
     assert 0 < d < 5e-4                                         # two different arithmetics, both f32-grade
 
 
-def test_two_models_with_different_modes_from_two_threads(gpu_model, synthetic_sd, golden):
+def test_two_models_with_different_modes_from_two_threads(gpu_model, synthetic_sd, golden, monkeypatch):
     """ABI 16 is stateless: the arithmetic mode is an argument of each launch and a thread-local of each forward.  A "split"
-    model and an "f32" model run concurrently from two threads (own streams), three forwards each; every result equals what
-    the same model produces alone, bit for bit, and meets the reference golden."""
+    model and an "f32" model run concurrently from two threads (own streams), three forwards each.  Checked per thread: which
+    kernels it launched (the bf16-split-only kernels K20 / K23 / K24 from the "split" thread only; the `split` argument K1 and
+    K13 were called with), and that every result meets the reference golden and equals what the same model produces alone to
+    within the forward's run-to-run noise (a few library kernels accumulate with atomics: ~4e-5, see the soak test)."""
     import threading
+    from neurips2023_soc_amd import _lib, hot_ops
     g = golden("full_forward.npz")
     other, _, _ = S.build_model(S.default_args(text_encoder_random_init=True))
     other.load_state_dict(synthetic_sd, strict=False)
@@ -122,12 +125,32 @@ def test_two_models_with_different_modes_from_two_threads(gpu_model, synthetic_s
     other.matmul_mode = "f32"
     models = {"split": gpu_model, "f32": other}
     alone = {k: run_cfg(m, g["cfg"])["pred_masks"].clone() for k, m in models.items()}
-    assert not torch.equal(alone["split"], alone["f32"])
-    results, errors = {"split": [], "f32": []}, []
+    d_modes = maxdiff(alone["split"], alone["f32"].cpu())
+    assert 0 < d_modes < 5e-4
+
+    seen = {}          # thread ident -> {"split_only": launches of K20 / K23 / K24, "k1": set of split args, "k13": set of split args}
+    lib = _lib.load()
+
+    def note(key, value=None):
+        rec = seen.setdefault(threading.get_ident(), {"split_only": 0, "k1": set(), "k13": set()})
+        if value is None:
+            rec[key] += 1
+        else:
+            rec[key].add(value)
+
+    for name in ("linear_split", "mlp_split", "xs_linear"):
+        real = getattr(hot_ops, name)
+        monkeypatch.setattr(hot_ops, name, lambda *a, _real=real, **kw: (note("split_only"), _real(*a, **kw))[1])
+    real_k1, real_k13 = lib.soc_win_attn3d_f32, lib.soc_ws_linear_f32
+    monkeypatch.setattr(lib, "soc_win_attn3d_f32", lambda *a: (note("k1", int(a[-2])), real_k1(*a))[1])
+    monkeypatch.setattr(lib, "soc_ws_linear_f32", lambda *a: (note("k13", int(a[-2])), real_k13(*a))[1])
+
+    results, errors, idents = {"split": [], "f32": []}, [], {}
     start = threading.Barrier(2)
 
     def worker(name):
         try:
+            idents[name] = threading.get_ident()
             stream = torch.cuda.Stream()
             start.wait()
             with torch.cuda.stream(stream):
@@ -144,11 +167,14 @@ def test_two_models_with_different_modes_from_two_threads(gpu_model, synthetic_s
         t_.join()
     torch.cuda.synchronize()
     assert not errors, errors
+    s_rec, f_rec = seen[idents["split"]], seen[idents["f32"]]
+    assert s_rec["split_only"] >= 3 * 20 and s_rec["k1"] == {1} and s_rec["k13"] == {1}, s_rec
+    assert f_rec["split_only"] == 0 and f_rec["k1"] == {0} and f_rec["k13"] <= {0}, f_rec
     for name in models:
         assert len(results[name]) == 3
         for r in results[name]:
-            assert torch.equal(r, alone[name]), name
-        assert maxdiff(sub(results[name][0], 1 << 17), g["pred_masks_sub"]) < 1e-3
+            assert maxdiff(r, alone[name].cpu()) < 1e-4, name
+            assert maxdiff(sub(r, 1 << 17), g["pred_masks_sub"]) < 1e-3
 
 
 @pytest.fixture(scope="module")
@@ -306,9 +332,12 @@ def test_clip_inferencer_pads_expressions_for_graph_reuse(gpu_model, golden):
     assert len(graphs._graphs) == 1
 
 
-def test_pipelined_graph_matches_plain_graph(gpu_model):
-    """PipelinedClipGraph (tail of clip i beside the head of clip i+1) returns ClipGraph's records, one call late."""
-    from neurips2023_soc_amd.graph_runner import ClipGraph, PipelinedClipGraph
+@pytest.mark.parametrize("pipeline", ["two-stream", "one-graph"])
+def test_pipelined_graph_matches_plain_graph(gpu_model, pipeline):
+    """The software pipelines (tail of clip i beside the head of clip i+1: TwoStreamClipGraph, what ships, and the one-graph
+    PipelinedClipGraph of rounds 1-4) return ClipGraph's records, one call late."""
+    from neurips2023_soc_amd.graph_runner import ClipGraph, pipeline_class
+    PipelinedClipGraph = pipeline_class(pipeline)
     T, H, Wd, L = 3, 96, 128, 6
     clips = [W.synthetic_clip(40 + i, T, H, Wd).cuda() for i in range(5)]
     ids = [W.synthetic_token_ids(40 + i, L).cuda() for i in range(5)]
@@ -336,12 +365,14 @@ def test_pipelined_graph_matches_plain_graph(gpu_model):
             assert maxdiff(a, b.cpu()) < 1e-4
 
 
-def test_pipelined_graph_full_config_matches_reference(gpu_model, golden):
-    """What bench.py times -- PipelinedClipGraph at the BASELINE size (T=8, 360x640) -- against the reference's
+@pytest.mark.parametrize("pipeline", ["two-stream", "one-graph"])
+def test_pipelined_graph_full_config_matches_reference(gpu_model, golden, pipeline):
+    """What bench.py times -- the software pipeline at the BASELINE size (T=8, 360x640) -- against the reference's
     own output (full_forward.npz): selected query, its mask logits, class scores; with other clips before and
     after it in the pipeline, and again after a flush (state-buffer reuse)."""
     from neurips2023_soc_amd import clip_parallel as CP
-    from neurips2023_soc_amd.graph_runner import PipelinedClipGraph
+    from neurips2023_soc_amd.graph_runner import pipeline_class
+    PipelinedClipGraph = pipeline_class(pipeline)
     g = golden("full_forward.npz")
     seed, T, H, Wd, L = (int(v) for v in g["cfg"])
     hm, wm = -(-H // 4), -(-Wd // 4)
@@ -386,7 +417,8 @@ import sys, torch
 sys.path.insert(0, %r)
 import neurips2023_soc_amd as S
 from neurips2023_soc_amd import weights as W
-from neurips2023_soc_amd.graph_runner import PipelinedClipGraph
+from neurips2023_soc_amd.graph_runner import pipeline_class
+PipelinedClipGraph = pipeline_class()          # the shipped one (two-stream)
 T, H, Wd, L, N = 8, 360, 640, 10, 1536
 model, _, _ = S.build_model(S.default_args(text_encoder_random_init=True))
 W.load_synthetic(model, 2023)

@@ -1402,13 +1402,12 @@ def test_mlp_split_residual_layernorm_needs_the_input_itself(ops):
     lib = _lib.load()
     packed = ops._mlp_packed(w1, w2)
     out = torch.empty_like(x)
+    ws = torch.empty(max(lib.soc_mlp_split_workspace_bytes(4099, 256, 2048, None), 16), dtype=torch.uint8, device="cuda")
     args = lambda res: (x.data_ptr(), packed.data_ptr(), b1.data_ptr(), b2.data_ptr(), g1.data_ptr(), e1.data_ptr(), 1e-5,    # noqa: E731
-                        res.data_ptr(), None, None, 0.0, out.data_ptr(), None, None, 0, 4099, 256, 2048, 1, 1, None)
+                        res.data_ptr(), None, None, 0.0, out.data_ptr(), None, ws.data_ptr(), ws.numel(), 4099, 256, 2048, 1, 1,
+                        None)
     assert lib.soc_mlp_split_f32(*args(other)) == -1            # SOC_EINVAL
-    ws = torch.empty(lib.soc_mlp_split_workspace_bytes(4099, 256, 2048), dtype=torch.uint8, device="cuda")
-    ok = list(args(x))
-    ok[13], ok[14] = ws.data_ptr() if ws.numel() else None, ws.numel()
-    assert lib.soc_mlp_split_f32(*ok) == 0
+    assert lib.soc_mlp_split_f32(*args(x)) == 0
     torch.cuda.synchronize()
 
 

@@ -38,7 +38,7 @@ p, i, f = C.c_void_p, C.c_int, C.c_float
 lib.soc_mlp_split_packed_bytes.restype = C.c_size_t
 lib.soc_mlp_split_packed_bytes.argtypes = [i, i]
 lib.soc_mlp_split_pack_f32.argtypes = [p, p, p, i, i, p]
-lib.soc_mlp_split_plan.argtypes = [C.c_long, i, i, C.POINTER(i), C.POINTER(i)]
+lib.soc_mlp_split_plan.argtypes = [C.c_long, i, i, C.POINTER(i), C.POINTER(i), C.c_void_p]
 lib.soc_mlp_split_variant_f32.argtypes = [p, p, p, p, p, p, f, p, p, p, f, p, p, p, C.c_long, i, i, i, i, i, i, i, p]
 g = torch.Generator().manual_seed(0)
 quick = "--quick" in sys.argv
@@ -86,7 +86,7 @@ def case(name, M, Cw, F, act, ln, res, cuts, variants):
     for cut in cuts:
         if cut is None:
             nrg, nfs = C.c_int(0), C.c_int(0)
-            lib.soc_mlp_split_plan(M, Cw, F, C.byref(nrg), C.byref(nfs))
+            lib.soc_mlp_split_plan(M, Cw, F, C.byref(nrg), C.byref(nfs), None)
             nrg, nfs = nrg.value, nfs.value
         else:
             nrg, nfs = cut

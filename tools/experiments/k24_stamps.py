@@ -28,7 +28,7 @@ p, i, f = C.c_void_p, C.c_int, C.c_float
 lib.soc_xs_linear_packed_bytes.restype = C.c_size_t
 lib.soc_xs_linear_packed_bytes.argtypes = [i, i]
 lib.soc_xs_linear_pack_f32.argtypes = [p, p, i, i, p]
-lib.soc_xs_linear_plan.argtypes = [C.c_long, i, i, C.POINTER(i), C.POINTER(i), C.POINTER(i)]
+lib.soc_xs_linear_plan.argtypes = [C.c_long, i, i, C.POINTER(i), C.POINTER(i), C.POINTER(i), C.c_void_p]
 lib.soc_xs_linear_f32.argtypes = [p, p, p, p, p, f, p, p, C.c_long, i, i, i, i, i, p]
 lib.soc_xs_debug_set_buffer.argtypes = [p]
 g = torch.Generator().manual_seed(0)
@@ -42,7 +42,7 @@ for name, M, N, K in (("s2.qkv", 7360, 1152, 384), ("s2.proj", 7360, 384, 384), 
     st = torch.cuda.current_stream().cuda_stream
     assert lib.soc_xs_linear_pack_f32(w.data_ptr(), packed.data_ptr(), N, K, st) == 0
     nrg, ncr, nct = C.c_int(), C.c_int(), C.c_int()
-    lib.soc_xs_linear_plan(M, N, K, C.byref(nrg), C.byref(ncr), C.byref(nct))
+    lib.soc_xs_linear_plan(M, N, K, C.byref(nrg), C.byref(ncr), C.byref(nct), None)
     dbg = torch.zeros(4096 * 8 * 8, dtype=torch.int64, device="cuda")
 
     def run():
