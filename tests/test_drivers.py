@@ -213,6 +213,7 @@ def test_forward_text_strings_equal_pretokenised_ids(gpu_model, tmp_path):
     """SOC.forward_text on strings of different length (the tokenizer pads the batch) == the same ids fed directly."""
     from neurips2023_soc_amd.soc import encode_expressions, load_roberta_tokenizer
     model, _ = gpu_model
+    torch.set_grad_enabled(False)
     hf = load_roberta_tokenizer(SD.write_synthetic_roberta_tokenizer(str(tmp_path / "tok")))
     texts = ["the dog", "a person riding the white car"]
     old = model.tokenizer
