@@ -270,12 +270,16 @@ class TwoStreamClipGraph(PipelinedClipGraph):
     Video-Swin -- two sources of short launches, each of which can take a CU away from a one-workgroup-per-CU kernel of the head
     for its whole duration.  Here every short, latency-bound launch of a period (text encoder: ~150, tail: ~150) sits on ONE
     auxiliary stream, one behind the other, so at most one of them is beside the head at any time, and the head itself is a
-    single-branch graph.  Measured with tools/experiments/partition_probe.py (same box, graph replays, events on the main
-    stream): 6.07-6.10 ms per clip against 6.17 with the fusion levels forked, 6.7 with the text encoder on a third stream,
-    6.96 with the tail in front of the text encoder, and 6.30 for the one-graph pipeline.  Giving the auxiliary stream its own
-    CUs (hipExtStreamCreateWithCUMask; the kernels size their grids from the stream's mask, soc_stream_cus) was measured too and
-    is slower at every split tried (8 / 16 / 24 / 32 CUs: 14.3 / 7.8 / 8.9 / 7.0 ms): Video-Swin alone takes 5.2 ms on 248 CUs
-    against 3.4 on 256.
+    single-branch graph.  Measured (tools/experiments/partition_probe.py, pipeline_ab.py; always inside one process, the boxes
+    differ by 6 %): the schedule above 6.07-6.10 ms per clip on the box where the pieces alone take 3.37 + 2.19 (main) and 0.81 +
+    0.88 (aux); 6.17 with the fusion levels forked, 6.7 with the text encoder on a third stream, 6.96 with the tail in front of
+    the text encoder.  Against the one-graph pipeline in the same process it is a tie (6.43-6.51 both), so the idea that the
+    head loses 0.6-0.7 ms to COLLISIONS with short launches is wrong: what the head loses is the CU time the tail and the text
+    encoder really need.  Giving the auxiliary stream its own CUs (hipExtStreamCreateWithCUMask; the kernels size their grids
+    from the stream's mask, soc_stream_cus) was measured too and is slower at every split tried (8 / 16 / 24 / 32 CUs: 14.3 /
+    7.8 / 8.9 / 7.0 ms): Video-Swin alone takes 5.2 ms on 248 CUs against 3.4 on 256 -- the dispatcher deals workgroups to the
+    shader engines evenly whatever the mask leaves of each.  Kept as an option (SOC_PIPELINE=two-stream, bench.py --pipeline):
+    its four single-branch launches cost the host 0.25 ms per clip where the one multi-branch launch blocks it for 1.2-4.8 ms.
 
     Hand-over: Video-Swin(i) and the encoder write the double-buffered state sb[i % 2] (as in the parent); the text encoder
     writes tx[i % 2].  Cross-stream order is carried by events recorded / awaited around the graph launches (never inside a
@@ -440,7 +444,9 @@ PIPELINES = {"two-stream": TwoStreamClipGraph, "one-graph": PipelinedClipGraph}
 
 
 def pipeline_class(name: Optional[str] = None):
-    """The software pipeline across clips the drivers and bench.py stream through: "two-stream" (default; SOC_PIPELINE
-    overrides) or "one-graph" (rounds 1-4)."""
+    """The software pipeline across clips the drivers and bench.py stream through: "one-graph" (default; SOC_PIPELINE
+    overrides) or "two-stream".  Same GPU time per clip within the box-to-box spread (tools/experiments/pipeline_ab.py in
+    one process: 6.44-6.51 ms both; bench.py on one of three boxes: two-stream 0.2 ms slower); the two-stream form needs
+    0.25 ms of host time per clip for its four single-branch launches where the one multi-branch launch blocks 1.2-4.8 ms."""
     import os
-    return PIPELINES[name or os.environ.get("SOC_PIPELINE", "two-stream")]
+    return PIPELINES[name or os.environ.get("SOC_PIPELINE", "one-graph")]

@@ -334,8 +334,8 @@ def test_clip_inferencer_pads_expressions_for_graph_reuse(gpu_model, golden):
 
 @pytest.mark.parametrize("pipeline", ["two-stream", "one-graph"])
 def test_pipelined_graph_matches_plain_graph(gpu_model, pipeline):
-    """The software pipelines (tail of clip i beside the head of clip i+1: TwoStreamClipGraph, what ships, and the one-graph
-    PipelinedClipGraph of rounds 1-4) return ClipGraph's records, one call late."""
+    """The software pipelines (tail of clip i beside the head of clip i+1: the one-graph PipelinedClipGraph, what ships, and
+    TwoStreamClipGraph) return ClipGraph's records, one call late."""
     from neurips2023_soc_amd.graph_runner import ClipGraph, pipeline_class
     PipelinedClipGraph = pipeline_class(pipeline)
     T, H, Wd, L = 3, 96, 128, 6
@@ -418,7 +418,7 @@ sys.path.insert(0, %r)
 import neurips2023_soc_amd as S
 from neurips2023_soc_amd import weights as W
 from neurips2023_soc_amd.graph_runner import pipeline_class
-PipelinedClipGraph = pipeline_class()          # the shipped one (two-stream)
+PipelinedClipGraph = pipeline_class()          # the shipped one
 T, H, Wd, L, N = 8, 360, 640, 10, 1536
 model, _, _ = S.build_model(S.default_args(text_encoder_random_init=True))
 W.load_synthetic(model, 2023)

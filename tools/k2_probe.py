@@ -1,5 +1,6 @@
-"""K2 (multi-scale deformable attention) at the BASELINE encoder size: plain fused launch vs the LDS-staged encoder form.
-usage: python tools/k2_probe.py [reps]      (run under rocprofv3 --pmc ... for the cache counters)"""
+"""K2 (multi-scale deformable attention, fused form) at the encoder size of the BASELINE configurations.
+usage: python tools/k2_probe.py [reps] [360p|720p] [offset scale]      (run under rocprofv3 --pmc ... for the cache counters)
+360p: S = 4 820 per frame (configs 1-3, 5); 720p: S = 19 160 (config 4)."""
 import sys
 
 import torch
@@ -9,8 +10,8 @@ from neurips2023_soc_amd import hot_ops  # noqa: E402
 from neurips2023_soc_amd.deformable_transformer import DeformableTransformerEncoder as E  # noqa: E402
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 50
-which = sys.argv[2] if len(sys.argv) > 2 else "both"
-shapes = [[45, 80], [23, 40], [12, 20], [6, 10]]
+which = sys.argv[2] if len(sys.argv) > 2 else "360p"
+shapes = {"360p": [[45, 80], [23, 40], [12, 20], [6, 10]], "720p": [[90, 160], [45, 80], [23, 40], [12, 20]]}[which]
 N, M = 8, 8
 sh = torch.tensor(shapes).cuda()
 lsi = torch.cat((sh.new_zeros(1), sh.prod(1).cumsum(0)[:-1]))
@@ -40,9 +41,7 @@ def timeit(fn):
     return s.elapsed_time(e) / reps * 1e3
 
 
-if which in ("both", "plain"):
-    us = timeit(lambda: hot_ops.msda_fused_forward(value, sh, lsi, ref, off, logits))
-    print(f"plain fused launch   : {us:7.1f} us  {algo / us / 1e3:7.1f} GB/s algorithmic ({algo / us / 1e3 / 8000:.3f} of HBM peak)")
-if which in ("both", "patch"):
-    us = timeit(lambda: hot_ops.msda_fused_forward(value, sh, lsi, ref, off, logits, shapes_list=shapes))
-    print(f"encoder form, LDS    : {us:7.1f} us  {algo / us / 1e3:7.1f} GB/s algorithmic ({algo / us / 1e3 / 8000:.3f} of HBM peak)")
+us = timeit(lambda: hot_ops.msda_fused_forward(value, sh, lsi, ref, off, logits))
+taps = N * S * M * 64                       # 16 points x 4 bilinear taps per (query, head), 128 B (two 64-B L1 accesses) each
+print(f"K2 fused {which} S={S}: {us:7.1f} us  {algo / us / 1e3:7.1f} GB/s algorithmic ({algo / us / 1e3 / 8000:.3f} of HBM peak); "
+      f"gather {taps * 128 / 1e9:.2f} GB through the L1s = {taps * 128 / us / 1e6:.1f} TB/s, {2 * taps / 1e6:.1f} M 64-B accesses")
