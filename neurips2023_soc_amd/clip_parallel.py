@@ -110,10 +110,22 @@ def rank_cpu_share(rank: int, world: int, allowed: Sequence[int], granted: int) 
 
 
 def pin_rank_cpus(rank: int, world: int) -> List[int]:
-    """Pin this process to its share (world > 1 only) and size torch's intra-op pool to it.  Returns the CPUs kept."""
+    """Pin this process to its share (world > 1 only) and size torch's intra-op pool to it.  Returns the CPUs kept.
+    The share is a share of THIS NODE's CPUs: under a multi-node launch the node's ranks are LOCAL_RANK of LOCAL_WORLD_SIZE
+    (torch.distributed.run sets both), not RANK of WORLD_SIZE.  The native library is loaded -- and, if stale, rebuilt with
+    the node's full CPU set -- before the pin, not after it with a two-CPU compiler pool while the other ranks wait."""
     if world <= 1 or not hasattr(os, "sched_setaffinity"):
         return sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else []
-    share = rank_cpu_share(rank, world, os.sched_getaffinity(0), granted_cpus())
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    local_rank = int(os.environ.get("LOCAL_RANK", rank % max(local_world, 1)))
+    if not (0 < local_world <= world and 0 <= local_rank < local_world):
+        local_rank, local_world = rank, world
+    try:
+        from . import _lib
+        _lib.load()
+    except Exception:           # noqa: BLE001 -- a CPU-only stub run has no library to load; the product path fails later, loudly
+        pass
+    share = rank_cpu_share(local_rank, local_world, os.sched_getaffinity(0), granted_cpus())
     try:
         os.sched_setaffinity(0, share)
         torch.set_num_threads(len(share))

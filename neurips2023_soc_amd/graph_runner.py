@@ -18,6 +18,26 @@ from . import postprocessing as P
 from .nested_tensor import NestedTensor
 
 
+# Diagnostic switches read from the environment (gathered here; bench.py records every one that is set).  The
+# first four are read while a graph is CAPTURED and change what is captured; none of them changes results beyond f32 rounding.
+SWITCHES = {
+    "SOC_PIPELINE": "one-graph | two-stream: which software pipeline pipeline_class() returns (default one-graph)",
+    "SOC_NO_PLACE": "1: the head's two large hand-over tensors are copied into the static state instead of produced there",
+    "SOC_TAIL_ROW_FUSION": "1: the pipelined tail keeps K16's fused row chains (default: K7's small workgroups beside a head)",
+    "SOC_TAIL_NO_FORK": "1: the tail never forks FPN || query chain, not even in the drain graph",
+    "SOC_TAIL_PRIORITY": "0: the tail branch of the one-graph pipeline is captured at default stream priority (default: high)",
+    "SOC_MATMUL": "split | f32: arithmetic a model is built with (hot_ops.DEFAULT_MATMUL_MODE; SOC.matmul_mode overrides per model)",
+    "SOC_SPLIT_OFF": "comma list of call sites / kernels forced back to the f32 path (k1, k13, k24, mlp, swin, gelu, ...)",
+    "SOC_PNG": "pillow: the drivers write PNGs through Pillow instead of libsoc_host.so (SOC_PNG_LEVEL: its compress_level)",
+}
+
+
+def switches_set() -> Dict[str, str]:
+    """The diagnostic switches that are set in this process's environment (empty in a default run)."""
+    import os
+    return {k: os.environ[k] for k in list(SWITCHES) + ["SOC_PNG_LEVEL"] if os.environ.get(k) not in (None, "")}
+
+
 # Stream-capture error mode.  The drivers decode and upload the NEXT clip on a background thread (clip_io.VideoClipCache)
 # while this thread captures a graph: in HIP's default "global" mode a hipMalloc / hipHostMalloc issued by ANY thread during
 # the capture invalidates it (hipErrorStreamCaptureInvalidated -- seen as a rare failure of the Ref-YouTube-VOS driver test in

@@ -43,10 +43,16 @@ def davis_palette() -> list:
 
 
 def save_label_map(labels: np.ndarray, path: str, palette: Sequence[int]) -> None:
-    from PIL import Image
-    img = Image.fromarray(labels.astype(np.uint8))
-    img.putpalette(list(palette))
-    img.save(path, compress_level=1)      # same pixels and palette, zlib level 1 (see infer_refytb.save_binary_mask)
+    """[H,W] object labels -> 8-bit palette PNG (reference infer_davis.py:285-291): same pixels and palette; written by the
+    run-length encoder of libsoc_host.so unless SOC_PNG=pillow (see infer_refytb.save_binary_mask)."""
+    from . import png_fast
+    if png_fast.use_pillow():
+        from PIL import Image
+        img = Image.fromarray(labels.astype(np.uint8))
+        img.putpalette(list(palette))
+        img.save(path, **png_fast.pillow_save_kwargs())
+    else:
+        png_fast.save(path, labels.astype(np.uint8, copy=False), palette=palette)
 
 
 @torch.no_grad()

@@ -36,11 +36,16 @@ def split_videos(videos: Sequence[str], rank: int, world: int):
 
 
 def save_binary_mask(mask: np.ndarray, path: str) -> None:
-    """bool/0-1 [H,W] -> 8-bit 'L' PNG with 0 / 255 (reference :272-277).  Same mode and pixels as the reference writes;
-    zlib level 1 instead of Pillow's default 6: 1.7 instead of 3.0 ms of CPU per 720p mask (profiles/r04_files_to_png.json --
-    at 8 masks per clip the PNG encoder is the larger half of the host's work), files of 6 KB instead of 3 KB."""
-    from PIL import Image
-    Image.fromarray(mask.astype(np.uint8) * 255, mode="L").save(path, compress_level=1)
+    """bool/0-1 [H,W] -> 8-bit 'L' PNG with 0 / 255 (reference :272-277).  Same mode and pixels as the reference writes.
+    Written by the run-length encoder of libsoc_host.so (png_fast.py: ~0.2 ms of CPU per 720p mask where zlib needs 1.9 at its
+    fastest level and 3.0 at Pillow's default -- at 8 masks per clip the PNG encoder was the larger half of the host's work,
+    profiles/r04_files_to_png.json); SOC_PNG=pillow writes through Pillow instead (SOC_PNG_LEVEL, default Pillow's own)."""
+    from . import png_fast
+    if png_fast.use_pillow():
+        from PIL import Image
+        Image.fromarray(mask.astype(np.uint8) * 255, mode="L").save(path, **png_fast.pillow_save_kwargs())
+    else:
+        png_fast.save(path, mask, binarize=True)
 
 
 def load_meta(root: str, split: str = "valid"):

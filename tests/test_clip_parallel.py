@@ -176,3 +176,21 @@ def test_rank_cpu_shares_partition_the_granted_cpus():
     shares = [CP.rank_cpu_share(r, 8, [3, 5, 7, 9], 4) for r in range(8)]
     assert all(len(s) == 1 for s in shares) and {s[0] for s in shares} == {3, 5, 7, 9}
     assert CP.rank_cpu_share(2, 4, [10, 11, 12, 13, 14, 15, 16, 17], 8) == [14, 15]
+
+
+def test_pin_rank_cpus_uses_the_local_rank_of_a_multi_node_launch(monkeypatch):
+    """under `torch.distributed.run --nnodes 2 --nproc-per-node 4` rank 5 is LOCAL rank 1 of 4 on its node: it takes
+    the second quarter of THAT node's CPUs, not the sixth eighth."""
+    import os
+    pinned = {}
+    allowed = set(range(16))
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: allowed)
+    monkeypatch.setattr(os, "sched_setaffinity", lambda pid, cpus: pinned.update(cpus=list(cpus)))
+    monkeypatch.setattr(CP, "granted_cpus", lambda *a: 16)
+    monkeypatch.setattr(CP.torch, "set_num_threads", lambda n: pinned.update(threads=n))
+    monkeypatch.setenv("LOCAL_RANK", "1")
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "4")
+    assert CP.pin_rank_cpus(5, 8) == [4, 5, 6, 7] and pinned == {"cpus": [4, 5, 6, 7], "threads": 4}
+    monkeypatch.delenv("LOCAL_RANK")
+    monkeypatch.delenv("LOCAL_WORLD_SIZE")
+    assert CP.pin_rank_cpus(5, 8) == [10, 11]             # one node: the global rank is the local one

@@ -162,3 +162,12 @@ def test_derived_cache_keys_on_the_tensors_and_dies_with_them():
     del w, wt
     gc.collect()
     assert len(c) == 0                                                                      # freed with the parameter
+    # a parameter re-pointed with `p.data = new` keeps its old entry's key reachable for whoever is later
+    # allocated at the old address; an entry is only hit while its owner still sits at the keyed address
+    p1 = torch.nn.Parameter(torch.randn(8, 4))
+    assert c.get((p1,), build) == 6 and c.get((p1,), build) == 6
+    old = p1.data
+    key_view = old[:]                    # same address, shape, strides, version as the keyed tensor, another owner
+    p1.data = torch.randn(8, 4)
+    assert c.get((key_view,), build) == 7                                                   # not the stale image
+    assert c.get((p1,), build) == 8 and c.get((p1,), build) == 8                            # the re-pointed parameter: rebuilt once
