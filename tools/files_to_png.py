@@ -3,7 +3,7 @@ it: the driver on a synthetic Ref-YouTube-VOS-shaped set (N 
 expressions), plus the CPU seconds one clip costs on the host side -- JPEG decode (once per video, shared by its expressions)
 and PNG encode (8 masks per clip) -- measured single-threaded, and the clips/s at which the granted CPUs saturate.
 
-    python tools/files_to_png.py [--videos 64] [--out profiles/r04_files_to_png.json]
+    python tools/files_to_png.py [--videos 64] [--out profiles/r05_files_to_png.json]
 """
 import argparse
 import json
@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 ap = argparse.ArgumentParser()
 ap.add_argument("--videos", type=int, default=64)
-ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r04_files_to_png.json"))
+ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r05_files_to_png.json"))
 a = ap.parse_args()
 
 import numpy as np  # noqa: E402
