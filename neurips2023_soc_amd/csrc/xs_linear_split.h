@@ -57,7 +57,7 @@ template <int K, int ACT, bool HAS_LN, int NCT>
 __global__ __launch_bounds__(Geo<K>::NW * 64, Geo<K>::NW / 4) void xs_linear_kernel(
     const float* __restrict__ x, const u32x4* __restrict__ img, const float* __restrict__ bias,
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps, const float* __restrict__ res,
-    float* __restrict__ out, long M, int N, int nrg, int ncr) {
+    float* __restrict__ out, long M, int N, int nrg, int ncr, int xcd_rows) {
     using G = Geo<K>;
     constexpr int NW = G::NW, THREADS = NW * 64, KS = G::KS, SB = G::SB, CTP = G::CTP, NSLOT = G::NSLOT;
     constexpr int SLOT = G::PIECE_U4, P = SLOT / THREADS, D = NSLOT - 1, NQ = NCT * SB / CTP, KSP = KS / SB;
@@ -72,7 +72,22 @@ __global__ __launch_bounds__(Geo<K>::NW * 64, Geo<K>::NW / 4) void xs_linear_ker
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, kq = lane >> 4;
-    const int cr = blockIdx.x % ncr, g = blockIdx.x / ncr;
+    // Workgroup -> (row group g, column range cr).  Workgroups are dealt to the 8 XCDs round-robin (b, b + 8, ... share an XCD
+    // and its private 4 MB L2).  Default: consecutive workgroups are the column ranges of one row group, so an XCD streams
+    // 1 / gcd(ncr, 8) of the weight image and sees gcd(ncr, 8) / 8 of the rows -- the rows of x are fetched from HBM once per
+    // column range.  xcd_rows (chosen by the launcher when the whole weight image fits an L2 beside the rows): the ncr
+    // workgroups of a row group sit on ONE XCD, x comes from HBM once and from that L2 for the other ranges, every XCD streams
+    // the whole image (stage-2 qkv of Video-Swin-T: 50 -> 33 MB of HBM traffic per launch).
+    int cr, g;
+    if (xcd_rows) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        cr = j % ncr;
+        g = (j / ncr) * 8 + xcd;
+        if (g >= nrg) return;           // the grid is padded to whole groups of 8 row groups: a surplus workgroup has no rows
+    } else {
+        cr = blockIdx.x % ncr;
+        g = blockIdx.x / ncr;
+    }
     const int n0 = cr * NCT * 16;                                       // first column of this range
     const long ntiles = (M + 15) >> 4;
     const long t0 = (long)g * ntiles / nrg, t1 = (long)(g + 1) * ntiles / nrg;
@@ -258,6 +273,21 @@ int num_cus(hipStream_t st) { return soc_num_cus(st); }      // CUs the launch s
 
 using soc_xs::Args;
 
+// HBM traffic of the two workgroup -> XCD mappings (see the kernel): rows x gcd + 8 images / gcd against rows + 8 images.  The
+// second one needs the whole split image (6 B per weight) in an XCD's 4 MB L2 beside its share of the rows (the grid is
+// padded to whole groups of 8 row groups, one per XCD; surplus workgroups return at once).
+inline int xcd_rows_pays(long M, int N, int K, int nrg, int ncr) {
+#ifdef SOC_K24_NO_XCD_ROWS          // diagnostic build: the round-4 mapping everywhere (tools/experiments/k24_xcd_rows.py)
+    return 0;
+#endif
+    if (ncr <= 1 || nrg < 8) return 0;
+    const double x_bytes = 4.0 * (double)M * K, w_bytes = 6.0 * (double)N * K;
+    if (w_bytes > 3.0 * 1024 * 1024) return 0;
+    int g = 8;
+    while (ncr % g != 0) g >>= 1;                       // gcd(ncr, 8)
+    return x_bytes + 8.0 * w_bytes < x_bytes * g + 8.0 * w_bytes / g ? 1 : 0;
+}
+
 template <int K, int ACT, bool HAS_LN, int NCT>
 int launch(const Args& a) {
     using G = Geo<K>;
@@ -270,8 +300,10 @@ int launch(const Args& a) {
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return SOC_ELAUNCH;
         attr_set[dev].store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL((xs_linear_kernel<K, ACT, HAS_LN, NCT>), dim3((unsigned)(a.nrg * a.ncr)), dim3(G::NW * 64), lds, a.st,
-                       a.x, a.img, a.bias, a.gamma, a.beta, a.eps, a.res, a.out, a.M, a.N, a.nrg, a.ncr);
+    const int xcd_rows = xcd_rows_pays(a.M, a.N, K, a.nrg, a.ncr);
+    const int groups = xcd_rows ? (a.nrg + 7) / 8 * 8 : a.nrg;         // xcd_rows: whole groups of 8 row groups (one per XCD)
+    hipLaunchKernelGGL((xs_linear_kernel<K, ACT, HAS_LN, NCT>), dim3((unsigned)(groups * a.ncr)), dim3(G::NW * 64), lds, a.st,
+                       a.x, a.img, a.bias, a.gamma, a.beta, a.eps, a.res, a.out, a.M, a.N, a.nrg, a.ncr, xcd_rows);
     return soc_check_launch();
 }
 
