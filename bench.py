@@ -172,6 +172,8 @@ def compact_line(full):
         for k, v in full.get("roofline_other", {}).items():
             fams[k] = {"bound": "hbm", "frac": round(v["frac"], 4), "ms_per_clip": round(v["ms_per_clip"], 4),
                        "avg_launch_us": round(v["avg_launch_us"], 1)}
+            if "ta_busy_share" in v:          # K2: bound by the CUs' vector-memory path, not by HBM
+                fams[k]["texture_path_busy"] = v["ta_busy_share"]
         line["roofline_families"] = fams
     if "cpu_baseline" in full:
         line["cpu_baseline"] = {k: full["cpu_baseline"][k] for k in ("value", "unit", "cores", "kind", "cpu_model", "sample")}
@@ -621,6 +623,17 @@ def main():
                                "ms_per_clip": r["ms"] / a.steps,
                                "algorithmic_bytes_per_clip": r["work"] / a.steps,
                                "traffic": traffic.get(name) if default_cfg else None}
+        if "msda_fwd" in other:
+            # K2's binding unit is not HBM: the CU's vector-memory (texture) path, 64 B per clock -- measured busy share from
+            # the committed counter passes
+            try:
+                with open(os.path.join(ROOT, "profiles", "r05_k2_counters.json")) as fh:
+                    k2 = json.load(fh)["k2_fused_720p" if H >= 720 else "k2_fused_360p"]["derived"]
+                other["msda_fwd"]["binding_unit"] = ("vector-memory (texture) path of the CUs, 64 B/clk each: busy "
+                                                     f"{k2['ta_busy_share']:.2f} of the launch (profiles/r05_k2_counters.json)")
+                other["msda_fwd"]["ta_busy_share"] = round(k2["ta_busy_share"], 3)
+            except (OSError, KeyError, ValueError):
+                pass
         line["roofline_other"] = other
         # every hand-written kernel of the forward (HIP-event time of the instrumented eager pass)
         from neurips2023_soc_amd.graph_runner import switches_set
