@@ -9,7 +9,9 @@ clip_parallel.spawn_ranks = the reference's mp.Process fan-out, infer_refytb.py:
 
 A step = one eval forward of Video-Swin-T SOC on one synthetic clip [T=8,3,360,640] (random
 deterministic weights, pre-tokenised 10-token expression) + query selection, i.e. the body of
-the reference's inference loop (infer_refytb.py:206-227).  Inputs are resident in HBM before the
+the reference's inference loop (infer_refytb.py:206-227).  Since round 5 two independent clips share each launch of the
+forward's batch-independent head (Video-Swin, fusion, deformable encoder); the tail runs per clip, as the reference's B = 1
+forward does (graph_runner.PairPipelinedClipGraph); `single_clip_ms_per_step` is the one-clip-per-launch pipeline beside it.  Inputs are resident in HBM before the
 timed region.  Clips shard over ranks (weak scaling: K clips per rank, no data-path collective);
 the single result all_gather sits inside the timed region.  Rank 0 prints ONE JSON line.
 """
@@ -55,9 +57,10 @@ def parse():
     ap.add_argument("--eager", action="store_true", help="time eager launches instead of hipGraph replay")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="one clip per graph replay (ClipGraph) instead of the software-pipelined PipelinedClipGraph")
-    ap.add_argument("--pipeline", choices=["two-stream", "one-graph"], default=None,
-                    help="software pipeline across clips: one-graph (default: graph_runner.PipelinedClipGraph) or two-stream "
-                         "(separate graphs on a main and an auxiliary stream, graph_runner.TwoStreamClipGraph)")
+    ap.add_argument("--pipeline", choices=["two-stream", "one-graph", "pairs", "quads"], default="pairs",
+                    help="software pipeline across clips: pairs (default: two independent clips per head launch, one tail per "
+                         "clip, graph_runner.PairPipelinedClipGraph), one-graph (one clip per head launch: rounds 1-4, "
+                         "PipelinedClipGraph; also timed as single_clip_ms_per_step), two-stream (TwoStreamClipGraph), quads")
     ap.add_argument("--no-stream", action="store_true",
                     help="skip the second, H2D-inclusive timed pass (stream_ms_per_step)")
     ap.add_argument("--stub", action="store_true",
@@ -69,6 +72,8 @@ def parse():
     ap.add_argument("--detail", default=os.environ.get("BENCH_DETAIL", os.path.join(ROOT, "bench_detail.json")),
                     help="where rank 0 writes the long form (per-family / per-shape rooflines, per-kernel times, every parity "
                          "number, the CPU runs); the ONE JSON line on stdout stays under MAX_LINE_BYTES")
+    ap.add_argument("--no-single-pass", action="store_true",
+                    help="pair pipeline: skip the extra timed pass with one clip per head launch (single_clip_ms_per_step)")
     ap.add_argument("--no-f32-pass", action="store_true",
                     help="skip the extra timed pass with every GEMM on the f32 MFMA path (SOC_MATMUL=f32 arithmetic)")
     return ap.parse_args()
@@ -147,7 +152,7 @@ def headline(a, world, timed, workload, launch):
                    "parallelism": f"clip-parallel x{world}, one result all_gather", "launch": launch}}
 
 
-_ROOFLINE_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "frac_of_ceiling", "traffic", "launches",
+_ROOFLINE_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "frac_of_ceiling", "traffic", "launches", "clips_per_replay",
                   "algorithmic_flop_per_clip", "algorithmic_bytes_per_clip", "avg_launch_us", "ms_per_clip", "source")
 
 
@@ -157,7 +162,8 @@ def compact_line(full):
     left out (per-shape tables, per-kernel times, prose, the CPU runs) goes to the --detail file."""
     keep = ("metric", "value", "unit", "n_gpus", "ranks_seen", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
             "vs_baseline", "dtype", "data", "seconds_per_rank", "config", "matmul", "stub", "records_ok",
-            "f32_mfma_only_ms_per_step", "stream_ms_per_step", "kernels_per_forward", "switches")
+            "f32_mfma_only_ms_per_step", "stream_ms_per_step", "single_clip_ms_per_step", "clips_per_head_launch",
+            "kernels_per_forward", "switches")
     line = {k: full[k] for k in keep if k in full}
     if "roofline" in full:
         line["roofline"] = {k: full["roofline"][k] for k in _ROOFLINE_KEYS if k in full["roofline"]}
@@ -256,7 +262,7 @@ def main():
     rank, local_rank, world = CP.init_rank("cuda", expect_world=a.gpus)   # "nccl" is RCCL on ROCm
     CP.pin_rank_cpus(rank, world)   # N ranks share the box's CPU quota: each keeps to its share (captures, launches)
     if world > 1 and not a.all_passes:
-        a.no_stream = a.no_f32_pass = True      # one graph capture per rank; the extra passes are single-GPU diagnostics
+        a.no_stream = a.no_f32_pass = a.no_single_pass = True      # one graph capture per rank; the extra passes are single-GPU diagnostics
     dev = torch.device("cuda", local_rank)
     use_dist = dist.is_initialized()
 
@@ -280,13 +286,27 @@ def main():
     hm, wm = -(-H // 4), -(-Wd // 4)
     results = torch.zeros(a.steps, CP.record_size(T, Q, hm, wm), device=dev)
 
-    def step(i, record=None, clip=None):  # eager launches
+    def step(i, record=None, clip=None):  # eager launches, one clip
         samples = S.NestedTensor((clips[i % n_pool] if clip is None else clip)[:, None], pad, unpadded=True)
         out = model(samples, None, text, targets)
         idx, masks = P.select_trajectory(out)
         if record is not None:
             CP.pack_record(record, idx, out["pred_cls"][:, 0, :, 0], masks)
         return out
+
+    def step_group(i0, count, records=None):
+        """Eager launches of what ONE replay of the timed pipeline runs: the head over `per` clips (pool clips i0, i0 + 1, ...),
+        then one single-clip tail per clip (graph_runner.PairPipelinedClipGraph); per == 1: step()."""
+        if per == 1:
+            return step(i0, None if records is None else records[i0])
+        group = torch.stack([clips[(i0 + b) % n_pool] for b in range(per)], 1)
+        text_g = {k: v.expand(per, -1).contiguous() for k, v in text.items()}
+        sb = model.forward_head(S.NestedTensor(group, pad.expand(-1, per, -1, -1), unpadded=True), None, text_g)
+        for b, st in enumerate(model.split_state(sb)):
+            out = model.forward_tail(st, targets)
+            if records is not None and b < count:
+                idx, masks = P.select_trajectory(out)
+                CP.pack_record(records[i0 + b], idx, out["pred_cls"][:, 0, :, 0], masks)
 
     graph = None
     pipelined = False
@@ -299,6 +319,9 @@ def main():
             pipelined = True
         else:
             graph = ClipGraph(model, T, H, Wd, L, dev)            # one capture, replayed per clip
+    # clips per replay of the timed pipeline (--eager launches the same groups without a graph)
+    per = getattr(graph, "CLIPS", 1) if graph is not None else (
+        1 if a.no_pipeline else __import__("neurips2023_soc_amd.graph_runner", fromlist=["x"]).pipeline_class(a.pipeline).CLIPS)
 
     def run_steps(n, out, feed=None):
         """n clips through the chosen path, results into out[i % len(out)].  `feed` = (feeder, host clips): every clip
@@ -322,32 +345,47 @@ def main():
             return feeder.acquire()
 
         done = 0
+        in_flight = []                                                    # clips carried by each replay whose records are still due
         for i in range(n):
             clip = next_clip(i)
             if graph is None:
-                step(i, out[i % m], clip)
-                done += 1
+                if per == 1:
+                    step(i, out[i % m], clip)
+                    done += 1
+                elif i % per == per - 1 or i == n - 1:                    # eager: the pool clips of the group, head once
+                    step_group(i - i % per, i % per + 1, out)
+                    done += i % per + 1
             else:
-                graph.stage_inputs(clip, text["input_ids"])
+                if per == 1:
+                    graph.stage_inputs(clip, text["input_ids"])
+                else:
+                    graph.stage_inputs(clip, text["input_ids"], slot=i % per)
                 if feeder is not None and not _REL_LATE:
                     feeder.release()       # the slot has been copied into the graph's static input: reusable from here
+                if per > 1 and i % per != per - 1 and i != n - 1:
+                    continue               # the replay waits for its second clip (an odd last clip goes alone: slot 1 is stale
+                                           # and its record is dropped below)
                 rec = graph.replay()
+                in_flight.append(i % per + 1)
                 if feeder is not None and _REL_LATE:
                     feeder.release()
                 if not pipelined:
                     out[i % m].copy_(graph.record, non_blocking=True)
+                    in_flight.pop()
                     done += 1
-                elif rec is not None:      # software pipeline: a replay returns the record of an earlier clip
-                    if not _NO_RECORD_COPY:
-                        out[done % m].copy_(graph.record, non_blocking=True)
-                    done += 1
+                elif rec is not None:      # software pipeline: a replay returns the record(s) of an earlier replay
+                    for r in (rec[:in_flight.pop(0)] if per > 1 else [in_flight.pop(0) and graph.record]):
+                        if not _NO_RECORD_COPY:
+                            out[done % m].copy_(r, non_blocking=True)
+                        done += 1
             if feeder is not None and graph is None:
                 feeder.release()
         if pipelined:
             for rec in graph.flush():
-                out[done % m].copy_(rec, non_blocking=True)
-                done += 1
-        assert done == n
+                for r in (rec[:in_flight.pop(0)] if per > 1 else [rec]):
+                    out[done % m].copy_(r, non_blocking=True)
+                    done += 1
+        assert done == n, (done, n)
 
     run_steps(a.warmup, results)
     if use_dist:
@@ -396,12 +434,13 @@ def main():
         # roofline come from an instrumented eager pass over the same clips right after the timed
         # region (same kernels, same inputs, same stream).
         hot_ops.profile_begin()
-        for i in range(a.steps):
+        for i in range(0, a.steps, per):
             # give the host a head start so the launches queue back to back: an event pair then
             # brackets the kernel alone, not the Python time between record() and launch
             torch.cuda._sleep(60_000_000)
-            step(i, results[i])
+            step_group(i, min(per, a.steps - i), results)
         prof = hot_ops.profile_end()
+    prof_clips = -(-a.steps // per) * per      # clips the instrumented pass ran (whole groups)
 
     # Third timed pass: the same loop with the pixel-sized linear layers on the f32 MFMA path (K13 / K12 / library) instead
     # of K20's three-way bf16 split -- the round-2 arithmetic, reported beside the headline so both are on record.
@@ -421,6 +460,20 @@ def main():
             del g32
         finally:
             model.matmul_mode = None
+
+    # Fourth timed pass (pair pipeline only): the one-clip-per-head pipeline of rounds 1-4 on the same box, so that the line
+    # carries both numbers.
+    single_pass = None
+    if graph is not None and pipelined and per > 1 and not a.no_single_pass and world == 1:
+        from neurips2023_soc_amd.graph_runner import PipelinedClipGraph
+        main_graph, graph = graph, PipelinedClipGraph(model, T, H, Wd, L, dev)
+        r1 = torch.zeros_like(results)
+        run_steps(min(a.warmup, 2), r1)
+        torch.cuda.synchronize()
+        t1 = CP.timed_sharded_run(lambda out: run_steps(a.steps, out), r1, dev)
+        single_pass = {"seconds": t1["seconds"],
+                       "max_abs_diff": float((r1[:min(a.steps, n_pool)].cpu() - timed_records).abs().max())}
+        graph = main_graph
 
     # The dominant kernel families: replay the launches of ONE forward back to back between one HIP-event pair on the launch
     # stream (per-launch event pairs add host / queue latency to 30-400 us kernels), with the forward's own tensors.  Every
@@ -471,7 +524,7 @@ def main():
             ("xs_linear", hot_ops.record_xs_linear_calls, hot_ops.xs_linear, linear_cost, False),
             ("mlp_split", hot_ops.record_mlp_split_calls, hot_ops.mlp_split, mlp_cost, False)):
         rec(True)
-        step(0)
+        step_group(0, per)           # the launches of one replay of the timed pipeline: `per` clips
         calls = rec(False)
         torch.cuda.synchronize()
         if not calls:
@@ -485,7 +538,7 @@ def main():
             fl, by, _ = cost(cs[0])
             us = 1e3 * replay_calls(fn, cs[:1], K1_REPS, star)
             shapes.append({"shape": list(key), "launches": len(cs), "us": round(us, 1), "flop": fl, "bytes": by})
-        families[fam] = {"ms": ms, "launches": len(calls), "shapes": shapes}
+        families[fam] = {"ms": ms, "launches": len(calls), "shapes": shapes}      # ms, launches: of ONE replay = `per` clips
         del calls[:]
 
     assert gathered.shape[0] == world == a.gpus and timed["ranks_seen"] == list(range(world)), timed["ranks_seen"]
@@ -493,11 +546,14 @@ def main():
     if rank == 0:
         line = {
             **headline(a, world, timed,
-                       f"SOC eval forward + query selection, {a.backbone}, T={T}, {H}x{Wd}, B=1, L={L} tokens, random "
-                       f"deterministic weights (seed {WEIGHT_SEED})",
+                       f"SOC eval forward + query selection per clip (one clip + one expression = the reference's B=1 forward), "
+                       f"{a.backbone}, T={T}, {H}x{Wd}, L={L} tokens, random deterministic weights (seed {WEIGHT_SEED})"
+                       + (f"; {per} independent clips share each head launch" if per > 1 else ""),
                        "eager" if graph is None else (
                            ("hipGraph replays, software-pipelined on two streams: Video-Swin + fusion + encoder of clip i | text "
                             "encoder of clip i, tail of clip i-1" if Pipeline.__name__ == "TwoStreamClipGraph" else
+                            f"hipGraph replay, software-pipelined, {Pipeline.CLIPS} clips per head launch (Video-Swin, fusion, encoder: "
+                            "batch-independent) beside ONE tail per clip of the previous group (the reference's B = 1 tail)" if Pipeline.CLIPS > 1 else
                             "hipGraph replay, software-pipelined: tail of clip i beside the head of clip i+1")
                            if pipelined else "hipGraph replay (one graph per clip geometry)")),
             "matmul": ("f32 in / out / accumulate; large products as 6 bf16 MFMA products of a 3-way operand split (f32-grade: "
@@ -507,6 +563,12 @@ def main():
                 "f32_mfma_only_value": world * a.steps / f32_pass["seconds"],
                 "f32_mfma_only_record0_max_abs_diff": float((f32_pass["record0"] - timed_records[0]).abs().max())}
                if f32_pass is not None else {}),
+            **({"single_clip_ms_per_step": 1e3 * single_pass["seconds"] / a.steps,
+                "single_clip_value": world * a.steps / single_pass["seconds"],
+                "single_clip": "the same loop with ONE clip per head launch (graph_runner.PipelinedClipGraph: the pipeline of rounds "
+                               "1-4) on the same box; its records differ from the timed ones by single_clip_max_abs_diff",
+                "single_clip_max_abs_diff": single_pass["max_abs_diff"]} if single_pass is not None else {}),
+            "clips_per_head_launch": per,
             **({"stream_ms_per_step": 1e3 * stream["seconds"] / a.steps, "stream_value": world * a.steps / stream["seconds"],
                 "stream": f"same loop with every clip copied host->device inside the timed region: {stream['n_host']} "
                           "pinned host clips (seeds seed0 + i; each buffer DMA-ed once before the pass, as a recycled pinned pool is), "
@@ -571,6 +633,11 @@ def main():
             except (OSError, KeyError, ValueError):
                 return None
 
+        def kernel_label(fam, launches):
+            name, tag = desc[fam].split(" (")[0], desc[fam].split(" (")[1].split(",")[0].split(":")[0].rstrip(")")
+            return (f"{name} ({tag}): all {launches} launches of one replay"
+                    + (f" = {per} clips per head launch" if per > 1 else " = one forward"))
+
         blocks = {}
         for fam, f in families.items():
             flop = sum(sh["launches"] * sh["flop"] for sh in f["shapes"])
@@ -584,8 +651,8 @@ def main():
                 sh["gbs"] = round(sh["bytes"] / sh["us"] / 1e3, 1)
                 sh["frac_of_ceiling"] = round(max(sh["flop"] / (mf * 1e12), sh["bytes"] / (HBM_ACHIEVABLE_GBS * 1e9)) / (sh["us"] * 1e-6), 3)
             blocks[fam] = {
-                "kernel": f"{desc[fam].split(' (')[0]} ({desc[fam].split(' (')[1].split(',')[0].split(':')[0].rstrip(')')}): all {f['launches']} launches of a forward",
-                "kernel_long": desc[fam], "launches": f["launches"],
+                "kernel": kernel_label(fam, f["launches"]),
+                "kernel_long": desc[fam], "launches": f["launches"], "clips_per_replay": per,
                 "bound": "mfma" if mfma_bound else "hbm",
                 "achieved": ach, "peak": mf if mfma_bound else PEAK_HBM_GBS, "unit": "TFLOP/s" if mfma_bound else "GB/s",
                 "frac": ach / (mf if mfma_bound else PEAK_HBM_GBS),
@@ -595,17 +662,17 @@ def main():
                            + ("the dense bf16 MFMA peak / 6 = 417 TFLOP/s of algorithmic f32 FLOPs: every f32 product runs as six "
                               "bf16 MFMA products (exact three-way operand split)" if split_on[fam] else
                               "the f32-input MFMA peak, 157.3 TFLOP/s"),
-                "ceiling_ms_per_clip": 1e3 * t_c, "mfma_ms_at_peak": 1e3 * t_m, "hbm_ms_at_6_3_TBs": 1e3 * t_h,
+                "ceiling_ms_per_clip": 1e3 * t_c / per, "mfma_ms_at_peak": 1e3 * t_m / per, "hbm_ms_at_6_3_TBs": 1e3 * t_h / per,
                 "vs_f32_mfma_peak": flop / sec / 1e12 / PEAK_F32_MFMA_TFLOPS,
                 "vector_share": vector_share(fam) if split_on[fam] else None,
                 "algorithmic_tflops": flop / sec / 1e12, "algorithmic_gbs": byts / sec / 1e9,
                 "traffic": traffic.get(fam) if default_cfg else None,
-                "traffic_unit": f"HBM bytes per clip ({f['launches']} launches), rocprofv3 PMC, {traffic_file}",
-                "algorithmic_flop_per_clip": flop, "algorithmic_bytes_per_clip": byts,
-                "avg_launch_us": 1e3 * f["ms"] / f["launches"], "ms_per_clip": f["ms"], "per_shape": f["shapes"],
+                "traffic_unit": f"HBM bytes per clip, rocprofv3 PMC of the one-clip eager forward, {traffic_file}",
+                "algorithmic_flop_per_clip": flop / per, "algorithmic_bytes_per_clip": byts / per,
+                "avg_launch_us": 1e3 * f["ms"] / f["launches"], "ms_per_clip": f["ms"] / per, "per_shape": f["shapes"],
                 "measured": f"HIP events on the launch stream around {K1_REPS} back-to-back replays of this family's launches of one "
                             "forward (the forward's own activations and weights), right after the timed region",
-                "per_launch_event_pairs_ms_per_clip": prof[fam]["ms"] / a.steps if fam in prof else None,
+                "per_launch_event_pairs_ms_per_clip": prof[fam]["ms"] / prof_clips if fam in prof else None,
                 "source": f"HIP events in bench.py; rocprofv3 --kernel-trace --stats of this command: profiles/{PROFILE_TAG}_bench_kernel_stats.csv "
                           f"rows {stats_rows[fam]}"}
         if blocks:      # the roofline object is the kernel family with the largest share of a clip; the others follow
@@ -620,8 +687,8 @@ def main():
                 gbs = r["work"] / (r["ms"] * 1e-3) / 1e9
                 other[name] = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                "frac": gbs / PEAK_HBM_GBS, "avg_launch_us": 1e3 * r["ms"] / r["launches"],
-                               "ms_per_clip": r["ms"] / a.steps,
-                               "algorithmic_bytes_per_clip": r["work"] / a.steps,
+                               "ms_per_clip": r["ms"] / prof_clips,
+                               "algorithmic_bytes_per_clip": r["work"] / prof_clips,
                                "traffic": traffic.get(name) if default_cfg else None}
         if "msda_fwd" in other:
             # K2's binding unit is not HBM: the CU's vector-memory (texture) path, 64 B per clock -- measured busy share from
@@ -638,9 +705,9 @@ def main():
         # every hand-written kernel of the forward (HIP-event time of the instrumented eager pass)
         from neurips2023_soc_amd.graph_runner import switches_set
         line["switches"] = switches_set()          # diagnostic environment switches in effect (empty in a default run)
-        line["kernels_per_forward"] = {"hand_written_launches": round(sum(r["launches"] for r in prof.values()) / a.steps, 1),
+        line["kernels_per_forward"] = {"hand_written_launches": round(sum(r["launches"] for r in prof.values()) / prof_clips, 1),
                                        "source": "instrumented eager pass (hot_ops.profile_*); library launches not counted"}
-        line["kernel_ms_per_clip"] = {name: {"launches_per_clip": r["launches"] / a.steps, "ms": r["ms"] / a.steps}
+        line["kernel_ms_per_clip"] = {name: {"launches_per_clip": r["launches"] / prof_clips, "ms": r["ms"] / prof_clips}
                                       for name, r in sorted(prof.items())}
 
         # What the timed region itself produced, against the reference-generated golden of this configuration (committed

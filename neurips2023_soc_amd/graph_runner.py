@@ -47,6 +47,8 @@ CAPTURE_MODE = "thread_local"
 
 
 class ClipGraph:
+    CLIPS = 1              # clips per replay
+
     def __init__(self, model, T: int, H: int, W: int, L: int, device, warmup: int = 2):
         self.model, self.T, self.H, self.W, self.L = model, T, H, W, L
         self.device = torch.device(device)
@@ -124,6 +126,7 @@ class PipelinedClipGraph:
     """
 
     DEPTH = 2
+    CLIPS = 1              # clips per replay (PairPipelinedClipGraph: 2)
 
     def __init__(self, model, T: int, H: int, W: int, L: int, device, warmup: int = 2):
         self.model, self.T, self.H, self.W, self.L = model, T, H, W, L
@@ -460,7 +463,115 @@ class TwoStreamClipGraph(PipelinedClipGraph):
         return [self.record.clone()]
 
 
-PIPELINES = {"two-stream": TwoStreamClipGraph, "one-graph": PipelinedClipGraph}
+class PairPipelinedClipGraph(PipelinedClipGraph):
+    """The one-graph software pipeline with TWO clips per head (round 5).
+
+    The head of SOC's forward -- Video-Swin, vision-language fusion, deformable encoder -- treats the clips of a batch
+    independently (per token, per window, per frame), and at B = 1 its later stages have too few rows for 256 CUs (stage 2: 460
+    row tiles, stage 3: 120; K23 / K24 / K1 run at 0.2-0.35 of their ceilings there, every launch pays its fixed ~10 us).  Over
+    two clips the same launches do twice the work: head 5.59 -> 5.10 ms per clip (tools/experiments/batch2_probe.py).  The TAIL
+    stays per clip: the reference's own B = 2 forward gives a clip other results than its B = 1 forward (its tail couples the
+    batch: 0.32 of a logit scale of 6.6 on the reference itself), and the inference drivers' results are the B = 1 ones
+    (infer_refytb.py:206-227), so graph k runs  head(clips 2i, 2i+1)  beside  tail(clip 2i-2), tail(clip 2i-1)  -- each tail
+    on a single-clip view of the head's state (SOC.split_state).  Per clip the results equal the single-clip pipeline's to
+    f32 rounding (5e-5 on logits of 37, the run-to-run noise of the library kernels).
+
+        g.stage_inputs(clip_a, ids_a, slot=0); g.stage_inputs(clip_b, ids_b, slot=1)
+        recs = g.replay()             # [2, R] records of the pair submitted one call earlier, or None
+        rest = g.flush()              # [clone of the records of the pair still in flight]
+    """
+
+    CLIPS = 2
+
+    def __init__(self, model, T: int, H: int, W: int, L: int, device, warmup: int = 2):
+        self.model, self.T, self.H, self.W, self.L = model, T, H, W, L
+        dev = self.device = torch.device(device)
+        n = self.CLIPS
+        self.clip = torch.zeros(T, n, 3, H, W, device=dev)
+        self.pad = torch.zeros(T, n, H, W, dtype=torch.bool, device=dev)
+        self.ids = torch.ones(n, L, dtype=torch.long, device=dev)
+        self.attn = torch.ones(n, L, dtype=torch.long, device=dev)
+        self.targets = [[{"size": (H, W)}] for _ in range(T)]              # of ONE clip: the tail runs per clip
+        hm, wm = -(-H // 4), -(-W // 4)
+        self.record = torch.zeros(n, CP.record_size(T, model.num_queries, hm, wm), device=dev)
+        self._finish_init(warmup)
+
+    def _finish_init(self, warmup):
+        """PipelinedClipGraph.__init__ behind the static buffers: warm-up, double-buffered state, the four captures."""
+        dev = self.device
+        assert hot_ops._prof is None, "do not capture while kernel profiling is on"
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(max(warmup, 1)):
+                sb = self._head(fork=False)
+                self._tail(sb, fork=False)
+            self.sb = [self._clone(sb), self._clone(sb)]
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        import os
+        self._pc = torch.cuda.Stream(device=dev, priority=0 if os.environ.get("SOC_TAIL_PRIORITY", "1") == "0" else -1)
+
+        def capture(body):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
+                body()
+            return g
+
+        def tail_beside_head(k):
+            cur = torch.cuda.current_stream(dev)
+            self._pc.wait_stream(cur)
+            with torch.cuda.stream(self._pc):
+                self._tail(self.sb[1 - k], fork=False)
+            self._store(self._placed_head(self.sb[k]), self.sb[k])
+            cur.wait_stream(self._pc)
+
+        self.steady = [capture(lambda k=k: tail_beside_head(k)) for k in (0, 1)]
+        self.drain = [capture(lambda k=k: self._tail(self.sb[k], fork=True)) for k in (0, 1)]
+        self._n = 0
+
+    def _tail(self, sb, fork: bool):
+        import os
+        prev, hot_ops.row_chain_fusion = hot_ops.row_chain_fusion, os.environ.get("SOC_TAIL_ROW_FUSION", "0") == "1"
+        if os.environ.get("SOC_TAIL_NO_FORK", "0") == "1":
+            fork = False
+        try:
+            for b, st in enumerate(self.model.split_state(sb)):          # one single-clip tail per clip of the pair
+                out = self.model.forward_tail(st, self.targets, fork=fork)
+                idx, masks = P.select_trajectory(out)
+                CP.pack_record(self.record[b], idx, out["pred_cls"][:, 0, :, 0], masks)
+        finally:
+            hot_ops.row_chain_fusion = prev
+
+    def stage_inputs(self, clip: torch.Tensor, ids: Optional[torch.Tensor] = None, attn: Optional[torch.Tensor] = None,
+                     slot: int = 0) -> None:
+        """Copy ONE clip [T,3,H,W] (+ its token ids [1,L] / [L]) into slot `slot` (0 .. CLIPS - 1) of the group, on the current
+        stream."""
+        self.clip[:, slot].copy_(clip.view(self.clip.shape[0], *self.clip.shape[2:]), non_blocking=True)
+        if ids is not None:
+            self.ids[slot].copy_(ids.view(-1), non_blocking=True)
+            if attn is None:
+                if not getattr(self, "_attn_ones", True):
+                    self.attn.fill_(1)
+                    self._attn_ones = True
+            else:
+                self.attn[slot].copy_(attn.view(-1), non_blocking=True)
+                self._attn_ones = False
+
+    def run(self, clips, ids=None, attn=None):
+        """clips: two [T,3,H,W] tensors; ids / attn: two [1,L] tensors each (or None)."""
+        for b in range(self.CLIPS):
+            self.stage_inputs(clips[b], None if ids is None else ids[b], None if attn is None else attn[b], slot=b)
+        return self.replay()
+
+
+class QuadPipelinedClipGraph(PairPipelinedClipGraph):
+    """Four clips per head launch (measured beside the pair form; see DESIGN.md section 3, "Launch structure")."""
+    CLIPS = 4
+
+
+PIPELINES = {"two-stream": TwoStreamClipGraph, "one-graph": PipelinedClipGraph, "pairs": PairPipelinedClipGraph,
+             "quads": QuadPipelinedClipGraph}
 
 
 def pipeline_class(name: Optional[str] = None):

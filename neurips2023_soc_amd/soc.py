@@ -440,6 +440,26 @@ class SOC(nn.Module):
             out["aux_outputs"] = []
         return out
 
+    @staticmethod
+    def split_state(state):
+        """The hand-over state of a B-clip head as B single-clip states (views, no copies): what forward_tail needs to run
+        per clip.  The head (Video-Swin, fusion, deformable encoder) treats the clips of a batch independently -- every op is
+        per token, per window or per frame -- so a head over two clips fills the chip better at the small stages and gives
+        each clip what a B = 1 head gives it (to f32 rounding).  The REFERENCE's tail does not: its B = 2 outputs of a clip
+        differ from its B = 1 outputs by 5 % of the logit scale (measured on the reference itself), so a
+        clip-parallel caller that wants the reference's per-clip (B = 1) results batches the head only."""
+        B, T = state["B"], state["T"]
+        if B == 1:
+            return [state]
+        memory, spatial_shapes, level_start, ratios, mask, pad_flag, shapes = state["ctx"]
+        out = []
+        for b in range(B):
+            rows = slice(b * T, (b + 1) * T)
+            ctx = (memory[rows], spatial_shapes, level_start, ratios[rows], mask[rows], pad_flag, shapes)
+            out.append({"ctx": ctx, "feats0": state["feats0"][rows], "lang_last": state["lang_last"][:, b:b + 1],
+                        "word_pad": state["word_pad"][b:b + 1], "sentence": state["sentence"][b:b + 1], "B": 1, "T": T})
+        return out
+
     def num_parameters(self):
         return sum(p.numel() for p in self.parameters() if p.requires_grad)
 

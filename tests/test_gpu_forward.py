@@ -402,6 +402,77 @@ def test_pipelined_graph_full_config_matches_reference(gpu_model, golden, pipeli
         assert maxdiff(other, recs[order.index(seed)].cpu()) > 1e-2       # a different clip gave a different record
 
 
+def test_pair_pipeline_gives_every_clip_its_single_clip_result(gpu_model, golden):
+    """PairPipelinedClipGraph (what bench.py times): the head runs over TWO clips per launch, the tail per clip.  Every clip's
+    record equals the one-clip ClipGraph's to f32 rounding -- whichever slot it sits in, whoever its partner is, with an odd clip
+    going alone -- and the golden clip meets the reference's output.  (The reference's own B = 2 forward does NOT give a clip its
+    B = 1 result -- its tail couples the batch -- which is why only the head is shared.)"""
+    from neurips2023_soc_amd import clip_parallel as CP
+    from neurips2023_soc_amd.graph_runner import ClipGraph, PairPipelinedClipGraph
+    g = golden("full_forward.npz")
+    seed, T, H, Wd, L = (int(v) for v in g["cfg"])
+    hm, wm = -(-H // 4), -(-Wd // 4)
+    clips = [W.synthetic_clip(seed + i, T, H, Wd).cuda() for i in range(5)]
+    ids = [W.synthetic_token_ids(seed + (i % 2), L).cuda() for i in range(5)]          # two different expressions
+    plain = ClipGraph(gpu_model, T, H, Wd, L, "cuda")
+    want = []
+    for c, t_ in zip(clips, ids):
+        plain.run(c, t_)
+        want.append(plain.record.clone())
+    pipe = PairPipelinedClipGraph(gpu_model, T, H, Wd, L, "cuda")
+    assert pipe.CLIPS == 2 and pipe.flush() == []
+
+    def through(order):
+        """clips in `order` through the pair pipeline -> their records, in order"""
+        got, counts = [], []
+        for j in range(0, len(order), 2):
+            pair = order[j:j + 2]
+            for slot, i in enumerate(pair):
+                pipe.stage_inputs(clips[i], ids[i], slot=slot)
+            counts.append(len(pair))
+            r = pipe.replay()
+            if r is not None:
+                got += [x.clone() for x in r[:counts.pop(0)]]
+        for r in pipe.flush():
+            got += [x.clone() for x in r[:counts.pop(0)]]
+        return got
+
+    for order in ([0, 1, 2, 3, 4], [1, 0], [4], [3, 0, 2]):
+        got = through(order)
+        assert len(got) == len(order)
+        for i, rec in zip(order, got):
+            assert int(rec[0]) == int(want[i][0]), (order, i)
+            assert maxdiff(rec, want[i].cpu()) < 1e-4, (order, i)
+    q, cls, masks = CP.unpack_record(through([0, 1])[0].cpu(), T, 20, hm, wm)       # clip 0 = the golden's clip and expression
+    ref = t(g["selected_masks"]).reshape(T, hm, wm)
+    assert q == int(g["selected_query"]) and maxdiff(masks, ref) < 1e-3
+    flip = (masks > 0) != (ref > 0)
+    assert int(flip.sum()) <= 8 and (not bool(flip.any()) or float(ref[flip].abs().max()) < FLIP_WINDOW)
+
+
+def test_reference_tail_semantics_are_per_clip(gpu_model):
+    """SOC.split_state: a B = 2 head + per-clip tails gives each clip its single-clip outputs (5e-5), the full B = 2 forward
+    -- the reference's batch semantics, pinned by padded_b2_forward.npz -- does not."""
+    T, H, Wd, L = 3, 96, 128, 6
+    clips = [W.synthetic_clip(70 + i, T, H, Wd).cuda() for i in range(2)]
+    ids = torch.cat([W.synthetic_token_ids(70 + i, L) for i in range(2)], 0).cuda()
+    text = {"input_ids": ids, "attention_mask": torch.ones_like(ids)}
+    targets1 = [[{"size": (H, Wd)}] for _ in range(T)]
+    pad = torch.zeros(T, 2, H, Wd, dtype=torch.bool, device="cuda")
+    singles = [gpu_model(S.NestedTensor(clips[b][:, None].contiguous(), pad[:, :1], unpadded=True), None,
+                         {k: v[b:b + 1] for k, v in text.items()}, targets1) for b in range(2)]
+    sb = gpu_model.forward_head(S.NestedTensor(torch.stack(clips, 1), pad, unpadded=True), None, text)
+    states = gpu_model.split_state(sb)
+    assert len(states) == 2 and all(st["B"] == 1 for st in states)
+    for b, st in enumerate(states):
+        out = gpu_model.forward_tail(st, targets1)
+        scale = float(singles[b]["pred_masks"].abs().max())
+        assert maxdiff(out["pred_masks"], singles[b]["pred_masks"].cpu()) < 2e-5 * max(scale, 1.0) + 1e-4
+        assert maxdiff(out["pred_cls"], singles[b]["pred_cls"].cpu()) < 1e-4
+    both = gpu_model(S.NestedTensor(torch.stack(clips, 1), pad, unpadded=True), None, text, [[{"size": (H, Wd)}] * 2 for _ in range(T)])
+    assert maxdiff(both["pred_masks"][:, :1], singles[0]["pred_masks"].cpu()) > 1e-3        # the reference's tail couples the batch
+
+
 def test_pipelined_graph_soak_full_config():
     """>= 1 500 back-to-back replays of the shipped two-stage pipeline at the BASELINE size: no hang (the child is
     killed and the test fails after the timeout) and no drift: every time a clip comes round its record equals the

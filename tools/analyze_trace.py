@@ -6,7 +6,9 @@ import sys
 
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if "spin_kernel" not in r["Kernel_Name"]]  # drop torch.cuda._sleep
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "dyn_mask" in r["Kernel_Name"]]
+import os  # noqa: E402
+PER = int(os.environ.get("SOC_TRACE_CLIPS_PER_GROUP", "1"))      # pair pipeline: a replay (2 clips) ends with two dyn_mask launches
+idx = [i for i, r in enumerate(rows) if "dyn_mask" in r["Kernel_Name"]][PER - 1::PER]
 # a steady-state forward of the timed region: forward 10 (bench.py: 3 warm-up + 20 timed steps, then the streamed and
 # f32 passes and the back-to-back K1 / K20 replays, which are not forwards); short traces fall back to the last one
 k = 10 if len(idx) > 12 else len(idx) - 1

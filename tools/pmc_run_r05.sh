@@ -5,6 +5,7 @@
 set -x
 cd "$GRAFT_REPO_ROOT"
 export TMPDIR=/tmp
+export SOC_TRACE_CLIPS_PER_GROUP=2      # bench.py's default pipeline runs two clips per head launch: the trace tools count per group
 P=gpurun_out/r05
 mkdir -p $P
 PARTS=${1:-trace traffic k2 swinb rest}
@@ -20,16 +21,17 @@ trace)
   python3 tools/analyze_trace.py $T --top 30 > $P/r05_forward_breakdown.txt
   python3 tools/timeline.py $T > $P/r05_timeline.txt
   python3 tools/launch_sequence.py $T > $P/r05_launch_sequence.txt
-  # the one-graph pipeline of rounds 1-4 under the same tracer (same box): which kernels differ?
+  # the one-clip-per-launch pipeline of rounds 1-4 under the same tracer (same box)
   rocprofv3 --kernel-trace --stats --output-format csv -d $P/trace_onegraph -- python3 bench.py --pipeline one-graph --steps 20 --warmup 3 --no-cpu-baseline --no-stream --no-f32-pass --detail $P/trace_onegraph_detail.json > $P/trace_onegraph.json 2> $P/trace_onegraph.err
-  cp $(ls $P/trace_onegraph/*/*kernel_stats.csv | head -1) $P/r05_bench_kernel_stats_onegraph.csv
-  python3 tools/timeline.py $(ls $P/trace_onegraph/*/*kernel_trace.csv | head -1) > $P/r05_timeline_onegraph.txt
+  cp $(ls $P/trace_onegraph/*/*kernel_stats.csv | head -1) $P/r05_bench_kernel_stats_single_clip.csv
+  SOC_TRACE_CLIPS_PER_GROUP=1 python3 tools/timeline.py $(ls $P/trace_onegraph/*/*kernel_trace.csv | head -1) > $P/r05_timeline_single_clip.txt
+  SOC_TRACE_CLIPS_PER_GROUP=1 python3 tools/analyze_trace.py $(ls $P/trace_onegraph/*/*kernel_trace.csv | head -1) --top 30 > $P/r05_forward_breakdown_single_clip.txt
   ;;
 traffic)
   # ---- (b) HBM traffic per kernel and clip: FETCH_SIZE and WRITE_SIZE in separate passes
-  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $P/pmc_fetch -- python3 bench.py --eager --steps 2 --warmup 1 --no-cpu-baseline --no-stream --no-f32-pass --detail $P/pmc_fetch_detail.json > $P/pmc_fetch.log 2>&1
-  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $P/pmc_write -- python3 bench.py --eager --steps 2 --warmup 1 --no-cpu-baseline --no-stream --no-f32-pass --detail $P/pmc_write_detail.json > $P/pmc_write.log 2>&1
-  python3 tools/pmc_traffic.py $(ls $P/pmc_fetch/*/*counter_collection.csv | head -1) $(ls $P/pmc_write/*/*counter_collection.csv | head -1) > $P/r05_hbm_traffic_pmc.json
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $P/pmc_fetch -- python3 bench.py --eager --steps 4 --warmup 2 --no-cpu-baseline --no-stream --no-f32-pass --detail $P/pmc_fetch_detail.json > $P/pmc_fetch.log 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $P/pmc_write -- python3 bench.py --eager --steps 4 --warmup 2 --no-cpu-baseline --no-stream --no-f32-pass --detail $P/pmc_write_detail.json > $P/pmc_write.log 2>&1
+  python3 tools/pmc_traffic.py $(ls $P/pmc_fetch/*/*counter_collection.csv | head -1) $(ls $P/pmc_write/*/*counter_collection.csv | head -1) 2 > $P/r05_hbm_traffic_pmc.json
   ;;
 k2)
   # ---- (c) K2 (fused multi-scale deformable attention): where the gather is served from, at 360p and at 720p (config 4)
@@ -50,9 +52,9 @@ swinb)
     rocprofv3 --kernel-trace --stats --output-format csv -d $P/trace_swinb_$geo -- python3 bench.py --backbone video-swin-b $G --warmup 2 --no-cpu-baseline --no-stream --no-f32-pass --detail $P/trace_swinb_${geo}_detail.json > $P/trace_swinb_$geo.json 2> $P/trace_swinb_$geo.err
     cp $(ls $P/trace_swinb_$geo/*/*kernel_stats.csv | head -1) $P/r05_swinb_${geo}_kernel_stats.csv
     python3 tools/analyze_trace.py $(ls $P/trace_swinb_$geo/*/*kernel_trace.csv | head -1) --top 25 > $P/r05_swinb_${geo}_forward_breakdown.txt
-    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $P/pmc_fetch_swinb_$geo -- python3 bench.py --backbone video-swin-b $G --eager --steps 2 --warmup 1 --no-cpu-baseline --no-stream --no-f32-pass --detail $P/x.json > $P/pmc_fetch_swinb_$geo.log 2>&1
-    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $P/pmc_write_swinb_$geo -- python3 bench.py --backbone video-swin-b $G --eager --steps 2 --warmup 1 --no-cpu-baseline --no-stream --no-f32-pass --detail $P/x.json > $P/pmc_write_swinb_$geo.log 2>&1
-    python3 tools/pmc_traffic.py $(ls $P/pmc_fetch_swinb_$geo/*/*counter_collection.csv | head -1) $(ls $P/pmc_write_swinb_$geo/*/*counter_collection.csv | head -1) > $P/r05_swinb_${geo}_hbm_traffic_pmc.json
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $P/pmc_fetch_swinb_$geo -- python3 bench.py --backbone video-swin-b $G --eager --steps 4 --warmup 2 --no-cpu-baseline --no-stream --no-f32-pass --detail $P/x.json > $P/pmc_fetch_swinb_$geo.log 2>&1
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $P/pmc_write_swinb_$geo -- python3 bench.py --backbone video-swin-b $G --eager --steps 4 --warmup 2 --no-cpu-baseline --no-stream --no-f32-pass --detail $P/x.json > $P/pmc_write_swinb_$geo.log 2>&1
+    python3 tools/pmc_traffic.py $(ls $P/pmc_fetch_swinb_$geo/*/*counter_collection.csv | head -1) $(ls $P/pmc_write_swinb_$geo/*/*counter_collection.csv | head -1) 2 > $P/r05_swinb_${geo}_hbm_traffic_pmc.json
   done
   ;;
 rest)
@@ -61,6 +63,7 @@ rest)
   python3 tools/experiments/pipeline_ab.py 40 3 > $P/pipeline_ab.txt 2>&1
   python3 tools/gemm_sites.py 5 > $P/gemm_sites.txt 2>&1
   python3 bench.py --no-cpu-baseline --no-pipeline --no-stream --no-f32-pass --detail $P/x.json > $P/bench_r05_n1_one_clip_per_replay.json 2> /dev/null
+  python3 tools/experiments/batch2_probe.py > $P/batch2_probe.txt 2>&1
   ;;
 esac
 done

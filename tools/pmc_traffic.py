@@ -28,23 +28,28 @@ def load(path, counter):
     return rows, ends
 
 
+PER = int(sys.argv[3]) if len(sys.argv) > 3 else 1       # clips per launch group (bench.py --pipeline pairs: 2): a group ends with PER dyn_mask launches
+
+
 def per_forward(rows, ends):
-    """sum the counter per group over one steady-state forward: the second timed step (forward 0 is the warm-up; behind the
-    timed steps bench.py runs its instrumented pass and the back-to-back K1 / K20 replays, which are not forwards)"""
-    i = 2 if len(ends) > 2 else len(ends) - 1
-    seg = rows[ends[i - 1] + 1: ends[i] + 1]
+    """sum the counter per kernel group over one steady-state launch group (PER clips: one head, PER tails), per CLIP: the
+    second timed group (group 0 is the warm-up; behind the timed steps bench.py runs its instrumented pass and the
+    back-to-back family replays, which are not forwards)"""
+    i = 2 if len(ends) > 2 * PER else len(ends) // PER - 1
+    seg = rows[ends[i * PER - 1] + 1: ends[(i + 1) * PER - 1] + 1]
     out = collections.defaultdict(lambda: [0.0, 0])
     for r in seg:
         for g, keys in GROUPS.items():
             if any(k in r["Kernel_Name"] for k in keys):
-                out[g][0] += float(r["Counter_Value"]) * 1024.0
+                out[g][0] += float(r["Counter_Value"]) * 1024.0 / PER
                 out[g][1] += 1
     return out
 
 
 fetch = per_forward(*load(sys.argv[1], "FETCH_SIZE"))
 write = per_forward(*load(sys.argv[2], "WRITE_SIZE"))
-res = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (two separate runs) -- python3 bench.py --eager "
+res = {"clips_per_launch_group": PER,
+       "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (two separate runs) -- python3 bench.py --eager "
                   "--steps 2 --warmup 1 --no-cpu-baseline --no-stream --no-f32-pass; tools/pmc_traffic.py",
        "note": "counter unit = KiB; per MI355X_MICROARCH.md (HBM section) FETCH_SIZE on gfx950 reports 1/2 of the bytes of "
                "wide (16 B/lane) coalesced reads, so fetch bytes are doubled; WRITE_SIZE is exact for 16-B stores. "
@@ -54,6 +59,6 @@ for g in GROUPS:
     if g in fetch or g in write:
         f, n = fetch.get(g, [0.0, 0])
         w, _ = write.get(g, [0.0, 0])
-        res["per_clip_bytes"][g] = {"launches_per_clip": n, "fetch_raw": f, "fetch_corrected": 2 * f, "write": w,
+        res["per_clip_bytes"][g] = {"launches_per_group": n, "fetch_raw": f, "fetch_corrected": 2 * f, "write": w,
                                    "hbm_total": 2 * f + w}
 print(json.dumps(res, indent=1))

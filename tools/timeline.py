@@ -1,18 +1,22 @@
 """Steady-state timeline of bench.py's graph replays from a rocprofv3 --kernel-trace CSV: per clip (delimited by the
 single dyn_mask launch each forward ends with) the wall time, the time with 0 / 1 / >= 2 kernels in flight and the
 kernel-time sum, plus the longest idle gaps and what ran around them.
-usage: python tools/timeline.py <kernel_trace.csv> [clips_to_skip]"""
+usage: python tools/timeline.py <kernel_trace.csv> [groups_to_skip]
+SOC_TRACE_CLIPS_PER_GROUP=2 for the pair pipeline (a replay ends with two dyn_mask launches: every second one delimits)."""
 import csv
+import os
 import sys
+
+PER = int(os.environ.get("SOC_TRACE_CLIPS_PER_GROUP", "1"))
 
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if "spin_kernel" not in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 skip = int(sys.argv[2]) if len(sys.argv) > 2 else 6
-ends = [int(r["End_Timestamp"]) for r in rows if "dyn_mask" in r["Kernel_Name"]]
+ends = [int(r["End_Timestamp"]) for r in rows if "dyn_mask" in r["Kernel_Name"]][PER - 1::PER]
 if len(ends) < skip + 6:
     sys.exit("too few clips in the trace")
 t_lo, t_hi = ends[skip], ends[skip + 10] if len(ends) > skip + 10 else ends[-1]
-n_clips = (skip + 10 if len(ends) > skip + 10 else len(ends) - 1) - skip
+n_clips = ((skip + 10 if len(ends) > skip + 10 else len(ends) - 1) - skip) * PER
 ev = []
 for r in rows:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
