@@ -322,6 +322,7 @@ def main():
     # clips per replay of the timed pipeline (--eager launches the same groups without a graph)
     per = getattr(graph, "CLIPS", 1) if graph is not None else (
         1 if a.no_pipeline else __import__("neurips2023_soc_amd.graph_runner", fromlist=["x"]).pipeline_class(a.pipeline).CLIPS)
+    clips_per_group = per
 
     def run_steps(n, out, feed=None):
         """n clips through the chosen path, results into out[i % len(out)].  `feed` = (feeder, host clips): every clip
@@ -345,6 +346,7 @@ def main():
             return feeder.acquire()
 
         done = 0
+        per = getattr(graph, "CLIPS", 1) if graph is not None else clips_per_group      # clips per replay of THIS pass's pipeline
         in_flight = []                                                    # clips carried by each replay whose records are still due
         for i in range(n):
             clip = next_clip(i)
