@@ -9,9 +9,10 @@ clip_parallel.spawn_ranks = the reference's mp.Process fan-out, infer_refytb.py:
 
 A step = one eval forward of Video-Swin-T SOC on one synthetic clip [T=8,3,360,640] (random
 deterministic weights, pre-tokenised 10-token expression) + query selection, i.e. the body of
-the reference's inference loop (infer_refytb.py:206-227).  Since round 5 two independent clips share each launch of the
-forward's batch-independent head (Video-Swin, fusion, deformable encoder); the tail runs per clip, as the reference's B = 1
-forward does (graph_runner.PairPipelinedClipGraph); `single_clip_ms_per_step` is the one-clip-per-launch pipeline beside it.  Inputs are resident in HBM before the
+the reference's inference loop (infer_refytb.py:206-227).  Since round 5 four independent clips share each launch of the
+forward (graph_runner.QuadPipelinedClipGraph); the VOC module -- the one place where the reference's forward couples the clips
+of a batch -- runs per clip, so every clip gets its single-clip (B = 1) result; `single_clip_ms_per_step` is the
+one-clip-per-launch pipeline of rounds 1-4 beside it.  Inputs are resident in HBM before the
 timed region.  Clips shard over ranks (weak scaling: K clips per rank, no data-path collective);
 the single result all_gather sits inside the timed region.  Rank 0 prints ONE JSON line.
 """
@@ -57,10 +58,10 @@ def parse():
     ap.add_argument("--eager", action="store_true", help="time eager launches instead of hipGraph replay")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="one clip per graph replay (ClipGraph) instead of the software-pipelined PipelinedClipGraph")
-    ap.add_argument("--pipeline", choices=["two-stream", "one-graph", "pairs", "quads"], default="pairs",
-                    help="software pipeline across clips: pairs (default: two independent clips per head launch, one tail per "
-                         "clip, graph_runner.PairPipelinedClipGraph), one-graph (one clip per head launch: rounds 1-4, "
-                         "PipelinedClipGraph; also timed as single_clip_ms_per_step), two-stream (TwoStreamClipGraph), quads")
+    ap.add_argument("--pipeline", choices=["two-stream", "one-graph", "pairs", "quads"], default="quads",
+                    help="software pipeline across clips: quads (default: four independent clips per launch group, VOC per "
+                         "clip: graph_runner.QuadPipelinedClipGraph), pairs (two), one-graph (one clip per launch: rounds 1-4, "
+                         "PipelinedClipGraph; also timed as single_clip_ms_per_step), two-stream (TwoStreamClipGraph)")
     ap.add_argument("--no-stream", action="store_true",
                     help="skip the second, H2D-inclusive timed pass (stream_ms_per_step)")
     ap.add_argument("--stub", action="store_true",
@@ -295,19 +296,19 @@ def main():
         return out
 
     def step_group(i0, count, records=None):
-        """Eager launches of what ONE replay of the timed pipeline runs: the head over `per` clips (pool clips i0, i0 + 1, ...),
-        then one single-clip tail per clip (graph_runner.PairPipelinedClipGraph); per == 1: step()."""
+        """Eager launches of what ONE replay of the timed pipeline runs: head and tail over `per` clips (pool clips i0, i0 + 1,
+        ...), VOC per clip (graph_runner.group_tail); per == 1: step()."""
         if per == 1:
             return step(i0, None if records is None else records[i0])
         group = torch.stack([clips[(i0 + b) % n_pool] for b in range(per)], 1)
         text_g = {k: v.expand(per, -1).contiguous() for k, v in text.items()}
         sb = model.forward_head(S.NestedTensor(group, pad.expand(-1, per, -1, -1), unpadded=True), None, text_g)
-        for b, st in enumerate(model.split_state(sb)):
-            out = model.forward_tail(st, targets)
-            if records is not None and b < count:
-                idx, masks = P.select_trajectory(out)
-                CP.pack_record(records[i0 + b], idx, out["pred_cls"][:, 0, :, 0], masks)
+        from neurips2023_soc_amd.graph_runner import group_tail
+        group_tail(model, sb, targets, True, group_records)
+        if records is not None:
+            records[i0:i0 + count].copy_(group_records[:count])
 
+    group_records = torch.zeros(8, results.shape[1], device=dev)      # scratch of the eager group step
     graph = None
     pipelined = False
     if not a.eager:
@@ -463,7 +464,7 @@ def main():
         finally:
             model.matmul_mode = None
 
-    # Fourth timed pass (pair pipeline only): the one-clip-per-head pipeline of rounds 1-4 on the same box, so that the line
+    # Fourth timed pass (group pipelines only): the one-clip-per-launch pipeline of rounds 1-4 on the same box, so that the line
     # carries both numbers.
     single_pass = None
     if graph is not None and pipelined and per > 1 and not a.no_single_pass and world == 1:
@@ -554,8 +555,9 @@ def main():
                        "eager" if graph is None else (
                            ("hipGraph replays, software-pipelined on two streams: Video-Swin + fusion + encoder of clip i | text "
                             "encoder of clip i, tail of clip i-1" if Pipeline.__name__ == "TwoStreamClipGraph" else
-                            f"hipGraph replay, software-pipelined, {Pipeline.CLIPS} clips per head launch (Video-Swin, fusion, encoder: "
-                            "batch-independent) beside ONE tail per clip of the previous group (the reference's B = 1 tail)" if Pipeline.CLIPS > 1 else
+                            f"hipGraph replay, software-pipelined, {Pipeline.CLIPS} independent clips per launch group: head (Video-Swin, fusion, "
+                            "encoder) of group i beside the tail of group i-1, VOC -- the one module of the reference that couples "
+                            "a batch -- run per clip" if Pipeline.CLIPS > 1 else
                             "hipGraph replay, software-pipelined: tail of clip i beside the head of clip i+1")
                            if pipelined else "hipGraph replay (one graph per clip geometry)")),
             "matmul": ("f32 in / out / accumulate; large products as 6 bf16 MFMA products of a 3-way operand split (f32-grade: "

@@ -463,18 +463,33 @@ class TwoStreamClipGraph(PipelinedClipGraph):
         return [self.record.clone()]
 
 
+def group_tail(model, state, targets_one, fork: bool, records) -> None:
+    """The tail of a group of INDEPENDENT clips whose head ran as one batch: one batched pass over FPN, query decoder, heads and
+    mask head with the VOC module per clip (SOC.forward_tail(voc_per_clip=True): VOC is the only place where the reference
+    couples the clips of a batch), then selection + record packing per clip into records[b]."""
+    B = state["B"]
+    targets = [[frame[0]] * B for frame in targets_one]
+    out = model.forward_tail(state, targets, fork=fork, voc_per_clip=True)
+    for b in range(B):
+        idx, masks = P.select_trajectory({"pred_cls": out["pred_cls"][:, b:b + 1], "pred_masks": out["pred_masks"][:, b:b + 1]})
+        CP.pack_record(records[b], idx, out["pred_cls"][:, b, :, 0], masks)
+
+
 class PairPipelinedClipGraph(PipelinedClipGraph):
-    """The one-graph software pipeline with TWO clips per head (round 5).
+    """The one-graph software pipeline with a GROUP of independent clips per launch (round 5; CLIPS = 2 here, 4 in
+    QuadPipelinedClipGraph).
 
     The head of SOC's forward -- Video-Swin, vision-language fusion, deformable encoder -- treats the clips of a batch
     independently (per token, per window, per frame), and at B = 1 its later stages have too few rows for 256 CUs (stage 2: 460
     row tiles, stage 3: 120; K23 / K24 / K1 run at 0.2-0.35 of their ceilings there, every launch pays its fixed ~10 us).  Over
     two clips the same launches do twice the work: head 5.59 -> 5.10 ms per clip (tools/experiments/batch2_probe.py).  The TAIL
-    stays per clip: the reference's own B = 2 forward gives a clip other results than its B = 1 forward (its tail couples the
-    batch: 0.32 of a logit scale of 6.6 on the reference itself), and the inference drivers' results are the B = 1 ones
-    (infer_refytb.py:206-227), so graph k runs  head(clips 2i, 2i+1)  beside  tail(clip 2i-2), tail(clip 2i-1)  -- each tail
-    on a single-clip view of the head's state (SOC.split_state).  Per clip the results equal the single-clip pipeline's to
-    f32 rounding (5e-5 on logits of 37, the run-to-run noise of the library kernels).
+    needs one exception: the reference's own B = 2 forward gives a clip other results than its B = 1 forward (0.32 on a logit
+    scale of 6.6, run on the reference itself), and the inference drivers' results are the B = 1 ones (infer_refytb.py:206-227).
+    The ONE place where the reference couples the clips of a batch is its VOC module (tools/experiments/batch2_voc_probe.py:
+    with VOC run per clip a batched forward gives every clip its single-clip outputs to 5e-5), so the tail of a group is one
+    batched pass -- FPN, query decoder, heads, mask head -- with VOC once per clip (group_tail, SOC.forward_tail(voc_per_clip=
+    True)).  Graph k runs  head(group i)  beside  tail(group i-1).  Per clip the results equal the single-clip pipeline's to f32
+    rounding (5e-5 on logits of 37, the run-to-run noise of the library kernels), whichever slot a clip sits in.
 
         g.stage_inputs(clip_a, ids_a, slot=0); g.stage_inputs(clip_b, ids_b, slot=1)
         recs = g.replay()             # [2, R] records of the pair submitted one call earlier, or None
@@ -536,10 +551,7 @@ class PairPipelinedClipGraph(PipelinedClipGraph):
         if os.environ.get("SOC_TAIL_NO_FORK", "0") == "1":
             fork = False
         try:
-            for b, st in enumerate(self.model.split_state(sb)):          # one single-clip tail per clip of the pair
-                out = self.model.forward_tail(st, self.targets, fork=fork)
-                idx, masks = P.select_trajectory(out)
-                CP.pack_record(self.record[b], idx, out["pred_cls"][:, 0, :, 0], masks)
+            group_tail(self.model, sb, self.targets, fork, self.record)
         finally:
             hot_ops.row_chain_fusion = prev
 
@@ -566,7 +578,9 @@ class PairPipelinedClipGraph(PipelinedClipGraph):
 
 
 class QuadPipelinedClipGraph(PairPipelinedClipGraph):
-    """Four clips per head launch (measured beside the pair form; see DESIGN.md section 3, "Launch structure")."""
+    """Four clips per launch group: what bench.py times.  Same box, bench.py, 20 / 200 steps: 5.74-5.80 / 5.59 ms per clip against
+    5.89-5.93 / 5.76 for pairs and 6.25-6.39 / 6.24 for one clip per launch; three clips per group lose a slot whenever the clip
+    count is not a multiple of three (6.21 at 20 steps)."""
     CLIPS = 4
 
 

@@ -402,13 +402,14 @@ def test_pipelined_graph_full_config_matches_reference(gpu_model, golden, pipeli
         assert maxdiff(other, recs[order.index(seed)].cpu()) > 1e-2       # a different clip gave a different record
 
 
-def test_pair_pipeline_gives_every_clip_its_single_clip_result(gpu_model, golden):
-    """PairPipelinedClipGraph (what bench.py times): the head runs over TWO clips per launch, the tail per clip.  Every clip's
-    record equals the one-clip ClipGraph's to f32 rounding -- whichever slot it sits in, whoever its partner is, with an odd clip
-    going alone -- and the golden clip meets the reference's output.  (The reference's own B = 2 forward does NOT give a clip its
-    B = 1 result -- its tail couples the batch -- which is why only the head is shared.)"""
+@pytest.mark.parametrize("group", [4, 2])
+def test_group_pipeline_gives_every_clip_its_single_clip_result(gpu_model, golden, group):
+    """QuadPipelinedClipGraph (what bench.py times) / PairPipelinedClipGraph: four / two independent clips per launch group, the
+    VOC module per clip.  Every clip's record equals the one-clip ClipGraph's to f32 rounding -- whichever slot it sits in, whoever
+    its partners are, with a part-filled last group -- and the golden clip meets the reference's output.  (The reference's own
+    B = 2 forward does NOT give a clip its B = 1 result: its VOC couples the batch.)"""
     from neurips2023_soc_amd import clip_parallel as CP
-    from neurips2023_soc_amd.graph_runner import ClipGraph, PairPipelinedClipGraph
+    from neurips2023_soc_amd.graph_runner import ClipGraph, PairPipelinedClipGraph, QuadPipelinedClipGraph
     g = golden("full_forward.npz")
     seed, T, H, Wd, L = (int(v) for v in g["cfg"])
     hm, wm = -(-H // 4), -(-Wd // 4)
@@ -419,14 +420,14 @@ def test_pair_pipeline_gives_every_clip_its_single_clip_result(gpu_model, golden
     for c, t_ in zip(clips, ids):
         plain.run(c, t_)
         want.append(plain.record.clone())
-    pipe = PairPipelinedClipGraph(gpu_model, T, H, Wd, L, "cuda")
-    assert pipe.CLIPS == 2 and pipe.flush() == []
+    pipe = {2: PairPipelinedClipGraph, 4: QuadPipelinedClipGraph}[group](gpu_model, T, H, Wd, L, "cuda")
+    assert pipe.CLIPS == group and pipe.flush() == []
 
     def through(order):
-        """clips in `order` through the pair pipeline -> their records, in order"""
+        """clips in `order` through the group pipeline -> their records, in order"""
         got, counts = [], []
-        for j in range(0, len(order), 2):
-            pair = order[j:j + 2]
+        for j in range(0, len(order), group):
+            pair = order[j:j + group]
             for slot, i in enumerate(pair):
                 pipe.stage_inputs(clips[i], ids[i], slot=slot)
             counts.append(len(pair))
@@ -437,7 +438,7 @@ def test_pair_pipeline_gives_every_clip_its_single_clip_result(gpu_model, golden
             got += [x.clone() for x in r[:counts.pop(0)]]
         return got
 
-    for order in ([0, 1, 2, 3, 4], [1, 0], [4], [3, 0, 2]):
+    for order in ([0, 1, 2, 3, 4], [1, 0], [4], [3, 0, 2], [4, 3, 2, 1, 0, 1, 2, 3, 4]):
         got = through(order)
         assert len(got) == len(order)
         for i, rec in zip(order, got):
@@ -450,9 +451,10 @@ def test_pair_pipeline_gives_every_clip_its_single_clip_result(gpu_model, golden
     assert int(flip.sum()) <= 8 and (not bool(flip.any()) or float(ref[flip].abs().max()) < FLIP_WINDOW)
 
 
-def test_reference_tail_semantics_are_per_clip(gpu_model):
-    """SOC.split_state: a B = 2 head + per-clip tails gives each clip its single-clip outputs (5e-5), the full B = 2 forward
-    -- the reference's batch semantics, pinned by padded_b2_forward.npz -- does not."""
+def test_reference_couples_a_batch_in_voc_only(gpu_model):
+    """A B = 2 head + per-clip tails (SOC.split_state) and a fully batched forward with ONLY the VOC module per clip
+    (forward_tail(voc_per_clip=True)) both give each clip its single-clip outputs; the plain B = 2 forward -- the reference's
+    batch semantics, pinned by padded_b2_forward.npz -- does not."""
     T, H, Wd, L = 3, 96, 128, 6
     clips = [W.synthetic_clip(70 + i, T, H, Wd).cuda() for i in range(2)]
     ids = torch.cat([W.synthetic_token_ids(70 + i, L) for i in range(2)], 0).cuda()
@@ -469,8 +471,14 @@ def test_reference_tail_semantics_are_per_clip(gpu_model):
         scale = float(singles[b]["pred_masks"].abs().max())
         assert maxdiff(out["pred_masks"], singles[b]["pred_masks"].cpu()) < 2e-5 * max(scale, 1.0) + 1e-4
         assert maxdiff(out["pred_cls"], singles[b]["pred_cls"].cpu()) < 1e-4
-    both = gpu_model(S.NestedTensor(torch.stack(clips, 1), pad, unpadded=True), None, text, [[{"size": (H, Wd)}] * 2 for _ in range(T)])
-    assert maxdiff(both["pred_masks"][:, :1], singles[0]["pred_masks"].cpu()) > 1e-3        # the reference's tail couples the batch
+    targets2 = [[{"size": (H, Wd)}] * 2 for _ in range(T)]
+    batched = gpu_model.forward_tail(sb, targets2, voc_per_clip=True)
+    for b in range(2):
+        scale = float(singles[b]["pred_masks"].abs().max())
+        assert maxdiff(batched["pred_masks"][:, b:b + 1], singles[b]["pred_masks"].cpu()) < 2e-5 * max(scale, 1.0) + 1e-4
+        assert maxdiff(batched["pred_cls"][:, b:b + 1], singles[b]["pred_cls"].cpu()) < 1e-4
+    both = gpu_model(S.NestedTensor(torch.stack(clips, 1), pad, unpadded=True), None, text, targets2)
+    assert maxdiff(both["pred_masks"][:, :1], singles[0]["pred_masks"].cpu()) > 1e-3        # the reference's VOC couples the batch
 
 
 def test_pipelined_graph_soak_full_config():

@@ -11,12 +11,13 @@ PER = int(os.environ.get("SOC_TRACE_CLIPS_PER_GROUP", "1"))
 
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if "spin_kernel" not in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-skip = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+skip = int(sys.argv[2]) if len(sys.argv) > 2 else (6 if PER == 1 else 3)
+SPAN = 10 if PER == 1 else 7          # launch groups in the window: inside the 20 timed clips of bench.py either way
 ends = [int(r["End_Timestamp"]) for r in rows if "dyn_mask" in r["Kernel_Name"]][PER - 1::PER]
 if len(ends) < skip + 6:
     sys.exit("too few clips in the trace")
-t_lo, t_hi = ends[skip], ends[skip + 10] if len(ends) > skip + 10 else ends[-1]
-n_clips = ((skip + 10 if len(ends) > skip + 10 else len(ends) - 1) - skip) * PER
+t_lo, t_hi = ends[skip], ends[skip + SPAN] if len(ends) > skip + SPAN else ends[-1]
+n_clips = ((skip + SPAN if len(ends) > skip + SPAN else len(ends) - 1) - skip) * PER
 ev = []
 for r in rows:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
