@@ -58,10 +58,11 @@ def parse():
     ap.add_argument("--eager", action="store_true", help="time eager launches instead of hipGraph replay")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="one clip per graph replay (ClipGraph) instead of the software-pipelined PipelinedClipGraph")
-    ap.add_argument("--pipeline", choices=["two-stream", "one-graph", "pairs", "quads"], default="quads",
-                    help="software pipeline across clips: quads (default: four independent clips per launch group, VOC per "
-                         "clip: graph_runner.QuadPipelinedClipGraph), pairs (two), one-graph (one clip per launch: rounds 1-4, "
-                         "PipelinedClipGraph; also timed as single_clip_ms_per_step), two-stream (TwoStreamClipGraph)")
+    ap.add_argument("--pipeline", choices=["two-stream", "one-graph", "pairs", "quads"], default=None,
+                    help="software pipeline across clips: quads (default up to 360x640: four independent clips per launch group, "
+                         "VOC per clip: graph_runner.QuadPipelinedClipGraph), pairs (two), one-graph (default above 360x640, where a "
+                         "clip fills the chip by itself -- Swin-B 720p: 44.1 ms per clip against 49.2 in groups of four; one clip "
+                         "per launch: rounds 1-4, PipelinedClipGraph; also timed as single_clip_ms_per_step), two-stream")
     ap.add_argument("--no-stream", action="store_true",
                     help="skip the second, H2D-inclusive timed pass (stream_ms_per_step)")
     ap.add_argument("--stub", action="store_true",
@@ -252,6 +253,8 @@ def stub_main(a, CP):
 
 def main():
     a = parse()
+    if a.pipeline is None:
+        a.pipeline = "quads" if a.frames * a.height * a.width <= 8 * 360 * 640 else "one-graph"
     from neurips2023_soc_amd import clip_parallel as CP
     CP.rank_environment()           # before anything touches the GPU: the same process environment in both launch modes
     if a.gpus > 1 and not CP.launched_as_rank():

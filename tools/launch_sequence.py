@@ -11,7 +11,7 @@ PER = int(os.environ.get("SOC_TRACE_CLIPS_PER_GROUP", "1"))      # pair pipeline
 idx = [i for i, r in enumerate(rows) if "dyn_mask" in r["Kernel_Name"]][PER - 1::PER]
 # a steady-state forward of the timed region: forward 10 (bench.py: 3 warm-up + 20 timed steps, then the streamed and
 # f32 passes and the back-to-back K1 / K20 replays, which are not forwards); short traces fall back to the last one
-k = 10 if len(idx) > 12 else len(idx) - 1
+k = (10 if PER == 1 else max(2, 12 // PER)) if len(idx) > (12 if PER == 1 else 12 // PER + 2) else len(idx) - 1
 seg = rows[idx[k - 1] + 1: idx[k] + 1]
 t0 = int(seg[0]["Start_Timestamp"])
 prev_end = t0

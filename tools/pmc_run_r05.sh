@@ -5,7 +5,8 @@
 set -x
 cd "$GRAFT_REPO_ROOT"
 export TMPDIR=/tmp
-export SOC_TRACE_CLIPS_PER_GROUP=2      # bench.py's default pipeline runs two clips per head launch: the trace tools count per group
+GROUP=4                                 # bench.py's default pipeline runs four clips per launch group: the trace / PMC tools count per group
+export SOC_TRACE_CLIPS_PER_GROUP=$GROUP
 P=gpurun_out/r05
 mkdir -p $P
 PARTS=${1:-trace traffic k2 swinb rest}
@@ -29,9 +30,9 @@ trace)
   ;;
 traffic)
   # ---- (b) HBM traffic per kernel and clip: FETCH_SIZE and WRITE_SIZE in separate passes
-  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $P/pmc_fetch -- python3 bench.py --eager --steps 4 --warmup 2 --no-cpu-baseline --no-stream --no-f32-pass --detail $P/pmc_fetch_detail.json > $P/pmc_fetch.log 2>&1
-  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $P/pmc_write -- python3 bench.py --eager --steps 4 --warmup 2 --no-cpu-baseline --no-stream --no-f32-pass --detail $P/pmc_write_detail.json > $P/pmc_write.log 2>&1
-  python3 tools/pmc_traffic.py $(ls $P/pmc_fetch/*/*counter_collection.csv | head -1) $(ls $P/pmc_write/*/*counter_collection.csv | head -1) 2 > $P/r05_hbm_traffic_pmc.json
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $P/pmc_fetch -- python3 bench.py --eager --steps 8 --warmup 4 --no-cpu-baseline --no-stream --no-f32-pass --detail $P/pmc_fetch_detail.json > $P/pmc_fetch.log 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $P/pmc_write -- python3 bench.py --eager --steps 8 --warmup 4 --no-cpu-baseline --no-stream --no-f32-pass --detail $P/pmc_write_detail.json > $P/pmc_write.log 2>&1
+  python3 tools/pmc_traffic.py $(ls $P/pmc_fetch/*/*counter_collection.csv | head -1) $(ls $P/pmc_write/*/*counter_collection.csv | head -1) $GROUP > $P/r05_hbm_traffic_pmc.json
   ;;
 k2)
   # ---- (c) K2 (fused multi-scale deformable attention): where the gather is served from, at 360p and at 720p (config 4)
@@ -52,9 +53,9 @@ swinb)
     rocprofv3 --kernel-trace --stats --output-format csv -d $P/trace_swinb_$geo -- python3 bench.py --backbone video-swin-b $G --warmup 2 --no-cpu-baseline --no-stream --no-f32-pass --detail $P/trace_swinb_${geo}_detail.json > $P/trace_swinb_$geo.json 2> $P/trace_swinb_$geo.err
     cp $(ls $P/trace_swinb_$geo/*/*kernel_stats.csv | head -1) $P/r05_swinb_${geo}_kernel_stats.csv
     python3 tools/analyze_trace.py $(ls $P/trace_swinb_$geo/*/*kernel_trace.csv | head -1) --top 25 > $P/r05_swinb_${geo}_forward_breakdown.txt
-    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $P/pmc_fetch_swinb_$geo -- python3 bench.py --backbone video-swin-b $G --eager --steps 4 --warmup 2 --no-cpu-baseline --no-stream --no-f32-pass --detail $P/x.json > $P/pmc_fetch_swinb_$geo.log 2>&1
-    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $P/pmc_write_swinb_$geo -- python3 bench.py --backbone video-swin-b $G --eager --steps 4 --warmup 2 --no-cpu-baseline --no-stream --no-f32-pass --detail $P/x.json > $P/pmc_write_swinb_$geo.log 2>&1
-    python3 tools/pmc_traffic.py $(ls $P/pmc_fetch_swinb_$geo/*/*counter_collection.csv | head -1) $(ls $P/pmc_write_swinb_$geo/*/*counter_collection.csv | head -1) 2 > $P/r05_swinb_${geo}_hbm_traffic_pmc.json
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $P/pmc_fetch_swinb_$geo -- python3 bench.py --backbone video-swin-b $G --eager --steps 8 --warmup 4 --no-cpu-baseline --no-stream --no-f32-pass --detail $P/x.json > $P/pmc_fetch_swinb_$geo.log 2>&1
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $P/pmc_write_swinb_$geo -- python3 bench.py --backbone video-swin-b $G --eager --steps 8 --warmup 4 --no-cpu-baseline --no-stream --no-f32-pass --detail $P/x.json > $P/pmc_write_swinb_$geo.log 2>&1
+    python3 tools/pmc_traffic.py $(ls $P/pmc_fetch_swinb_$geo/*/*counter_collection.csv | head -1) $(ls $P/pmc_write_swinb_$geo/*/*counter_collection.csv | head -1) $GROUP > $P/r05_swinb_${geo}_hbm_traffic_pmc.json
   done
   ;;
 rest)

@@ -11,10 +11,10 @@ PER = int(os.environ.get("SOC_TRACE_CLIPS_PER_GROUP", "1"))
 
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if "spin_kernel" not in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-skip = int(sys.argv[2]) if len(sys.argv) > 2 else (6 if PER == 1 else 3)
-SPAN = 10 if PER == 1 else 7          # launch groups in the window: inside the 20 timed clips of bench.py either way
+skip = int(sys.argv[2]) if len(sys.argv) > 2 else max(1, 6 // PER)
+SPAN = 10 if PER == 1 else max(2, 14 // PER)       # launch groups in the window: inside the 20 timed clips of bench.py either way
 ends = [int(r["End_Timestamp"]) for r in rows if "dyn_mask" in r["Kernel_Name"]][PER - 1::PER]
-if len(ends) < skip + 6:
+if len(ends) < skip + min(SPAN, 6):
     sys.exit("too few clips in the trace")
 t_lo, t_hi = ends[skip], ends[skip + SPAN] if len(ends) > skip + SPAN else ends[-1]
 n_clips = ((skip + SPAN if len(ends) > skip + SPAN else len(ends) - 1) - skip) * PER
