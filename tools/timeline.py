@@ -11,13 +11,17 @@ PER = int(os.environ.get("SOC_TRACE_CLIPS_PER_GROUP", "1"))
 
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if "spin_kernel" not in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-skip = int(sys.argv[2]) if len(sys.argv) > 2 else max(1, 6 // PER)
-SPAN = 10 if PER == 1 else max(2, 14 // PER)       # launch groups in the window: inside the 20 timed clips of bench.py either way
-ends = [int(r["End_Timestamp"]) for r in rows if "dyn_mask" in r["Kernel_Name"]][PER - 1::PER]
-if len(ends) < skip + min(SPAN, 6):
+SPAN = 10 if PER == 1 else max(2, 14 // PER)       # launch groups in the window
+if len(ends) < SPAN + 2:
     sys.exit("too few clips in the trace")
-t_lo, t_hi = ends[skip], ends[skip + SPAN] if len(ends) > skip + SPAN else ends[-1]
-n_clips = ((skip + SPAN if len(ends) > skip + SPAN else len(ends) - 1) - skip) * PER
+if len(sys.argv) > 2:
+    skip = int(sys.argv[2])
+else:
+    # the SPAN consecutive launch groups that took the least wall time: a steady-state stretch of one timed pass (the passes
+    # of bench.py are separated by host work, and a group pipeline has few groups per pass)
+    skip = min(range(1, len(ends) - SPAN), key=lambda s_: ends[s_ + SPAN] - ends[s_])
+t_lo, t_hi = ends[skip], ends[skip + SPAN]
+n_clips = SPAN * PER
 ev = []
 for r in rows:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
