@@ -46,8 +46,11 @@ def _lin(n: int, k: int, bias: bool = True):
     return SimpleNamespace(weight=Stand(n, k), bias=Stand(n) if bias else None)
 
 
-def table(backbone: str, T: int, H: int, W: int) -> Dict[str, str]:
+def table(backbone: str, T: int, H: int, W: int, clips: int = 1) -> Dict[str, str]:
+    """`clips` independent clips per launch group (graph_runner.QuadPipelinedClipGraph: 4): a batch of `clips`, so every
+    pixel-sized layer sees `clips` times the rows."""
     cfg = SWIN_CONFIGS[backbone]
+    T = T * clips                  # the routing predicates read row counts: frames of all clips of the group
     d = cfg["embed_dim"]
     h, w = -(-H // 4), -(-W // 4)
     out: Dict[str, str] = {}
@@ -115,8 +118,14 @@ def table(backbone: str, T: int, H: int, W: int) -> Dict[str, str]:
     return out
 
 
+# what bench.py runs by default: groups of four clips up to 360 x 640, one clip per launch above
+GROUPED = (("video-swin-t", 8, 360, 640, 4), ("video-swin-b", 8, 360, 640, 4))
+
+
 def all_tables() -> Dict[str, Dict[str, str]]:
-    return {f"{b} T={t} {hh}x{ww}": table(b, t, hh, ww) for b, t, hh, ww in BASELINE_GEOMETRIES}
+    tabs = {f"{b} T={t} {hh}x{ww}": table(b, t, hh, ww) for b, t, hh, ww in BASELINE_GEOMETRIES}
+    tabs.update({f"{b} T={t} {hh}x{ww} x{c} clips": table(b, t, hh, ww, c) for b, t, hh, ww, c in GROUPED})
+    return tabs
 
 
 if __name__ == "__main__":

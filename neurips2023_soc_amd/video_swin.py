@@ -199,7 +199,12 @@ class BasicLayer(nn.Module):
         # stage 1 (C = 192) in the split arithmetic: K13b beats K20 on qkv / proj / fc1 (49 / 24 / 71 against 60 / 30 / 74 us,
         # tools/experiments/k13b_time.py); with SOC_SPLIT_OFF=k13 the K20 flow takes it
         prefer_ws = hot_ops.k13_split_enabled() and x.shape[-1] in hot_ops.WS_SPLIT_LN_K and self._weight_stationary(x)
-        if not prefer_ws and self._split_flow(x):
+        # C = 384 / 512 keep the "k23" flow however many rows a launch group brings (four clips: 29 440): K24 qkv 161 us against
+        # K20 + LayerNorm 229, K23 with norm1 of the next block 392 against 415 + a LayerNorm in the next qkv
+        # (tools/experiments/stage2_group_flow.py); the "k20" flow is for the tall stages K24 / K23 do not cover that way
+        prefer_k23 = (x.shape[-1] in (384, 512) and fused.mlp_ok(x, blk.mlp.fc1, blk.mlp.fc2)
+                      and all(fused.xs_ok(x, w) for w in (blk.attn.qkv.weight, blk.attn.proj.weight)))
+        if not prefer_ws and not prefer_k23 and self._split_flow(x):
             return "k20"
         if self._weight_stationary(x):
             return "ws"
