@@ -11,6 +11,7 @@ PER = int(os.environ.get("SOC_TRACE_CLIPS_PER_GROUP", "1"))
 
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if "spin_kernel" not in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+ends = [int(r["End_Timestamp"]) for r in rows if "dyn_mask" in r["Kernel_Name"]][PER - 1::PER]
 SPAN = 10 if PER == 1 else max(2, 14 // PER)       # launch groups in the window
 if len(ends) < SPAN + 2:
     sys.exit("too few clips in the trace")
