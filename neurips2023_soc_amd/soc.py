@@ -377,12 +377,13 @@ class SOC(nn.Module):
         """Second part of forward: FPN spatial decoder ‖ query decoder -> VOC -> heads, dynamic mask head.
         ``fork=False`` keeps everything on the calling stream (used when the caller already runs the tail beside
         another clip's head).
-        ``voc_per_clip=True``: the VOC module runs once per clip of the batch instead of once over the batch.  VOC is the ONE
-        place where the reference's forward couples the clips of a batch (measured: with VOC per clip a B = 2 forward gives
-        each clip its B = 1 outputs to 5e-5, without it they differ by 4.9 on a logit scale of 37;
-        tools/experiments/batch2_voc_probe.py), so a caller that batches INDEPENDENT clips and wants the reference's per-clip
-        (B = 1) results -- graph_runner.PairPipelinedClipGraph -- sets it; the default reproduces the reference's batch
-        semantics (golden padded_b2_forward.npz)."""
+        ``voc_per_clip=True``: the VOC module clusters every clip over its own frames (VOC.forward(independent_clips=True): one
+        batched pass that computes what B calls with B = 1 compute).  VOC is the ONE place where the reference's forward couples
+        the clips of a batch -- it reshapes [T,B,Q,C] to [B,T,Q,C] instead of permuting (models/voc.py:279), which deals the
+        frames of a batch over its clips; measured: with VOC per clip a B = 2 forward gives each clip its B = 1 outputs to 5e-5,
+        without it they differ by 4.9 on a logit scale of 37 (tools/experiments/batch2_voc_probe.py) -- so a caller that batches
+        INDEPENDENT clips and wants the reference's per-clip (B = 1) results (the group pipelines of graph_runner) sets it; the
+        default reproduces the reference's batch semantics (golden padded_b2_forward.npz)."""
         ctx, feats0, lang_last = state["ctx"], state["feats0"], state["lang_last"]
         word_pad, sentence, B, T = state["word_pad"], state["sentence"], state["B"], state["T"]
         device = feats0.device
@@ -416,10 +417,10 @@ class SOC(nn.Module):
 
         C = hs.shape[-1]
         hs_t = hs.view(hs.shape[0], B, T, Q, C).transpose(1, 2)              # l t b q c
-        if voc_per_clip and B > 1:
-            voc_hs = torch.cat([self.voc(hs_t[:, :, b:b + 1].contiguous(), sentence[b:b + 1]) for b in range(B)], 1)
-        else:
-            voc_hs = self.voc(hs_t, sentence)                                # [1,B,Q,C]
+        # voc_per_clip: every clip clustered over its own frames -- one batched pass, bit-compatible with B separate B = 1 calls
+        # (the reference reshapes [T,B,Q,C] to [B,T,Q,C] instead of permuting, which deals the frames of a batch over its
+        # clips: models/voc.py:279; identity at B = 1)
+        voc_hs = self.voc(hs_t, sentence, independent_clips=bool(voc_per_clip))     # [1,B,Q,C]
         hs0 = hs[0].view(B, T, Q, C) + voc_hs[0][:, None]                    # level 0 (b t q c)
 
         cls = self.class_embed[0](hs0)

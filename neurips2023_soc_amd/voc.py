@@ -84,10 +84,13 @@ class VOC(nn.Module):
             self.transformer_cross_attention_layers.append(CrossAttentionLayer(d, self.num_heads))
             self.transformer_ffn_layers.append(FFNLayer(d, config["dim_feedforward"]))
 
-    def forward(self, frame_query: torch.Tensor, language_query: torch.Tensor) -> torch.Tensor:
+    def forward(self, frame_query: torch.Tensor, language_query: torch.Tensor, independent_clips: bool = False) -> torch.Tensor:
         """frame_query [L,T,B,Q,C] (all decoder levels), language_query [B,C] -> [1,B,Q,C].
 
-        Eval semantics of the reference (:274-275): only the LAST decoder level is clustered."""
+        Eval semantics of the reference (:274-275): only the LAST decoder level is clustered.
+        independent_clips: the B clips are separate inference requests that share a launch (graph_runner group pipelines): every
+        clip is clustered over ITS OWN frames, i.e. exactly what B forwards with B = 1 compute, in one batched pass (the
+        attention layers treat b as the batch dimension).  Default (False): the reference's B > 1 behaviour, see below."""
         if self.training:
             raise RuntimeError("inference-only module")
         fq = frame_query[-1]                      # [T,B,Q,C]
@@ -95,7 +98,8 @@ class VOC(nn.Module):
         # The reference RESHAPES [L,T,B,Q,C] to [L*B,T,Q,C] (:279) instead of permuting: for B > 1 the (t, b)
         # pairs are re-read as (b, t) in memory order, i.e. frames are redistributed over the batch.
         # Identity for B = 1 (every inference driver); kept so that a padded batch matches the reference too.
-        fq = fq.reshape(B, T, Q, C).transpose(0, 1)
+        if not independent_clips:
+            fq = fq.reshape(B, T, Q, C).transpose(0, 1)
         if self.enc_layers == 0:
             x = fq.permute(0, 2, 1, 3).reshape(T * Q, B, C)
         elif self.window_size == 0:
