@@ -562,13 +562,14 @@ class PairPipelinedClipGraph(PipelinedClipGraph):
         self.clip[:, slot].copy_(clip.view(self.clip.shape[0], *self.clip.shape[2:]), non_blocking=True)
         if ids is not None:
             self.ids[slot].copy_(ids.view(-1), non_blocking=True)
+            masked = self.__dict__.setdefault("_attn_masked", set())       # slots whose static mask is not all ones
             if attn is None:
-                if not getattr(self, "_attn_ones", True):
-                    self.attn.fill_(1)
-                    self._attn_ones = True
+                if slot in masked:
+                    self.attn[slot].fill_(1)
+                    masked.discard(slot)
             else:
                 self.attn[slot].copy_(attn.view(-1), non_blocking=True)
-                self._attn_ones = False
+                masked.add(slot)
 
     def run(self, clips, ids=None, attn=None):
         """clips: two [T,3,H,W] tensors; ids / attn: two [1,L] tensors each (or None)."""

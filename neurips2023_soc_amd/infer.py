@@ -33,13 +33,20 @@ class ClipInferencer:
     PAD_ID = 1            # RoBERTa <pad>
 
     def __init__(self, model, device="cuda", use_graphs: bool = True, max_graphs: int = 4,
-                 pad_tokens_to: Optional[int] = None):
+                 pad_tokens_to: Optional[int] = None, group: int = 1):
         """pad_tokens_to: with graphs, pad every expression to this many tokens (<pad> + attention mask 0), so
         that the graph geometry does not depend on the expression.  The reference's outputs are exactly
         invariant to such padding (checked on the reference itself; tests/test_host_plumbing.py checks the
         oracle), which is what tokenizer(..., padding="longest") does to the shorter expressions of a batch."""
         self.model, self.device = model, torch.device(device)
         self.use_graphs, self.max_graphs, self.pad_tokens_to = use_graphs, max_graphs, pad_tokens_to
+        # group > 1 (2 or 4): the streaming form shares every launch between `group` consecutive clips of one geometry
+        # (graph_runner.PairPipelinedClipGraph / QuadPipelinedClipGraph: each clip still gets its single-clip result); a
+        # part-filled group -- geometry change, end of the stream -- runs with stale partner slots
+        if group not in (1, 2, 4):
+            raise ValueError("group must be 1, 2 or 4")
+        self.group = group
+        self._filling = []           # (tag, original_size) of the clips staged into the group that has not been replayed yet
         self._graphs: Dict[Tuple[int, int, int, int], ClipGraph] = {}
         self._pipes: Dict[Tuple[int, int, int, int], PipelinedClipGraph] = {}
         self._active = None          # (key, pipe, tag of the clip in flight)
@@ -73,42 +80,69 @@ class ClipInferencer:
             res["masks"] = P.upsample_and_threshold(masks, original_size)
         return res
 
+    def _pipeline(self, key):
+        if key not in self._pipes:
+            while len(self._pipes) >= self.max_graphs:
+                torch.cuda.synchronize(self.device)
+                self._pipes.pop(next(iter(self._pipes)))
+            from .graph_runner import PairPipelinedClipGraph, QuadPipelinedClipGraph
+            cls = {1: pipeline_class(), 2: PairPipelinedClipGraph, 4: QuadPipelinedClipGraph}[self.group]
+            self._pipes[key] = cls(self.model, *key, self.device)
+        return self._pipes[key]
+
+    def _replay(self):
+        """Replay the group that has been staged; -> result dicts of the group replayed one call earlier."""
+        key, pipe, in_flight = self._active
+        rec = pipe.replay()
+        filled, self._filling = self._filling, []
+        self._active = (key, pipe, filled)
+        if rec is None or not in_flight:
+            return []
+        rows = rec if self.group > 1 else [rec]
+        return [self._unpack(rows[b], key, tag, osz) for b, (tag, osz) in enumerate(in_flight)]
+
     @torch.no_grad()
     def submit(self, clip: torch.Tensor, token_ids: torch.Tensor, tag, original_size=None):
-        """Streaming form of __call__ for use_graphs=True: submits `clip` and returns the result dict of the clip
-        submitted BEFORE it (its `tag` and `original_size` were given then), or None for the first clip / after a
-        geometry change has drained the pipeline (then a LIST of one result is returned first by drain()).
-        Results: 'tag', 'query', 'mask_logits' (a view of the graph's record: consume it, e.g. through 'masks', before
-        the next submit), 'pred_cls', 'masks' when original_size was given."""
+        """Streaming form of __call__ for use_graphs=True: submits `clip` and returns the LIST of result dicts that became
+        available -- those of the group of clips replayed one replay earlier (group = 1: the clip submitted before this one),
+        preceded by whatever a geometry change had to drain; often empty.  Every result carries the `tag` / `original_size`
+        given at its own submit.  Results: 'tag', 'query', 'mask_logits' (a view of the graph's record: consume it, e.g.
+        through 'masks', before the next submit), 'pred_cls', 'masks' when original_size was given.  `clip` may be reused by
+        the caller as soon as submit returns (it has been copied into the graph's static input)."""
         if not self.use_graphs:
             raise RuntimeError("submit() streams through hipGraphs; construct with use_graphs=True")
         T, _, H, W = clip.shape
         ids, attn = self._pad_tokens(token_ids)
         key = (T, H, W, ids.shape[-1])
-        done = None
+        out = []
         if self._active is not None and self._active[0] != key:
-            done = self.drain()                                   # geometry change: finish what is in flight
-        if key not in self._pipes:
-            while len(self._pipes) >= self.max_graphs:
-                torch.cuda.synchronize(self.device)
-                self._pipes.pop(next(iter(self._pipes)))
-            self._pipes[key] = pipeline_class()(self.model, T, H, W, ids.shape[-1], self.device)
-        pipe = self._pipes[key]
-        rec = pipe.run(clip, ids, attn)
-        prev = self._active
-        self._active = (key, pipe, tag, original_size)
-        if rec is not None and prev is not None:
-            return self._unpack(rec, prev[0], prev[2], prev[3])
-        return done[0] if done else None
+            out += self.drain()                                   # geometry change: finish what is staged and in flight
+        pipe = self._pipeline(key)
+        if self._active is None:
+            self._active = (key, pipe, [])
+        if self.group > 1:
+            pipe.stage_inputs(clip, ids, attn, slot=len(self._filling))
+        else:
+            pipe.stage_inputs(clip, ids, attn)
+        self._filling.append((tag, original_size))
+        if len(self._filling) == self.group:
+            out += self._replay()
+        return out
 
     @torch.no_grad()
     def drain(self):
-        """Finish the clip still in flight: [result dict] or []."""
+        """Finish what is staged (a part-filled group runs with stale partner slots) and in flight: list of result dicts."""
         if self._active is None:
             return []
-        key, pipe, tag, osz = self._active
+        out = []
+        if self._filling:
+            out += self._replay()
+        key, pipe, in_flight = self._active
         self._active = None
-        return [self._unpack(rec, key, tag, osz) for rec in pipe.flush()]
+        for rec in pipe.flush():
+            rows = rec if self.group > 1 else [rec]
+            out += [self._unpack(rows[b], key, tag, osz) for b, (tag, osz) in enumerate(in_flight)]
+        return out
 
     @torch.no_grad()
     def forward_clip(self, clip: torch.Tensor, token_ids: torch.Tensor):
@@ -202,7 +236,7 @@ def _run_dataset(a):
         tokenize = synthetic_dataset.HashTokenizer()
     driver = infer_refytb if a.dataset == "refytb" else infer_davis
     model = model.to(dev).eval()
-    engine = ClipInferencer(model, dev, use_graphs=a.graphs, pad_tokens_to=32)   # shared across passes
+    engine = ClipInferencer(model, dev, use_graphs=a.graphs, pad_tokens_to=32, group=a.group if a.graphs else 1)   # shared across passes
     for _ in range(max(a.repeat, 1)):
         stats = driver.run(model, tokenize, a.root, a.out, rank, world, dev, engine=engine)
     stats["clips_per_s"] = stats["expressions"] / stats["seconds"]
@@ -225,6 +259,9 @@ def parse_args(argv=None):
     ap.add_argument("--make-synthetic", type=int, default=0, metavar="N",
                     help="first write an N-video synthetic dataset (720x1280 JPEGs) under --root")
     ap.add_argument("--graphs", action="store_true", help="hipGraph replay per clip geometry in the dataset drivers")
+    ap.add_argument("--group", type=int, default=1, choices=[1, 2, 4],
+                    help="--graphs: consecutive clips of one geometry per launch group (each gets its single-clip result); "
+                         "pays where many clips share a geometry (DAVIS chunks, several expressions per video)")
     ap.add_argument("--words", type=int, default=0, help="--make-synthetic: fixed number of words per expression")
     ap.add_argument("--repeat", type=int, default=1, help="run the driver this many times, report the last (warm) pass")
     ap.add_argument("--gpus", "-ng", type=int, default=None,

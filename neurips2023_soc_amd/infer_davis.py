@@ -60,7 +60,7 @@ def run(model, tokenize: Tokenize, root: str, out_dir: str, rank: int = 0, world
         split: str = "valid", size: int = 360, max_size: Optional[int] = 640, use_graphs: bool = False,
         decode_workers: int = 8, writer_workers: int = 16, palette: Optional[Sequence[int]] = None,
         videos: Optional[Sequence[str]] = None, annotators: int = 4,
-        engine: Optional[ClipInferencer] = None, pad_tokens_to: Optional[int] = 32) -> Dict:
+        engine: Optional[ClipInferencer] = None, pad_tokens_to: Optional[int] = 32, group: int = 1) -> Dict:
     img_folder, data = load_meta(root, split)
     if palette is None:
         ref_png = os.path.join(root, split, "Annotations", "blackswan", "00000.png")
@@ -70,7 +70,7 @@ def run(model, tokenize: Tokenize, root: str, out_dir: str, rank: int = 0, world
         else:
             palette = davis_palette()
     todo = split_videos(sorted(data.keys()) if videos is None else list(videos), rank, world)
-    engine = engine or ClipInferencer(model, device, use_graphs=use_graphs, pad_tokens_to=pad_tokens_to)
+    engine = engine or ClipInferencer(model, device, use_graphs=use_graphs, pad_tokens_to=pad_tokens_to, group=group)
     cache = clip_io.VideoClipCache(clip_io.FramePreprocessor(device, size, max_size), workers=decode_workers)
     stats = {"videos": 0, "expressions": 0, "frames": 0, "seconds_input": 0.0, "seconds_model": 0.0}
     pending = []
@@ -122,8 +122,7 @@ def run(model, tokenize: Tokenize, root: str, out_dir: str, rank: int = 0, world
                     stats["seconds_input"] += time.perf_counter() - t1
                     for obj in range(num_obj):
                         if streaming:
-                            res = engine.submit(clip, ids[obj], (job, obj, ci))     # the PREVIOUS clip's result, or None
-                            if res is not None:
+                            for res in engine.submit(clip, ids[obj], (job, obj, ci)):   # results of the PREVIOUS replay, if any
                                 place(res)
                         else:
                             job["got"][obj][ci] = engine(clip, ids[obj])["mask_logits"].clone()   # [t,h,w]

@@ -58,12 +58,13 @@ def load_meta(root: str, split: str = "valid"):
 def run(model, tokenize: Tokenize, root: str, out_dir: str, rank: int = 0, world: int = 1, device="cuda",
         split: str = "valid", size: int = 360, max_size: Optional[int] = 640, use_graphs: bool = False,
         decode_workers: int = 8, writer_workers: int = 16, videos: Optional[Sequence[str]] = None,
-        engine: Optional[ClipInferencer] = None, pad_tokens_to: Optional[int] = 32) -> Dict:
-    """Process this rank's videos; returns counters + timings.  `tokenize(expression) -> int64 [1,L]`
+        engine: Optional[ClipInferencer] = None, pad_tokens_to: Optional[int] = 32, group: int = 1) -> Dict:
+    """Process this rank's videos; returns counters + timings.  group > 1 (with use_graphs): consecutive clips of one
+    geometry share every launch of the forward, each still getting its single-clip result (ClipInferencer(group=...)).  `tokenize(expression) -> int64 [1,L]`
     (RobertaTokenizerFast in production; no vocabulary files exist offline, so the caller supplies it)."""
     img_folder, data = load_meta(root, split)
     todo = split_videos(sorted(data.keys()) if videos is None else list(videos), rank, world)
-    engine = engine or ClipInferencer(model, device, use_graphs=use_graphs, pad_tokens_to=pad_tokens_to)
+    engine = engine or ClipInferencer(model, device, use_graphs=use_graphs, pad_tokens_to=pad_tokens_to, group=group)
     cache = clip_io.VideoClipCache(clip_io.FramePreprocessor(device, size, max_size), workers=decode_workers)
     stats = {"videos": 0, "expressions": 0, "frames": 0, "seconds_input": 0.0, "seconds_model": 0.0}
     pending = []
@@ -88,12 +89,16 @@ def run(model, tokenize: Tokenize, root: str, out_dir: str, rank: int = 0, world
 
     d2h = torch.cuda.Stream(device=device)    # mask download overlaps the next clip's forward
 
-    streaming = engine.use_graphs        # graphs: software-pipelined replays, results arrive one clip late
+    streaming = engine.use_graphs        # graphs: software-pipelined replays, results arrive one replay late
+    # downloads left in flight behind the newest results: with a group pipeline (engine.group clips per replay) the results
+    # of a group arrive together, right behind the replay of the NEXT group -- waiting for them at once would hold the host
+    # for that whole replay
+    lag = engine.group if streaming else 1
 
     def enqueue_download(res):
         """masks of a finished clip -> pinned host buffer on the d2h stream; returns the job for flush()"""
         masks, (save_dir, names) = res["masks"], res["tag"]
-        host = host_buffer(masks.shape, enqueue_download.n % 2)
+        host = host_buffer(masks.shape, enqueue_download.n % (2 * lag + 2))
         enqueue_download.n += 1
         d2h.wait_stream(torch.cuda.current_stream(device))
         with torch.cuda.stream(d2h):
@@ -104,8 +109,16 @@ def run(model, tokenize: Tokenize, root: str, out_dir: str, rank: int = 0, world
         return (host, done, save_dir, names)
     enqueue_download.n = 0
 
+    import collections
+    jobs = collections.deque()           # downloads in flight, oldest first
+
+    def handle(results):
+        for res in results:
+            jobs.append(enqueue_download(res))
+            while len(jobs) > lag:
+                flush(jobs.popleft())
+
     with ThreadPoolExecutor(max_workers=writer_workers) as writers:
-        prev = None
         for vi, video in enumerate(todo):
             frames = data[video]["frames"]
             paths = clip_io.frame_paths(img_folder, video, frames)
@@ -119,26 +132,20 @@ def run(model, tokenize: Tokenize, root: str, out_dir: str, rank: int = 0, world
                 save_dir = os.path.join(out_dir, video, exp_id)
                 os.makedirs(save_dir, exist_ok=True)
                 if streaming:
-                    res = engine.submit(clip, ids, (save_dir, frames), orig)   # result of the PREVIOUS clip, or None
+                    handle(engine.submit(clip, ids, (save_dir, frames), orig))  # results of the PREVIOUS replay, if any
                 else:
                     res = engine(clip, ids, orig)                              # [T,H0,W0] bool, still in flight
                     res["tag"] = (save_dir, frames)
-                job = enqueue_download(res) if res is not None else None
-                if prev is not None:
-                    flush(prev)
-                prev = job
+                    handle([res])
                 stats["seconds_input"] += t2 - t1
                 stats["seconds_model"] += time.perf_counter() - t2
                 stats["expressions"] += 1
                 stats["frames"] += len(frames)
             stats["videos"] += 1
         if streaming:
-            for res in engine.drain():
-                if prev is not None:
-                    flush(prev)
-                prev = enqueue_download(res)
-        if prev is not None:
-            flush(prev)
+            handle(engine.drain())
+        while jobs:
+            flush(jobs.popleft())
         t_tail = time.perf_counter()
         for f in pending:
             f.result()

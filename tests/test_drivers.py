@@ -64,10 +64,12 @@ def gpu_model():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("use_graphs", [False, True])
+@pytest.mark.parametrize("use_graphs", [False, True, 4, 2])
 def test_refytb_driver_matches_reference_recipe(gpu_model, tmp_path, use_graphs):
     """use_graphs=True: the driver streams through the software-pipelined hipGraph (results one clip late, drained
-    at the end) -- the same PNGs must come out."""
+    at the end) -- the same PNGs must come out.  4 / 2: through the group pipelines (four / two clips per launch group: the four
+    clips of the set are one full group / two; results arrive a whole group late)."""
+    group, use_graphs = (use_graphs, True) if use_graphs not in (False, True) else (1, use_graphs)
     from PIL import Image
     from neurips2023_soc_amd import infer_refytb
     model, sd = gpu_model
@@ -75,7 +77,7 @@ def test_refytb_driver_matches_reference_recipe(gpu_model, tmp_path, use_graphs)
     tok = SD.HashTokenizer()
     out_dir = str(tmp_path / "out")
     stats = infer_refytb.run(model, tok, root, out_dir, size=SIZE, max_size=MAX_SIZE, decode_workers=2,
-                             use_graphs=use_graphs)
+                             use_graphs=use_graphs, group=group)
     assert stats["videos"] == 2 and stats["expressions"] == 4 and stats["frames"] == 12
     assert stats["cache_misses"] == 2 and stats["cache_hits"] == 2      # frames decoded once per video
     _, data = infer_refytb.load_meta(root)
@@ -99,10 +101,11 @@ def test_refytb_driver_matches_reference_recipe(gpu_model, tmp_path, use_graphs)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("use_graphs", [False, True])
+@pytest.mark.parametrize("use_graphs", [False, True, 4])
 def test_davis_driver_matches_reference_recipe(gpu_model, tmp_path, use_graphs):
     """use_graphs=True streams the (object, chunk) clips through the software-pipelined replay and merges an
-    annotator's label maps when its last result has arrived"""
+    annotator's label maps when its last result has arrived; 4: through the group pipeline (eight clips = two groups)"""
+    group, use_graphs = (use_graphs, True) if use_graphs not in (False, True) else (1, use_graphs)
     from PIL import Image
     from neurips2023_soc_amd import infer_davis, infer_refytb
     model, sd = gpu_model
@@ -111,7 +114,7 @@ def test_davis_driver_matches_reference_recipe(gpu_model, tmp_path, use_graphs):
     tok = SD.HashTokenizer()
     out_dir = str(tmp_path / "out")
     stats = infer_davis.run(model, tok, root, out_dir, size=SIZE, max_size=MAX_SIZE, decode_workers=2,
-                            use_graphs=use_graphs)
+                            use_graphs=use_graphs, group=group)
     # one chunk per video here: the clip is fetched once per annotator (per object in the reference's loop order)
     assert stats["expressions"] == 8 and stats["cache_misses"] == 1 and stats["cache_hits"] == 3
     _, data = infer_refytb.load_meta(root)

@@ -18,6 +18,7 @@ sys.path.insert(0, ROOT)
 ap = argparse.ArgumentParser()
 ap.add_argument("--videos", type=int, default=64)
 ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r05_files_to_png.json"))
+ap.add_argument("--group", type=int, default=1, help="clips per launch group of the driver's graph pipeline (1, 2, 4)")
 a = ap.parse_args()
 
 import numpy as np  # noqa: E402
@@ -30,7 +31,7 @@ root, out_dir = os.path.join(tmp, "data"), os.path.join(tmp, "out")
 synthetic_dataset.make_dataset(root, videos=a.videos, frames=8, expressions=3, n_words=8)
 # ---- the driver itself, warm pass reported (child process: its own GPU context, the parent stays CPU-only)
 cmd = [sys.executable, "-m", "neurips2023_soc_amd.infer", "--dataset", "refytb", "--root", root, "--out", out_dir, "--graphs",
-       "--repeat", "2"]
+       "--repeat", "2", "--group", str(a.group)]
 t0 = time.perf_counter()
 r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True)
 wall = time.perf_counter() - t0
