@@ -172,6 +172,9 @@ class PipelinedClipGraph:
 
         self.steady = [capture(lambda k=k: tail_beside_head(k)) for k in (0, 1)]
         self.drain = [capture(lambda k=k: self._tail(self.sb[k], fork=True)) for k in (0, 1)]
+        # the first replay after a flush has no tail to run: head only, into sb[0] (a steady graph there would run the tail of
+        # stale state beside it)
+        self.first = capture(lambda: self._store(self._placed_head(self.sb[0]), self.sb[0]))
         self._n = 0            # clips submitted since the last flush
 
     # -- stages ------------------------------------------------------------------------------------------
@@ -270,7 +273,7 @@ class PipelinedClipGraph:
     stage_inputs = ClipGraph.stage_inputs
 
     def replay(self):
-        self.steady[self._n % 2].replay()
+        (self.first if self._n == 0 else self.steady[self._n % 2]).replay()
         self._n += 1
         return self.record if self._n >= self.DEPTH else None
 
@@ -543,6 +546,7 @@ class PairPipelinedClipGraph(PipelinedClipGraph):
 
         self.steady = [capture(lambda k=k: tail_beside_head(k)) for k in (0, 1)]
         self.drain = [capture(lambda k=k: self._tail(self.sb[k], fork=True)) for k in (0, 1)]
+        self.first = capture(lambda: self._store(self._placed_head(self.sb[0]), self.sb[0]))      # head only: see the parent
         self._n = 0
 
     def _tail(self, sb, fork: bool):
