@@ -60,9 +60,10 @@ def parse():
                     help="one clip per graph replay (ClipGraph) instead of the software-pipelined PipelinedClipGraph")
     ap.add_argument("--pipeline", choices=["two-stream", "one-graph", "pairs", "quads"], default=None,
                     help="software pipeline across clips: quads (default up to 360x640: four independent clips per launch group, "
-                         "VOC per clip: graph_runner.QuadPipelinedClipGraph), pairs (two), one-graph (default above 360x640, where a "
-                         "clip fills the chip by itself -- Swin-B 720p: 44.1 ms per clip against 49.2 in groups of four; one clip "
-                         "per launch: rounds 1-4, PipelinedClipGraph; also timed as single_clip_ms_per_step), two-stream")
+                         "VOC over independent clips: graph_runner.QuadPipelinedClipGraph), pairs (two; default above 360x640, where "
+                         "a clip nearly fills the chip by itself -- Swin-B 720p: 42.1 ms per clip in pairs, 42.6 alone, 49.2 in "
+                         "fours), one-graph (one clip per launch: rounds 1-4, PipelinedClipGraph; always timed beside the headline "
+                         "as single_clip_ms_per_step), two-stream")
     ap.add_argument("--no-stream", action="store_true",
                     help="skip the second, H2D-inclusive timed pass (stream_ms_per_step)")
     ap.add_argument("--stub", action="store_true",
@@ -254,7 +255,7 @@ def stub_main(a, CP):
 def main():
     a = parse()
     if a.pipeline is None:
-        a.pipeline = "quads" if a.frames * a.height * a.width <= 8 * 360 * 640 else "one-graph"
+        a.pipeline = "quads" if a.frames * a.height * a.width <= 8 * 360 * 640 else "pairs"
     from neurips2023_soc_amd import clip_parallel as CP
     CP.rank_environment()           # before anything touches the GPU: the same process environment in both launch modes
     if a.gpus > 1 and not CP.launched_as_rank():

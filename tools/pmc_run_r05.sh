@@ -49,8 +49,8 @@ swinb)
   python3 bench.py --backbone video-swin-b --no-stream --detail $P/bench_r05_swinb_360p_detail.json > $P/bench_r05_swinb_360p.json 2> $P/bench_r05_swinb_360p.err
   python3 bench.py --backbone video-swin-b --height 720 --width 1280 --steps 10 --no-stream --detail $P/bench_r05_swinb_720p_detail.json > $P/bench_r05_swinb_720p.json 2> $P/bench_r05_swinb_720p.err
   for geo in 360p 720p; do
-    # 720p runs one clip per launch (bench.py's default above 360x640), 360p groups of $GROUP
-    if [ $geo = 720p ]; then G="--height 720 --width 1280 --steps 6"; PERG=1; else G="--steps 12"; PERG=$GROUP; fi
+    # 720p runs pairs (bench.py's default above 360x640), 360p groups of $GROUP
+    if [ $geo = 720p ]; then G="--height 720 --width 1280 --steps 6"; PERG=2; else G="--steps 12"; PERG=$GROUP; fi
     rocprofv3 --kernel-trace --stats --output-format csv -d $P/trace_swinb_$geo -- python3 bench.py --backbone video-swin-b $G --warmup 2 --no-cpu-baseline --no-stream --no-f32-pass --detail $P/trace_swinb_${geo}_detail.json > $P/trace_swinb_$geo.json 2> $P/trace_swinb_$geo.err
     cp $(ls $P/trace_swinb_$geo/*/*kernel_stats.csv | head -1) $P/r05_swinb_${geo}_kernel_stats.csv
     SOC_TRACE_CLIPS_PER_GROUP=$PERG python3 tools/analyze_trace.py $(ls $P/trace_swinb_$geo/*/*kernel_trace.csv | head -1) --top 25 > $P/r05_swinb_${geo}_forward_breakdown.txt
