@@ -59,6 +59,35 @@ swinb)
     python3 tools/pmc_traffic.py $(ls $P/pmc_fetch_swinb_$geo/*/*counter_collection.csv | head -1) $(ls $P/pmc_write_swinb_$geo/*/*counter_collection.csv | head -1) $PERG > $P/r05_swinb_${geo}_hbm_traffic_pmc.json
   done
   ;;
+counters)
+  # ---- (c2) K23 / K1 / K24 at the shapes of a launch group ($GROUP clips) and of one clip: matrix-pipe / VALU / LDS / wait counters
+  for clips in $GROUP 1; do
+    for site in k23enc k23s2 k1s0 k1s2 k24qkv2 k24qkv3; do
+      case $site in k23*) pat=mlp_split_kernel;; k1*) pat=win_attn3d_;; *) pat=xs_linear_kernel;; esac
+      tag=${site}_x${clips}
+      rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY -d $P/${tag}_sq -- python3 tools/run_kernel.py $site 12 $clips > $P/${tag}_sq.log 2>&1
+      rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_COEXEC_CYCLES GRBM_GUI_ACTIVE -d $P/${tag}_lds -- python3 tools/run_kernel.py $site 12 $clips > $P/${tag}_lds.log 2>&1
+      python3 tools/pmc_agg.py --kernels "${tag}=${pat}" -- $P/${tag}_sq $P/${tag}_lds > $P/${tag}_counters.json
+    done
+  done
+  python3 - <<'PY' > gpurun_out/r05/r05_group_counters.json
+import glob, json, os
+out = {"command": "tools/pmc_run_r05.sh counters: rocprofv3 --kernel-trace --pmc <8 SQ counters> | <LDS / co-execution counters, GRBM_GUI_ACTIVE> "
+                  "(two separate passes) -- python3 tools/run_kernel.py <site> 12 <clips per launch group>; tools/pmc_agg.py: mean per launch.  "
+                  "matrix_pipe_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 128); wait_share = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES"}
+for f in sorted(glob.glob("gpurun_out/r05/*_x[14]_counters.json")):
+    d = json.load(open(f))
+    for k, c in d.items():
+        if not isinstance(c, dict) or "SQ_INSTS_MFMA" not in c:
+            continue
+        g = c["GRBM_GUI_ACTIVE"]["mean_per_launch"]
+        c["derived"] = {"matrix_pipe_busy": c["SQ_VALU_MFMA_BUSY_CYCLES"]["mean_per_launch"] / (g * 128),
+                        "wait_share": c["SQ_WAIT_INST_ANY"]["mean_per_launch"] / c["SQ_WAVE_CYCLES"]["mean_per_launch"],
+                        "valu_per_mfma": c["SQ_INSTS_VALU"]["mean_per_launch"] / c["SQ_INSTS_MFMA"]["mean_per_launch"]}
+        out[k] = c
+print(json.dumps(out, indent=1))
+PY
+  ;;
 rest)
   # ---- (e) stage times of the replay, pipelines side by side on one box, probes
   python3 tools/head_probe.py > $P/head_probe.txt 2>&1

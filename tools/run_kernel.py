@@ -10,13 +10,14 @@ from neurips2023_soc_amd import hot_ops  # noqa: E402
 
 which = sys.argv[1] if len(sys.argv) > 1 else "k1s0"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+CLIPS = int(sys.argv[3]) if len(sys.argv) > 3 else 1      # clips per launch group (bench.py's default pipeline: 4): rows x CLIPS
 g = torch.Generator().manual_seed(0)
 dev = "cuda"
 if which.startswith("k1s"):
     st = int(which[-1])
     H, W, nH = [(90, 160, 3), (45, 80, 6), (23, 40, 12), (12, 20, 24)][st]
     C = nH * 32
-    qkv = torch.randn(1, 8, H, W, 3 * C, generator=g).to(dev)
+    qkv = torch.randn(CLIPS, 8, H, W, 3 * C, generator=g).to(dev)
     bias = torch.randn(3 * C, generator=g).to(dev)
     table = (torch.randn(2535, nH, generator=g) * 0.2).to(dev)
     fn = lambda: hot_ops.window_attention3d(qkv, bias, table, nH, (8, 7, 7), (4, 3, 3))  # noqa: E731
@@ -58,6 +59,7 @@ elif which.startswith("k23"):
     # K23 at its four call sites: Video-Swin stage 0 / 1 / 2 MLP (norm2 + fc1 + GELU + fc2 + shortcut), the encoder's FFN + norm2
     M, Cw, F, act, use_ln = {"k23s0": (115200, 96, 384, "gelu", True), "k23s1": (28800, 192, 768, "gelu", True),
                              "k23s2": (7360, 384, 1536, "gelu", True), "k23enc": (38560, 256, 2048, "relu", False)}[which]
+    M *= CLIPS
     x = torch.randn(M, Cw, generator=g).to(dev)
     w1, b1 = (torch.randn(F, Cw, generator=g) / Cw ** 0.5).to(dev), torch.randn(F, generator=g).to(dev)
     w2, b2 = (torch.randn(Cw, F, generator=g) / F ** 0.5).to(dev), torch.randn(Cw, generator=g).to(dev)
@@ -67,6 +69,7 @@ elif which.startswith("k24"):
     # K24 at four of its call sites: stage-2 qkv, the encoder's value_proj, stage-3 norm1 + qkv, the fusion query projection
     M, N, K, use_ln = {"k24qkv2": (7360, 1152, 384, False), "k24enc": (38560, 256, 256, False),
                        "k24qkv3": (1920, 2304, 768, True), "k24vlf": (28800, 256, 256, False)}[which]
+    M *= CLIPS
     x = torch.randn(M, K, generator=g).to(dev)
     wt = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
     b = torch.randn(N, generator=g).to(dev)
