@@ -284,6 +284,19 @@ int soc_mlp_split_f32(const float* x, const void* packed, const float* b1, const
                       const float* ln_beta, float ln_eps, const float* residual, const float* post_gamma,
                       const float* post_beta, float post_eps, float* out, float* out_sum, float* workspace,
                       size_t workspace_bytes, long M, int C, int F, int act, int residual_ln, void* stream);
+/*
+ * K26 -- query selection + record packing of the inference loop in one launch, for every clip of a launch group (reference
+ * infer_refytb.py:216-226: pred_cls.sigmoid().mean(0) -> max over classes -> argmax over queries -> the masks of that query):
+ *   records[b] = [ idx_b, pred_cls[:, b, :, 0]  (T*Q logits),  pred_masks[:, b, idx_b]  (T*HW logits) ]        (float32)
+ *   idx_b = argmax_q max_k mean_t sigmoid(pred_cls[t, b, q, k])     (the first maximum, as torch.argmax)
+ * pred_cls [T, B, Q, K] with element strides (cls_stride_t, cls_stride_b, cls_stride_q), K contiguous (the model hands out a
+ * transposed view); pred_masks [T, B, Q, HW] contiguous; records [B][record_stride], record_stride >= 1 + T*Q + T*HW.
+ * Q <= 256; otherwise SOC_EUNSUPPORTED.
+ */
+int soc_select_pack_f32(const float* pred_cls, long cls_stride_t, long cls_stride_b, long cls_stride_q,
+                        const float* pred_masks, float* records, long record_stride, int T, int B, int Q, int K, long HW,
+                        void* stream);
+
 /* Largest hidden width F soc_mlp_split_f32 takes at model width C (the b1 range of a workgroup shares the 160 KB of LDS with
  * the weight ring); 0 for a width K23 is not built for.  Pure function of C.  F beyond it: SOC_EUNSUPPORTED at launch. */
 int soc_mlp_split_max_hidden(int C);

@@ -24,7 +24,7 @@ EXPORTS = ("soc_hip_abi_version", "soc_hip_error_string", "soc_stream_cus", "soc
            "soc_mlp_split_packed_bytes", "soc_mlp_split_pack_f32",
            "soc_mlp_split_workspace_bytes", "soc_mlp_split_plan", "soc_mlp_split_max_hidden", "soc_mlp_split_f32", "soc_mlp_split_variant_f32",
            "soc_xs_linear_packed_bytes", "soc_xs_linear_pack_f32", "soc_xs_linear_plan", "soc_xs_linear_f32",
-           "soc_small_attn_f32")
+           "soc_small_attn_f32", "soc_select_pack_f32")
 ABI_VERSION = 16
 SOC_EUNSUPPORTED = -2      # include/soc_hip.h: shape outside what the kernel is built for
 
@@ -59,6 +59,8 @@ def load() -> C.CDLL:
     p, i, f = C.c_void_p, C.c_int, C.c_float
     lib.soc_hip_abi_version.restype = i
     lib.soc_mlp_split_max_hidden.restype = i
+    lib.soc_select_pack_f32.restype = i
+    lib.soc_select_pack_f32.argtypes = [p, C.c_long, C.c_long, C.c_long, p, p, C.c_long, i, i, i, i, C.c_long, p]
     lib.soc_stream_cus.restype = i
     lib.soc_stream_cus.argtypes = [p]
     lib.soc_mlp_split_max_hidden.argtypes = [i]

@@ -76,8 +76,7 @@ class ClipGraph:
     def _forward(self):
         samples = NestedTensor(self.clip, self.pad, unpadded=True)  # static all-False pad mask
         out = self.model(samples, None, {"input_ids": self.ids, "attention_mask": self.attn}, self.targets)
-        idx, masks = P.select_trajectory(out)
-        CP.pack_record(self.record, idx, out["pred_cls"][:, 0, :, 0], masks)
+        hot_ops.select_pack(out["pred_cls"], out["pred_masks"], self.record[None])      # K26 (was select_trajectory + pack_record)
         return out
 
     def run(self, clip: torch.Tensor, ids: Optional[torch.Tensor] = None,
@@ -213,8 +212,7 @@ class PipelinedClipGraph:
             out = self.model.forward_tail(sb, self.targets, fork=fork)
         finally:
             hot_ops.row_chain_fusion = prev
-        idx, masks = P.select_trajectory(out)
-        CP.pack_record(self.record, idx, out["pred_cls"][:, 0, :, 0], masks)
+        hot_ops.select_pack(out["pred_cls"], out["pred_masks"], self.record[None])      # K26
 
     _VARY = ("ctx", "feats0", "lang_last", "word_pad", "sentence")    # what the head hands to the tail per clip
 
@@ -473,9 +471,7 @@ def group_tail(model, state, targets_one, fork: bool, records) -> None:
     B = state["B"]
     targets = [[frame[0]] * B for frame in targets_one]
     out = model.forward_tail(state, targets, fork=fork, voc_per_clip=True)
-    for b in range(B):
-        idx, masks = P.select_trajectory({"pred_cls": out["pred_cls"][:, b:b + 1], "pred_masks": out["pred_masks"][:, b:b + 1]})
-        CP.pack_record(records[b], idx, out["pred_cls"][:, b, :, 0], masks)
+    hot_ops.select_pack(out["pred_cls"], out["pred_masks"], records[:B])        # K26: selection + packing of every clip, one launch
 
 
 class PairPipelinedClipGraph(PipelinedClipGraph):

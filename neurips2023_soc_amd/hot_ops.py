@@ -676,6 +676,27 @@ def box_refine(delta: Tensor, ref: Tensor, valid_ratios: Optional[Tensor] = None
     return new_ref, ref_in
 
 
+def select_pack(pred_cls: Tensor, pred_masks: Tensor, records: Tensor) -> None:
+    """K26.  pred_cls [T,B,Q,K] (any strides over t / b / q, K contiguous), pred_masks [T,B,Q,h,w] -> records [B, 1 + T*Q + T*h*w]
+    float32 (rows may be strided): per clip the selected query (best mean sigmoid score over frames, max over classes), its class-0
+    logits per frame and query, and the mask logits of the selected query -- what postprocessing.select_trajectory +
+    clip_parallel.pack_record produce with nine torch launches per clip."""
+    _need_gpu(pred_cls, pred_masks, records)
+    lib = _lib.load()
+    T, B, Q, K = pred_cls.shape
+    if pred_cls.dtype != torch.float32 or pred_cls.stride(3) != 1 and K > 1:
+        pred_cls = _f32c(pred_cls)
+    pred_masks = _f32c(pred_masks)
+    HW = pred_masks.shape[-2] * pred_masks.shape[-1]
+    if (records.dtype != torch.float32 or records.dim() != 2 or records.shape[0] != B or records.stride(1) != 1
+            or records.shape[1] < 1 + T * Q + T * HW or tuple(pred_masks.shape[:3]) != (T, B, Q)):
+        raise _lib.SocHipError("select_pack: records must be float32 [B, >= 1 + T*Q + T*h*w] with contiguous rows")
+    with _timed("select_pack", (T * Q * K * B + 2 * T * HW * B) * 4):
+        code = lib.soc_select_pack_f32(pred_cls.data_ptr(), pred_cls.stride(0), pred_cls.stride(1), pred_cls.stride(2),
+                                       pred_masks.data_ptr(), records.data_ptr(), records.stride(0), T, B, Q, K, HW, _stream())
+    _lib.check(code, "soc_select_pack_f32")
+
+
 def upsample_merge_labels(mask_logits: Tensor, size: Sequence[int], threshold: float = 0.5,
                           background: float = 0.1) -> Tensor:
     """K6, DAVIS form.  [O,T,h,w] logits of O objects -> uint8 labels [T,H0,W0] (0 = background):

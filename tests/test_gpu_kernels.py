@@ -1454,3 +1454,31 @@ def test_small_attention_vs_sdpa(ops, B, L, H, D, mask_kind):
     want = (p @ vd).transpose(1, 2).reshape(B, L, E)
     assert float((got.double() - want).abs().max()) < 2e-6 * max(1.0, float(want.abs().max()))
     assert torch.equal(got, ops.small_attention(q, k, v, H, mask))
+
+
+@pytest.mark.parametrize("T,B,Q,K,h,w", [(8, 1, 20, 1, 90, 160), (8, 4, 20, 1, 90, 160), (3, 2, 7, 3, 5, 9), (36, 1, 20, 1, 12, 20)])
+def test_select_pack_vs_torch(ops, T, B, Q, K, h, w):
+    """K26 against the nine torch ops it replaces (postprocessing.select_trajectory + clip_parallel.pack_record, i.e. reference
+    infer_refytb.py:216-226) for every clip of a launch group: the selected query, the class-0 logits, the selected masks -- bit
+    for bit; pred_cls as the transposed view the model hands out; a tie goes to the first query, as torch.argmax."""
+    from neurips2023_soc_amd import clip_parallel as CP, postprocessing as P
+    g = torch.Generator().manual_seed(T * 100 + B * 10 + Q)
+    cls = torch.randn(B, T, Q, K, generator=g).cuda().transpose(0, 1)             # [T,B,Q,K], non-contiguous
+    masks = torch.randn(T, B, Q, h, w, generator=g).cuda()
+    R = CP.record_size(T, Q, h, w)
+    got = torch.full((B + 1, R + 5), -7.0, device="cuda")[:B, :R]               # strided rows inside a larger buffer
+    ops.select_pack(cls, masks, got)
+    want = torch.zeros(B, R, device="cuda")
+    for b in range(B):
+        out = {"pred_cls": cls[:, b:b + 1], "pred_masks": masks[:, b:b + 1]}
+        idx, m = P.select_trajectory(out)
+        CP.pack_record(want[b], idx, cls[:, b, :, 0], m)
+    assert torch.equal(got[:, 1:], want[:, 1:]) and torch.equal(got[:, 0], want[:, 0])
+    # a tie: two queries with identical logits -> the first one
+    tied = cls.clone()
+    tied[:, :, 3] = 50.0
+    tied[:, :, 5] = 50.0
+    ops.select_pack(tied, masks, got)
+    assert bool((got[:, 0] == 3).all())
+    with pytest.raises(RuntimeError):
+        ops.select_pack(cls, masks, torch.zeros(B, R - 1, device="cuda"))
