@@ -171,3 +171,68 @@ def test_derived_cache_keys_on_the_tensors_and_dies_with_them():
     p1.data = torch.randn(8, 4)
     assert c.get((key_view,), build) == 7                                                   # not the stale image
     assert c.get((p1,), build) == 8 and c.get((p1,), build) == 8                            # the re-pointed parameter: rebuilt once
+
+
+def test_clip_inferencer_group_bookkeeping_with_a_stub_pipeline(monkeypatch):
+    """ClipInferencer.submit / drain with launch groups (group = 1 / 2 / 4), on CPU with a stub pipeline: every clip's result
+    comes back exactly once, under its own tag and original size, in submission order, one replay late; a geometry change and
+    the end of the stream drain a part-filled group; group = 1 keeps the one-clip behaviour."""
+    import torch
+
+    from neurips2023_soc_amd import infer
+
+    class StubPipe:
+        """records = the clip id each slot was staged with; replay() returns the previous replay's records (DEPTH 2)"""
+        def __init__(self, clips):
+            self.CLIPS = clips
+            self.slots = [None] * clips
+            self.in_head, self.n = None, 0
+            self.record = None
+
+        def stage_inputs(self, clip, ids, attn=None, slot=0):
+            self.slots[slot] = float(clip.view(-1)[0])
+
+        def replay(self):
+            prev, self.in_head = self.in_head, list(self.slots)
+            self.n += 1
+            if self.n >= 2:
+                self.record = torch.tensor([[v if v is not None else -1.0] for v in prev])
+                return self.record if self.CLIPS > 1 else self.record[0]
+            return None
+
+        def flush(self):
+            if self.n == 0:
+                return []
+            rec = torch.tensor([[v if v is not None else -1.0] for v in self.in_head])
+            self.n, self.in_head = 0, None
+            return [rec if self.CLIPS > 1 else rec[0]]
+
+    class Model:
+        num_queries = 1
+
+    for group in (1, 2, 4):
+        eng = infer.ClipInferencer(Model(), "cpu", use_graphs=True, group=group)
+        made = []
+
+        def pipeline(key, eng=eng, group=group, made=made):
+            if key not in eng._pipes:
+                eng._pipes[key] = StubPipe(group)
+                made.append(key)
+            return eng._pipes[key]
+
+        monkeypatch.setattr(eng, "_pipeline", pipeline)
+        monkeypatch.setattr(eng, "_unpack", lambda rec, key, tag, osz: {"tag": tag, "osz": osz, "clip": float(rec.view(-1)[0]), "key": key})
+        got = []
+        # 7 clips of one geometry, then 3 of another (drains a part-filled group), then the end of the stream
+        stream = [(i, (8, 4, 6)) for i in range(7)] + [(100 + i, (8, 6, 6)) for i in range(3)]
+        for cid, (T, H, W) in stream:
+            clip = torch.full((T, 3, H, W), float(cid))
+            got += eng.submit(clip, torch.ones(1, 5, dtype=torch.long), ("tag", cid), (H * 2, W * 2))
+        got += eng.drain()
+        assert [r["clip"] for r in got] == [float(c) for c, _ in stream], (group, [r["clip"] for r in got])
+        assert all(r["tag"] == ("tag", int(r["clip"])) for r in got)
+        assert all(r["osz"] == (r["key"][1] * 2, r["key"][2] * 2) for r in got)
+        assert len(made) == 2 and eng.drain() == []
+    import pytest
+    with pytest.raises(ValueError):
+        infer.ClipInferencer(Model(), "cpu", group=3)
