@@ -527,3 +527,53 @@ assert worst < 2e-4 and worst_late <= worst, (worst, worst_late)
 """ % root
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=420)
     assert r.returncode == 0 and "SOAK_OK" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
+
+
+def test_group_pipeline_soak_full_config():
+    """400 back-to-back replays (1 600 clips) of the four-clip launch-group pipeline that bench.py times, at the BASELINE size:
+    no hang (child process, killed after the timeout) and no drift -- every time a clip comes round, in whichever slot, its record
+    equals the first one to within the run-to-run noise of the library kernels, and the noise does not grow."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys, torch
+sys.path.insert(0, %r)
+import neurips2023_soc_amd as S
+from neurips2023_soc_amd import weights as W
+from neurips2023_soc_amd.graph_runner import QuadPipelinedClipGraph
+T, H, Wd, L, N = 8, 360, 640, 10, 400
+model, _, _ = S.build_model(S.default_args(text_encoder_random_init=True))
+W.load_synthetic(model, 2023)
+model = model.cuda().eval()
+clips = [W.synthetic_clip(1 + i, T, H, Wd).cuda() for i in range(5)]       # 5 clips over 4 slots: every clip visits every slot
+ids = [W.synthetic_token_ids(1 + i %% 2, L).cuda() for i in range(5)]
+pg = QuadPipelinedClipGraph(model, T, H, Wd, L, "cuda")
+first, worst, worst_late = {}, torch.zeros((), device="cuda"), torch.zeros((), device="cuda")
+order = []
+for r in range(N):
+    group = [(4 * r + b) %% 5 for b in range(4)]
+    for b, c in enumerate(group):
+        pg.stage_inputs(clips[c], ids[c], slot=b)
+    rec = pg.replay()
+    order.append(group)
+    if rec is not None:
+        for b, c in enumerate(order[-2]):
+            if c not in first:
+                first[c] = rec[b].clone()
+            else:
+                d = (rec[b] - first[c]).abs().max()
+                worst = torch.maximum(worst, d)
+                if r >= N // 2:
+                    worst_late = torch.maximum(worst_late, d)
+last = pg.flush()
+torch.cuda.synchronize()
+worst, worst_late = float(worst), float(worst_late)
+assert len(last) == 1 and last[0].shape[0] == 4 and len(first) == 5
+assert bool(torch.isfinite(last[0]).all())
+print("SOAK_OK replays", N, "max deviation from the first record", worst, "in the second half", worst_late)
+assert worst < 2e-4 and worst_late <= worst, (worst, worst_late)
+""" % root
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=420)
+    assert r.returncode == 0 and "SOAK_OK" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
