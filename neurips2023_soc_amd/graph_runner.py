@@ -26,6 +26,7 @@ SWITCHES = {
     "SOC_TAIL_ROW_FUSION": "1: the pipelined tail keeps K16's fused row chains (default: K7's small workgroups beside a head)",
     "SOC_TAIL_NO_FORK": "1: the tail never forks FPN || query chain, not even in the drain graph",
     "SOC_TAIL_PRIORITY": "0: the tail branch of the one-graph pipeline is captured at default stream priority (default: high)",
+    "SOC_GROUP_SEQ_FIRST": "1: a launch group keeps the reference's '(t h w) b c' / [T,B,...] layouts (a permute copy of every level each way)",
     "SOC_MATMUL": "split | f32: arithmetic a model is built with (hot_ops.DEFAULT_MATMUL_MODE; SOC.matmul_mode overrides per model)",
     "SOC_SPLIT_OFF": "comma list of call sites / kernels forced back to the f32 path (k1, k13, k24, mlp, swin, gelu, ...)",
     "SOC_PNG": "pillow: the drivers write PNGs through Pillow instead of libsoc_host.so (SOC_PNG_LEVEL: its compress_level)",
@@ -501,8 +502,13 @@ class PairPipelinedClipGraph(PipelinedClipGraph):
         self.model, self.T, self.H, self.W, self.L = model, T, H, W, L
         dev = self.device = torch.device(device)
         n = self.CLIPS
-        self.clip = torch.zeros(T, n, 3, H, W, device=dev)
-        self.pad = torch.zeros(T, n, H, W, dtype=torch.bool, device=dev)
+        # stored clip-major: the backbone's '(b t)' flatten of the [T,B,...] samples is then a view, not an 88 MB copy per replay
+        import os
+        if os.environ.get("SOC_GROUP_SEQ_FIRST") == "1":
+            self.clip, self.pad = torch.zeros(T, n, 3, H, W, device=dev), torch.zeros(T, n, H, W, dtype=torch.bool, device=dev)
+        else:
+            self.clip = torch.zeros(n, T, 3, H, W, device=dev).transpose(0, 1)
+            self.pad = torch.zeros(n, T, H, W, dtype=torch.bool, device=dev).transpose(0, 1)
         self.ids = torch.ones(n, L, dtype=torch.long, device=dev)
         self.attn = torch.ones(n, L, dtype=torch.long, device=dev)
         self.targets = [[{"size": (H, W)}] for _ in range(T)]              # of ONE clip: the tail runs per clip

@@ -224,19 +224,22 @@ class SOC(nn.Module):
         return NestedTensor(words, attn.ne(1)), sentence
 
     # ------------------------------------------------------------------ forward
-    def _project_level(self, l: int, src, B: int, T: int):
+    def _project_level(self, l: int, src, B: int, T: int, clip_major: bool = False):
         """input_proj[l] = Conv2d(1x1) + GroupNorm(32) of a backbone level, returned as the '(t h w) b c'
         sequence the fusion consumes (reference models/soc.py:226-230).  The backbone's maps are
         channels-last in memory, so on the GPU the 1x1 convolution is a GEMM over tokens and the
-        GroupNorm runs on the token-major result (K10): no layout copy before or after."""
+        GroupNorm runs on the token-major result (K10): no layout copy before or after.
+        clip_major: return 'b (t h w) c' instead -- a view for any B (the fusion then runs batch-first)."""
         conv, gn = self.input_proj[l][0], self.input_proj[l][1]
         n, cin, h, w = src.shape
         tok = src.permute(0, 2, 3, 1)                              # a view of the backbone's native layout
         if not (src.is_cuda and tok.is_contiguous() and conv.kernel_size == (1, 1)):
-            return self._seq(self.input_proj[l](src), B, T)
+            return (self._seq_clip_major if clip_major else self._seq)(self.input_proj[l](src), B, T)
         y = fused.linear(tok.reshape(n, h * w, cin), conv.weight.view(conv.out_channels, cin), conv.bias)   # K13b / K20 / library
         y = hot_ops.groupnorm_tokens(y, gn.weight, gn.bias, gn.num_groups, gn.eps)    # '(b t) (h w) c'
         c = y.shape[-1]
+        if clip_major:
+            return y.view(B, T * h * w, c)
         return y.view(B, T, h * w, c).permute(1, 2, 0, 3).reshape(T * h * w, B, c)  # a view for B = 1
 
     @staticmethod
@@ -244,6 +247,12 @@ class SOC(nn.Module):
         """'(b t) c h w -> (t h w) b c'"""
         _, c, h, w = x.shape
         return x.view(B, T, c, h, w).permute(1, 3, 4, 0, 2).reshape(T * h * w, B, c)
+
+    @staticmethod
+    def _seq_clip_major(x, B, T):
+        """'(b t) c h w -> b (t h w) c'"""
+        _, c, h, w = x.shape
+        return x.permute(0, 2, 3, 1).reshape(B, T * h * w, c)
 
     @staticmethod
     def _tokens(x, B, T, h, w):
@@ -322,6 +331,12 @@ class SOC(nn.Module):
         B = words.shape[1]
         T = pos[-1].shape[0] // B
         text_pos = sa["text_pos"]
+        # A launch group (B > 1): '(t h w) b c' would be a real permute of every level (118 MB each way at level 0 for four
+        # clips); the fusion is a cross-attention per clip, so it runs batch-first on the 'b (t h w) c' view of the tokens.
+        clip_major = B > 1 and device.type == "cuda" and os.environ.get("SOC_GROUP_SEQ_FIRST") != "1"
+        if clip_major:
+            words, text_pos = words.transpose(0, 1).contiguous(), text_pos.transpose(0, 1).contiguous()
+        to_seq = self._seq_clip_major if clip_major else self._seq
 
         levels = list(zip(feats[-3:], fmasks[-3:], pos[-3:]))
         n_levels = self.num_feature_levels
@@ -334,18 +349,22 @@ class SOC(nn.Module):
             if l < len(levels):
                 src, mask, pos_l = levels[l]
                 h, w = src.shape[-2:]
-                seq = self._project_level(l, src, B, T)
+                seq = self._project_level(l, src, B, T, clip_major)
                 if l == len(levels) - 1:  # only langs[-1] is read downstream
                     lang = self.lvf(tgt=words, memory=seq,
                                     memory_key_padding_mask=mask.view(B, T, h, w).reshape(B, -1),
-                                    pos=self._seq(pos_l, B, T))
+                                    pos=to_seq(pos_l, B, T), batch_first=clip_major)
+                    if clip_major:
+                        lang = lang.transpose(0, 1).contiguous()         # [L,B,C] like the sequence-first path
             else:                          # the extra level: 3x3 / stride-2 conv of the coarsest backbone map
                 src = self.input_proj[l](feats[-1])
                 mask = resize_pad_mask(sa["sample_mask"], src.shape[-2:], unpadded)
                 pos_l = self.backbone.position_encoding(NestedTensor(src, mask), unpadded)
                 h, w = src.shape[-2:]
-                seq = self._seq(src, B, T)
-            fused = self.vlf(tgt=seq, memory=words, memory_key_padding_mask=word_pad, pos=text_pos)
+                seq = to_seq(src, B, T)
+            fused = self.vlf(tgt=seq, memory=words, memory_key_padding_mask=word_pad, pos=text_pos, batch_first=clip_major)
+            if clip_major:
+                return fused.reshape(B * T, h * w, fused.shape[-1]), mask, pos_l, lang
             return self._tokens(fused, B, T, h, w), mask, pos_l, lang
 
         # The levels are independent of each other.  The two finest ones (94 % of the tokens: chip-filling GEMMs) run on

@@ -14,7 +14,8 @@ class MMF(nn.Module):
         self.multihead_attn = HipMultiheadAttention(d_model, nhead, dropout)
 
     def forward(self, tgt: Tensor, memory: Tensor, memory_key_padding_mask: Optional[Tensor] = None,
-                pos: Optional[Tensor] = None, query_pos: Optional[Tensor] = None) -> Tensor:
+                pos: Optional[Tensor] = None, query_pos: Optional[Tensor] = None, batch_first: bool = False) -> Tensor:
+        # batch_first: tgt [B,Lq,C], memory / pos [B,Lk,C] (a launch group of clips: the tokens stay in their '(b t) (h w) c' storage)
         # `tgt *` is applied in the epilogue of the output projection where that is a K20 launch (pixel-sized tgt)
         return self.multihead_attn(tgt, memory, memory, memory_key_padding_mask, query_add=query_pos, key_add=pos,
-                                   out_mul=tgt)
+                                   out_mul=tgt, batch_first=batch_first)
