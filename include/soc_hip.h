@@ -313,11 +313,12 @@ int soc_mlp_split_variant_f32(const float* x, const void* packed, const float* b
  * :254-259 behind), the PatchMerging reduction into stage 2 (:277-312), value_proj / output_proj of MSDeformAttn
  * (models/ops/modules/ms_deform_attn.py:95,114), the query projection of the fusion blocks (models/vla.py:18-24) and
  * input_proj of level 1 (models/soc.py:226-230).  A wave keeps its 16 rows as split MFMA fragments (split once); the weights
- * stream through an LDS ring; a launch is cut into `nrg` workgroup rows x `ncr` column ranges (0, 0: the library plans it).
+ * stream through an LDS ring; a launch is cut into `nrg` workgroup rows x `ncr` column spans (0, 0: the library plans it).  A
+ * span is N / ncr <= 2048 columns, walked as ranges of 4 / 6 / 8 / 12 / 16 / 18 column tiles by waves that keep their split rows;
+ * every cut gives the same bits.  soc_xs_linear_plan returns the cut the library would take (nct = column tiles per span).
  *   x [M, K], w [N, K] (nn.Linear.weight layout), bias [N] or NULL, ln_gamma / ln_beta [K] or both NULL, residual [M, N] or
- *   NULL, out [M, N]; K in {192, 256, 384, 512, 768, 1024}, N % 32 == 0 and N / 16 divisible into ranges of 4 / 6 / 8 / 12 / 16 / 18
- *   (K = 1024: 4 / 6 / 8)
- *   column tiles (soc_xs_linear_plan says whether and how); every pointer 16-byte aligned.
+ *   NULL, out [M, N]; K in {192, 256, 384, 512, 768, 1024}, N % 32 == 0 and N / 16 / ncr divisible into ranges of 4 / 6 / 8 / 12 /
+ *   16 / 18 (K = 1024: 4 / 6 / 8) column tiles (soc_xs_linear_plan says whether and how); every pointer 16-byte aligned.
  *   soc_xs_linear_packed_bytes / soc_xs_linear_pack_f32: split and lay out the weights ONCE (opaque image); re-pack after a
  *   weight update.
  */

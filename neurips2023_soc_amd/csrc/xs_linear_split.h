@@ -14,7 +14,7 @@ struct Args {
     float eps;
     float* out;
     long M;
-    int N, nrg, ncr;
+    int N, nrg, ncr, rpw;       // ncr column spans of rpw ranges each
     hipStream_t st;
 };
 }  // namespace soc_xs
@@ -32,8 +32,9 @@ struct Geo {
     static constexpr int CTP = K <= 256 ? 2 : 1;                        // column tiles per ring piece
     static constexpr int GROUPS = CTP * KS / SB;                        // fragment groups (16 columns x 32 k, three planes) per piece
     static constexpr int PIECE_U4 = (GROUPS * 3 * 64 + MAX_THREADS - 1) / MAX_THREADS * MAX_THREADS;   // whole DMA rounds
-    static constexpr int NSLOT = (160 * 1024 - 8 * K - 2048) / (PIECE_U4 * 16) >= 4 ? 4 : 3;
-    static_assert(KS % SB == 0 && (160 * 1024 - 8 * K - 2048) / (PIECE_U4 * 16) >= 3, "three ring slots at least");
+    static constexpr int BIAS_BYTES = 8192;                             // the bias of a workgroup's column span: <= 2048 columns
+    static constexpr int NSLOT = (160 * 1024 - 8 * K - BIAS_BYTES) / (PIECE_U4 * 16) >= 4 ? 4 : 3;
+    static_assert(KS % SB == 0 && (160 * 1024 - 8 * K - BIAS_BYTES) / (PIECE_U4 * 16) >= 3, "three ring slots at least");
 };
 
 template <int N_>
@@ -52,12 +53,15 @@ __device__ unsigned long long* g_xs_dbg = nullptr;
 #define XS_STAMP(slot) do {} while (0)
 #endif
 
-// NCT column tiles per range (compile time: the accumulators are registers)
+// NCT column tiles per range (compile time: the accumulators are registers).  A workgroup owns a SPAN of `rpw` consecutive
+// ranges: its waves keep their split rows for the whole span and walk the ranges one after the other (round 5: with one range
+// per workgroup the row prologue -- loads, LayerNorm, split, ring fill, about ten column tiles' worth of time -- was paid per
+// 18 tiles at most; at the row counts of a launch group the chip fills without cutting N that finely).
 template <int K, int ACT, bool HAS_LN, int NCT>
 __global__ __launch_bounds__(Geo<K>::NW * 64, Geo<K>::NW / 4) void xs_linear_kernel(
     const float* __restrict__ x, const u32x4* __restrict__ img, const float* __restrict__ bias,
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps, const float* __restrict__ res,
-    float* __restrict__ out, long M, int N, int nrg, int ncr, int xcd_rows) {
+    float* __restrict__ out, long M, int N, int nrg, int ncr, int xcd_rows, int rpw) {
     using G = Geo<K>;
     constexpr int NW = G::NW, THREADS = NW * 64, KS = G::KS, SB = G::SB, CTP = G::CTP, NSLOT = G::NSLOT;
     constexpr int SLOT = G::PIECE_U4, P = SLOT / THREADS, D = NSLOT - 1, NQ = NCT * SB / CTP, KSP = KS / SB;
@@ -88,16 +92,17 @@ __global__ __launch_bounds__(Geo<K>::NW * 64, Geo<K>::NW / 4) void xs_linear_ker
         cr = blockIdx.x % ncr;
         g = blockIdx.x / ncr;
     }
-    const int n0 = cr * NCT * 16;                                       // first column of this range
+    const int n00 = cr * rpw * NCT * 16;                                // first column of this workgroup's span (ncr spans)
     const long ntiles = (M + 15) >> 4;
     const long t0 = (long)g * ntiles / nrg, t1 = (long)(g + 1) * ntiles / nrg;
     if (HAS_LN)
         for (int i = tid; i < K; i += THREADS) { gs[i] = gamma[i]; bs[i] = beta[i]; }
     // the bias of the column range waits in LDS: read from global memory in the epilogue it was a dependent load in front of
     // the stores of every wave (tools/experiments/k24_stamps.py)
-    for (int i = tid; i < NCT * 16; i += THREADS) bias_s[i] = bias ? bias[n0 + i] : 0.f;
+    for (int i = tid; i < rpw * NCT * 16; i += THREADS) bias_s[i] = bias ? bias[n00 + i] : 0.f;
     // LDS-DMA from inline assembly, as K23 (mlp_split.hip): the compiler must not see an LDS-DMA in flight
-    const char* ibase = reinterpret_cast<const char*>(img + (long)cr * NQ * SLOT);
+    const char* const ibase0 = reinterpret_cast<const char*>(img + (long)cr * rpw * NQ * SLOT);
+    const char* ibase = ibase0;                                         // the current range's pieces
     const unsigned voff = (unsigned)tid * 16u;
     const unsigned lds_slots = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)slots + (unsigned)wave * 1024u;
     auto dma = [&](int piece, int slot) {
@@ -113,6 +118,7 @@ __global__ __launch_bounds__(Geo<K>::NW * 64, Geo<K>::NW / 4) void xs_linear_ker
         constexpr bool ACTIVE = decltype(act_c)::value;                 // this wave has a row tile in the pass
         bf16x8 xb[KS][3];
         XS_STAMP(0);
+        ibase = ibase0;
         {
             float4 xn[KS][2];
             const long m = min((pt + wave) * 16 + r, M - 1);
@@ -165,11 +171,14 @@ __global__ __launch_bounds__(Geo<K>::NW * 64, Geo<K>::NW / 4) void xs_linear_ker
                 for (int s = 0; s < KS; ++s) split8(v[s], xb[s][0], xb[s][1], xb[s][2]);
             }
         }
+#pragma nounroll
+        for (int rg = 0; rg < rpw; ++rg) {
         f32x4 acc[NCT];
 #pragma unroll
         for (int j = 0; j < NCT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         XS_STAMP(2);
-        if (NQ >= D) handoff<(D - 1) * P>(); else handoff<0>();         // piece 0 has landed
+        // piece 0 has landed (a later range of the span: behind the previous range's stores, which share the counter)
+        if (NQ >= D && rg == 0) handoff<(D - 1) * P>(); else handoff<0>();
         XS_STAMP(3);
         // ---- the ring: piece q = column tiles [CTP (q / SB), + CTP) x k-steps [KSP (q % SB), + KSP); fully unrolled (the
         // accumulators are registers), fragment groups read one ahead of the MFMAs that consume them
@@ -201,14 +210,23 @@ __global__ __launch_bounds__(Geo<K>::NW * 64, Geo<K>::NW / 4) void xs_linear_ker
                 if (q + D < NQ) handoff<(D - 1) * P>(); else handoff<0>();
             }
         }
+        // ---- the next range of the span: its first pieces travel while this range's results leave
+        if (rg + 1 < rpw) {
+            handoff<0>();                           // every wave is done with the slots
+            ibase += (long)NQ * (SLOT * 16);
+#pragma unroll
+            for (int b = 0; b < D; ++b)
+                if (b < NQ) dma(b, b);
+        }
         // ---- lane (r, kq) holds out[m][n0 + 16 j + 4 kq .. + 3]: bias, activation, residual, 16-B stores
         XS_STAMP(4);
         const long m = (pt + wave) * 16 + r;
         if (ACTIVE && m < M) {
-            long mo = m * N + n0 + 4 * kq;
+            const int nr = rg * (NCT * 16);         // first column of the range within the span
+            long mo = m * N + n00 + nr + 4 * kq;
             asm volatile("" : "+v"(mo));
 #pragma unroll
-            for (int j = 0; j < NCT; ++j) acc[j] += *reinterpret_cast<const f32x4*>(bias_s + 16 * j + 4 * kq);
+            for (int j = 0; j < NCT; ++j) acc[j] += *reinterpret_cast<const f32x4*>(bias_s + nr + 16 * j + 4 * kq);
             if (ACT == 1) {
 #pragma unroll
                 for (int j = 0; j < NCT; ++j)
@@ -222,15 +240,23 @@ __global__ __launch_bounds__(Geo<K>::NW * 64, Geo<K>::NW / 4) void xs_linear_ker
                     for (int i = 0; i < 4; ++i) acc[j][i] = gelu_erf(acc[j][i], gk);
             }
             if (res) {
-                f32x4 rr[NCT];
+                // the split rows stay in registers for the next range of the span: at K = 384 (144 registers of fragments) the
+                // shortcut of a wide range is fetched in two or three rounds
+                constexpr int RC = (K == 384 && NCT > 12) ? (NCT % 3 == 0 ? NCT / 3 : NCT / 2) : NCT;
 #pragma unroll
-                for (int j = 0; j < NCT; ++j) rr[j] = *reinterpret_cast<const f32x4*>(res + mo + 16 * j);
+                for (int j0 = 0; j0 < NCT; j0 += RC) {
+                    f32x4 rr[RC];
 #pragma unroll
-                for (int j = 0; j < NCT; ++j) acc[j] += rr[j];
+                    for (int j = 0; j < RC; ++j) rr[j] = *reinterpret_cast<const f32x4*>(res + mo + 16 * (j0 + j));
+#pragma unroll
+                    for (int j = 0; j < RC; ++j) acc[j0 + j] += rr[j];
+                    if (RC < NCT) __builtin_amdgcn_sched_barrier(0);
+                }
             }
 #pragma unroll
             for (int j = 0; j < NCT; ++j) *reinterpret_cast<f32x4*>(out + mo + 16 * j) = acc[j];
         }
+        }   // ranges of the span
         XS_STAMP(5);
     };
     for (long pt = t0; pt < t1; pt += NW) {
@@ -292,7 +318,8 @@ template <int K, int ACT, bool HAS_LN, int NCT>
 int launch(const Args& a) {
     using G = Geo<K>;
     const void* fn = reinterpret_cast<const void*>(xs_linear_kernel<K, ACT, HAS_LN, NCT>);
-    const size_t lds = (size_t)G::NSLOT * G::PIECE_U4 * 16 + 8 * K + 64 * NCT;
+    if ((size_t)a.rpw * NCT * 64 > (size_t)G::BIAS_BYTES) return SOC_EUNSUPPORTED;
+    const size_t lds = (size_t)G::NSLOT * G::PIECE_U4 * 16 + 8 * K + (size_t)a.rpw * NCT * 64;
     static std::atomic<bool> attr_set[SOC_MAX_DEVICES];
     const int dev = soc_current_device();
     if (dev < 0) return SOC_ELAUNCH;
@@ -303,7 +330,7 @@ int launch(const Args& a) {
     const int xcd_rows = xcd_rows_pays(a.M, a.N, K, a.nrg, a.ncr);
     const int groups = xcd_rows ? (a.nrg + 7) / 8 * 8 : a.nrg;         // xcd_rows: whole groups of 8 row groups (one per XCD)
     hipLaunchKernelGGL((xs_linear_kernel<K, ACT, HAS_LN, NCT>), dim3((unsigned)(groups * a.ncr)), dim3(G::NW * 64), lds, a.st,
-                       a.x, a.img, a.bias, a.gamma, a.beta, a.eps, a.res, a.out, a.M, a.N, a.nrg, a.ncr, xcd_rows);
+                       a.x, a.img, a.bias, a.gamma, a.beta, a.eps, a.res, a.out, a.M, a.N, a.nrg, a.ncr, xcd_rows, a.rpw);
     return soc_check_launch();
 }
 

@@ -19,6 +19,7 @@
 // travels as two (four at K = 1024) partial-K pieces.
 // Co-residence rule as K23: whole register file, final barrier, VGPR operands in packed f32 code.
 #include "xs_linear_split.h"
+#include <cstdlib>
 
 namespace {
 
@@ -26,32 +27,55 @@ bool width_ok(int K) { return K == 192 || K == 256 || K == 384 || K == 512 || K 
 int waves_of(int K) { return K > 384 ? 4 : 8; }
 int ctp_of(int K) { return K <= 256 ? 2 : 1; }
 
-// The cut of M rows x N columns: nrg workgroup rows (NW row tiles per pass each) x ncr column ranges of one of the built
-// widths.  Cost model (tools/experiments/k24_time.py): a workgroup pass costs a fixed part (row loads, LayerNorm, split, ring
-// fill: about ten column tiles' worth of MFMA time -- tools/experiments/k24_main_tail.py: 38 560 x 256 x 256 takes 41 us as
-// (256, 1) and 48 us as (128, 2)) plus its column tiles; a launch costs the passes of its busiest
-// workgroup.  Fewest passes x (tiles + fixed) wins, ties go to the wider range (x is split once per range).
+// The cut of M rows x N columns: nrg workgroup rows (NW row tiles per pass each) x ncr column SPANS; a span is rpw ranges of
+// one of the built widths, walked one after the other by waves that keep their split rows.  Cost model
+// (tools/experiments/k24_time.py): a workgroup pass costs a fixed part (row loads, LayerNorm, split, ring fill: about ten
+// column tiles' worth of MFMA time -- tools/experiments/k24_main_tail.py: 38 560 x 256 x 256 takes 41 us as (256, 1) and 48 us
+// as (128, 2)) plus its column tiles, plus two tiles' worth per further range of the span (the ring drains and refills behind
+// the stores); a launch costs the passes of its busiest workgroup.  Fewest passes x (tiles + fixed) wins, ties go to the
+// wider range and the longer span (x is split once per span).
+constexpr int SPAN_MAX_COLUMNS = 2048;          // Geo<K>::BIAS_BYTES / 4: the span's bias waits in LDS
+
+// widest built range that divides a span of `tiles` column tiles (0: none)
+int range_of(int K, int tiles) {
+    for (int nct : NCTS)
+        if (tiles % nct == 0 && nct % ctp_of(K) == 0 && nct <= max_nct(K)) return nct;
+    return 0;
+}
+
+// diagnostic switch SOC_K24_SPANS=0: one range per workgroup, the cut of round 4 (read once)
+bool spans_enabled() {
+    static const bool on = [] { const char* e = std::getenv("SOC_K24_SPANS"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 bool plan(long M, int N, int K, int cus, int* nrg_out, int* ncr_out, int* nct_out) {
     const long ntiles = (M + 15) >> 4;
     const int nw = waves_of(K), nct_all = N / 16;
     const long groups = (ntiles + nw - 1) / nw;
-    int best_nct = 0;
+    int best_span = 0;
     long best_cost = 0, best_nrg = 0;
     for (int nct : NCTS) {
         if (nct_all % nct != 0 || nct % ctp_of(K) != 0 || nct > max_nct(K)) continue;
-        const long ncr = nct_all / nct;
-        long nrg = cus / ncr > 0 ? cus / ncr : 1;
-        if (nrg > groups) nrg = groups;
-        const long tiles_per_wg = (ntiles + nrg - 1) / nrg;
-        const long passes = (tiles_per_wg + nw - 1) / nw;
-        const long rounds = (nrg * ncr + cus - 1) / cus;
-        const long cost = passes * rounds * (nct + 10);
-        if (best_nct == 0 || cost < best_cost) { best_nct = nct; best_cost = cost; best_nrg = nrg; }
+        const int ranges = nct_all / nct;
+        for (int rpw = 1; rpw <= (spans_enabled() ? ranges : 1); ++rpw) {
+            if (ranges % rpw != 0 || rpw * nct * 16 > SPAN_MAX_COLUMNS || (rpw > 1 && range_of(K, rpw * nct) != nct)) continue;
+            const long ncr = ranges / rpw;
+            long nrg = cus / ncr > 0 ? cus / ncr : 1;
+            if (nrg > groups) nrg = groups;
+            const long tiles_per_wg = (ntiles + nrg - 1) / nrg;
+            const long passes = (tiles_per_wg + nw - 1) / nw;
+            const long rounds = (nrg * ncr + cus - 1) / cus;
+            const long cost = passes * rounds * (rpw * nct + 10 + 2 * (rpw - 1));
+            if (best_span == 0 || cost < best_cost || (cost == best_cost && rpw * nct > best_span)) {
+                best_span = rpw * nct; best_cost = cost; best_nrg = nrg;
+            }
+        }
     }
-    if (best_nct == 0) return false;
+    if (best_span == 0) return false;
     *nrg_out = (int)best_nrg;
-    *ncr_out = nct_all / best_nct;
-    *nct_out = best_nct;
+    *ncr_out = nct_all / best_span;
+    *nct_out = best_span;
     return true;
 }
 
@@ -105,17 +129,18 @@ extern "C" int soc_xs_linear_f32(const float* x, const void* packed, const float
     if ((((uintptr_t)x | (uintptr_t)packed | (uintptr_t)bias | (uintptr_t)residual | (uintptr_t)out | (uintptr_t)ln_gamma |
           (uintptr_t)ln_beta) & 15) != 0)
         return SOC_EUNSUPPORTED;
-    int nct = 0;
+    int span = 0;               // column tiles per workgroup: rpw ranges of nct tiles
     if (nrg <= 0 || ncr <= 0) {
-        if (!plan(M, N, K, num_cus((hipStream_t)stream), &nrg, &ncr, &nct)) return SOC_EUNSUPPORTED;
+        if (!plan(M, N, K, num_cus((hipStream_t)stream), &nrg, &ncr, &span)) return SOC_EUNSUPPORTED;
     } else {
         if ((N / 16) % ncr != 0) return SOC_EINVAL;
-        nct = N / 16 / ncr;
+        span = N / 16 / ncr;
     }
-    if (nrg > (M + 15) / 16 || nct % ctp_of(K) != 0) return SOC_EINVAL;
-    if (nct > max_nct(K)) return SOC_EUNSUPPORTED;
+    if (nrg > (M + 15) / 16 || span % ctp_of(K) != 0) return SOC_EINVAL;
+    const int nct = range_of(K, span);
+    if (nct == 0 || span * 16 > SPAN_MAX_COLUMNS) return SOC_EUNSUPPORTED;
     Args a{x, bias, ln_gamma, ln_beta, residual, reinterpret_cast<const u32x4*>(packed), ln_eps, out, M, N, nrg, ncr,
-           (hipStream_t)stream};
+           span / nct, (hipStream_t)stream};
     switch (K) {
         case 192: return launch_k<192>(a, act, nct);
         case 256: return launch_k<256>(a, act, nct);

@@ -27,6 +27,7 @@ SWITCHES = {
     "SOC_TAIL_NO_FORK": "1: the tail never forks FPN || query chain, not even in the drain graph",
     "SOC_TAIL_PRIORITY": "0: the tail branch of the one-graph pipeline is captured at default stream priority (default: high)",
     "SOC_GROUP_SEQ_FIRST": "1: a launch group keeps the reference's '(t h w) b c' / [T,B,...] layouts (a permute copy of every level each way)",
+    "SOC_K24_SPANS": "0: K24 plans one column range per workgroup (the cut of round 4) instead of spans of ranges",
     "SOC_MATMUL": "split | f32: arithmetic a model is built with (hot_ops.DEFAULT_MATMUL_MODE; SOC.matmul_mode overrides per model)",
     "SOC_SPLIT_OFF": "comma list of call sites / kernels forced back to the f32 path (k1, k13, k24, mlp, swin, gelu, ...)",
     "SOC_PNG": "pillow: the drivers write PNGs through Pillow instead of libsoc_host.so (SOC_PNG_LEVEL: its compress_level)",

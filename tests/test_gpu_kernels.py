@@ -1331,6 +1331,8 @@ def test_mlp_split_emits_sum_and_next_layernorm(ops, M, Cw, F):
     (1920, 1024, 1024, "none", False, True),    # ... proj + shortcut
     (1920, 4096, 1024, "gelu", True, False),    # ... norm2 + fc1 + GELU
     (7360, 512, 1024, "none", True, False),     # Swin-B patch merging into stage 2
+    (29440, 1152, 384, "none", True, False),    # stage-2 qkv of a four-clip launch group: one column span of 72 tiles per workgroup
+    (7680, 3072, 768, "gelu", True, False),     # stage-3 fc1 of a group: two spans of 96 tiles (six ranges of 16)
     (50, 96, 1024, "relu", False, True),
     (33, 64, 192, "relu", False, True), (4099, 1152, 384, "gelu", True, True), (17, 576, 256, "none", True, False)])
 def test_xs_linear_vs_f64(ops, M, N, K, act, ln, res):
@@ -1360,7 +1362,11 @@ def test_xs_linear_vs_f64(ops, M, N, K, act, ln, res):
     print(f"K24 {M}x{N}x{K} {act}: split {e_k / scale:.2e}  library f32 {e_lib / scale:.2e}  plan {ops.xs_linear_plan(M, N, K)}")
     assert e_k < 1e-5 * scale and e_k <= 1.5 * e_lib + 3e-7 * scale, (e_k, e_lib)
     nrg, ncr, nct = ops.xs_linear_plan(M, N, K)
-    for cut in {(max(1, nrg // 2), ncr), (min((M + 15) // 16, nrg + 3), ncr)}:
+    cuts = {(max(1, nrg // 2), ncr), (min((M + 15) // 16, nrg + 3), ncr)}
+    # column spans (round 5): a workgroup walks N / 16 / ncr column tiles as ranges of a built width, rows split once
+    cuts |= {(nrg, c) for c in (1, 2, 3, 4, 6) if (N // 16) % c == 0 and N // c <= 2048
+             and any((N // 16 // c) % t == 0 for t in ((4, 6, 8) if K > 768 else (4, 6, 8, 12, 16, 18)) if t % (2 if K <= 256 else 1) == 0)}
+    for cut in cuts:
         assert torch.equal(got, ops.xs_linear(x, w, b, lnp, r, act, cut=cut)), cut
     w.mul_(0.5)
     assert float((ops.xs_linear(x, w, b, lnp, r, act).double() - ref(torch.float64)).abs().max()) < 1e-5 * scale

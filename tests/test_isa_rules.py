@@ -131,13 +131,14 @@ def test_the_waves_retire_behind_a_barrier(unit):
 def test_no_scratch_inside_the_mfma_stream(unit):
     """A spilled register is re-loaded through the vector-memory counter the LDS-DMA ring is paced by (K23 / K24: a scratch load
     in the block loop would wait for every piece in flight).  A slot used in the row prologue only (K24 at K = 384 with a
-    LayerNorm in front: 12 bytes, stored and re-loaded before the first MFMA) is tolerated; nothing between the first and the
-    last MFMA of a kernel may touch scratch."""
+    LayerNorm in front: 12 bytes, stored and re-loaded before the first MFMA; since the column-span loop of round 5 keeps the
+    split rows alive across the epilogue, up to 16 dwords of loop invariants at K = 256 / 384) is tolerated; nothing from the
+    first MFMA of a kernel on -- the ring, the epilogue of a range, the way back into the span loop -- may touch scratch."""
     src, kernels, meta = unit
     for name, body in kernels.items():
-        ms = [m.start() for m in BF16_MFMA_ISA.finditer(body)]
-        assert "scratch_" not in body[ms[0]:ms[-1]], (src, name)
-        assert meta[name]["private_segment_fixed_size"] <= 16, (src, name, meta[name])
+        first = BF16_MFMA_ISA.search(body).start()
+        assert "scratch_" not in body[first:], (src, name)
+        assert meta[name]["private_segment_fixed_size"] <= 64, (src, name, meta[name])
 
 
 def test_k23_k24_ring_discipline(unit):
