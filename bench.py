@@ -10,7 +10,7 @@ clip_parallel.spawn_ranks = the reference's mp.Process fan-out, infer_refytb.py:
 A step = one eval forward of Video-Swin-T SOC on one synthetic clip [T=8,3,360,640] (random
 deterministic weights, pre-tokenised 10-token expression) + query selection, i.e. the body of
 the reference's inference loop (infer_refytb.py:206-227).  Since round 5 four independent clips share each launch of the
-forward (graph_runner.QuadPipelinedClipGraph); the VOC module -- the one place where the reference's forward couples the clips
+forward (graph_runner.QuadPipelinedClipGraph; eight when --steps is a multiple of eight); the VOC module -- the one place where the reference's forward couples the clips
 of a batch -- runs per clip, so every clip gets its single-clip (B = 1) result; `single_clip_ms_per_step` is the
 one-clip-per-launch pipeline of rounds 1-4 beside it.  Inputs are resident in HBM before the
 timed region.  Clips shard over ranks (weak scaling: K clips per rank, no data-path collective);
@@ -58,12 +58,13 @@ def parse():
     ap.add_argument("--eager", action="store_true", help="time eager launches instead of hipGraph replay")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="one clip per graph replay (ClipGraph) instead of the software-pipelined PipelinedClipGraph")
-    ap.add_argument("--pipeline", choices=["two-stream", "one-graph", "pairs", "quads"], default=None,
-                    help="software pipeline across clips: quads (default up to 360x640: four independent clips per launch group, "
-                         "VOC over independent clips: graph_runner.QuadPipelinedClipGraph), pairs (two; default above 360x640, where "
-                         "a clip nearly fills the chip by itself -- Swin-B 720p: 42.1 ms per clip in pairs, 42.6 alone, 49.2 in "
-                         "fours), one-graph (one clip per launch: rounds 1-4, PipelinedClipGraph; always timed beside the headline "
-                         "as single_clip_ms_per_step), two-stream")
+    ap.add_argument("--pipeline", default=None,
+                    type=lambda v: v if v in ("two-stream", "one-graph", "pairs", "quads", "octs") or (v.startswith("group") and v[5:].isdigit())
+                    else (_ for _ in ()).throw(argparse.ArgumentTypeError("two-stream | one-graph | pairs | quads | octs | group<N>")),
+                    help="software pipeline across clips (default: default_pipeline()): group<N> / octs / quads / pairs = N / 8 / 4 / 2 "
+                         "independent clips per launch group, VOC over independent clips (graph_runner.group_pipeline_class); "
+                         "one-graph = one clip per launch (rounds 1-4, PipelinedClipGraph; always timed beside the headline as "
+                         "single_clip_ms_per_step); two-stream")
     ap.add_argument("--no-stream", action="store_true",
                     help="skip the second, H2D-inclusive timed pass (stream_ms_per_step)")
     ap.add_argument("--stub", action="store_true",
@@ -157,6 +158,20 @@ def headline(a, world, timed, workload, launch):
 
 _ROOFLINE_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "frac_of_ceiling", "traffic", "launches", "clips_per_replay",
                   "algorithmic_flop_per_clip", "algorithmic_bytes_per_clip", "avg_launch_us", "ms_per_clip", "source")
+
+
+def default_pipeline(steps: int, frames: int, height: int, width: int) -> str:
+    """The pipeline bench.py times when --pipeline is not given.  Up to 360x640 several independent clips share every launch
+    (graph_runner.group_pipeline_class): per clip 5.13 ms in fours, 4.81-4.84 in eights / tens / twelves, 4.89 in sixteens (same
+    box, Swin-T) -- and a part-filled group costs a whole replay, so the group is the first of 8, 10, 12, 9, 6, 7, 5, 4 that
+    divides the clip count (20 clips: two groups of ten), fours otherwise.  Above 360x640 a clip nearly fills the chip by itself:
+    pairs (Swin-B 720p: 42.1 ms per clip in pairs, 42.6 alone, 49.2 in fours)."""
+    if frames * height * width > 8 * 360 * 640:
+        return "pairs"
+    for g in (8, 10, 12, 9, 6, 7, 5, 4):
+        if steps % g == 0:
+            return {8: "octs", 4: "quads"}.get(g, f"group{g}")
+    return "quads" if steps > 3 else ("pairs" if steps == 2 else "one-graph" if steps == 1 else "group3")
 
 
 def compact_line(full):
@@ -255,7 +270,7 @@ def stub_main(a, CP):
 def main():
     a = parse()
     if a.pipeline is None:
-        a.pipeline = "quads" if a.frames * a.height * a.width <= 8 * 360 * 640 else "pairs"
+        a.pipeline = default_pipeline(a.steps, a.frames, a.height, a.width)
     from neurips2023_soc_amd import clip_parallel as CP
     CP.rank_environment()           # before anything touches the GPU: the same process environment in both launch modes
     if a.gpus > 1 and not CP.launched_as_rank():
@@ -312,7 +327,6 @@ def main():
         if records is not None:
             records[i0:i0 + count].copy_(group_records[:count])
 
-    group_records = torch.zeros(8, results.shape[1], device=dev)      # scratch of the eager group step
     graph = None
     pipelined = False
     if not a.eager:
@@ -328,6 +342,7 @@ def main():
     per = getattr(graph, "CLIPS", 1) if graph is not None else (
         1 if a.no_pipeline else __import__("neurips2023_soc_amd.graph_runner", fromlist=["x"]).pipeline_class(a.pipeline).CLIPS)
     clips_per_group = per
+    group_records = torch.zeros(max(per, 1), results.shape[1], device=dev)      # scratch of the eager group step
 
     def run_steps(n, out, feed=None):
         """n clips through the chosen path, results into out[i % len(out)].  `feed` = (feeder, host clips): every clip

@@ -139,6 +139,10 @@ __global__ __launch_bounds__(Geo<K>::NW * 64, Geo<K>::NW / 4) void xs_linear_ker
                     v[s][4] = xn[s][1].x; v[s][5] = xn[s][1].y; v[s][6] = xn[s][1].z; v[s][7] = xn[s][1].w;
                 }
                 if (HAS_LN) {   // as nn.LayerNorm: two-pass mean / variance over the row, which lives in lanes (r, kq = 0..3)
+                    // every rounding below is written out: left to contract on its own, the compiler rounded 0.07 % of the
+                    // normalised values one ulp apart between two instantiations (tools/experiments/k24_dbg.py), and a cut
+                    // must not change the bits
+#pragma clang fp contract(off)
                     const float inv_k = in_vgpr(1.0f / K), eps_v = in_vgpr(eps);
                     float sm = 0.f;
 #pragma unroll
@@ -168,7 +172,17 @@ __global__ __launch_bounds__(Geo<K>::NW * 64, Geo<K>::NW / 4) void xs_linear_ker
                     }
                 }
 #pragma unroll
-                for (int s = 0; s < KS; ++s) split8(v[s], xb[s][0], xb[s][1], xb[s][2]);
+                for (int s = 0; s < KS; ++s) {
+                    split8(v[s], xb[s][0], xb[s][1], xb[s][2]);
+                    // four 512-register waves: half of the file is accumulation registers, which the matrix cores read as
+                    // well as the others.  The first fragments go there as they are made (the row's f32 values still hold 192
+                    // of the 256 others at that point); left to itself the allocator spilled six fragments here and re-loaded
+                    // them at the top of every range of the span.
+#ifndef SOC_K24_NO_PIN          // diagnostic build: tools/experiments/k24_dbg.py
+                    if (NW == 4 && s < (256 - 4 * NCT - 4) / 12)
+                        asm volatile("" : "+a"(xb[s][0]), "+a"(xb[s][1]), "+a"(xb[s][2]));
+#endif
+                }
             }
         }
 #pragma nounroll
@@ -225,36 +239,39 @@ __global__ __launch_bounds__(Geo<K>::NW * 64, Geo<K>::NW / 4) void xs_linear_ker
             const int nr = rg * (NCT * 16);         // first column of the range within the span
             long mo = m * N + n00 + nr + 4 * kq;
             asm volatile("" : "+v"(mo));
+            // The split rows stay in registers for the next range of the span, so the epilogue has what the fragments leave: at
+            // K = 384 (144 of 256 registers) and K >= 768 (288 / 384 of 512) the range leaves in rounds of EC column tiles --
+            // bias, activation, shortcut, stores of one round before the next (all 18 tiles at once: the compiler kept 72
+            // registers each of bias, shortcut and accumulator copies and spilled 100 registers of fragments, re-loaded through
+            // the vector-memory counter at the top of every range).
+            constexpr int EC = K > 768 ? NCT / 2 : ((K == 384 || K == 768) && NCT > 12) ? (NCT % 3 == 0 ? NCT / 3 : NCT / 2) : NCT;
+            const GeluK gk = gelu_k();
 #pragma unroll
-            for (int j = 0; j < NCT; ++j) acc[j] += *reinterpret_cast<const f32x4*>(bias_s + nr + 16 * j + 4 * kq);
-            if (ACT == 1) {
+            for (int j0 = 0; j0 < NCT; j0 += EC) {
 #pragma unroll
-                for (int j = 0; j < NCT; ++j)
+                for (int j = j0; j < j0 + EC; ++j) acc[j] += *reinterpret_cast<const f32x4*>(bias_s + nr + 16 * j + 4 * kq);
+                if (ACT == 1) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[j][i] = fmaxf(acc[j][i], 0.f);
-            } else if (ACT == 2) {
-                const GeluK gk = gelu_k();
+                    for (int j = j0; j < j0 + EC; ++j)
 #pragma unroll
-                for (int j = 0; j < NCT; ++j)
+                        for (int i = 0; i < 4; ++i) acc[j][i] = fmaxf(acc[j][i], 0.f);
+                } else if (ACT == 2) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[j][i] = gelu_erf(acc[j][i], gk);
-            }
-            if (res) {
-                // the split rows stay in registers for the next range of the span: at K = 384 (144 registers of fragments) the
-                // shortcut of a wide range is fetched in two or three rounds
-                constexpr int RC = (K == 384 && NCT > 12) ? (NCT % 3 == 0 ? NCT / 3 : NCT / 2) : NCT;
+                    for (int j = j0; j < j0 + EC; ++j)
 #pragma unroll
-                for (int j0 = 0; j0 < NCT; j0 += RC) {
-                    f32x4 rr[RC];
-#pragma unroll
-                    for (int j = 0; j < RC; ++j) rr[j] = *reinterpret_cast<const f32x4*>(res + mo + 16 * (j0 + j));
-#pragma unroll
-                    for (int j = 0; j < RC; ++j) acc[j0 + j] += rr[j];
-                    if (RC < NCT) __builtin_amdgcn_sched_barrier(0);
+                        for (int i = 0; i < 4; ++i) acc[j][i] = gelu_erf(acc[j][i], gk);
                 }
-            }
+                if (res) {
+                    f32x4 rr[EC];
 #pragma unroll
-            for (int j = 0; j < NCT; ++j) *reinterpret_cast<f32x4*>(out + mo + 16 * j) = acc[j];
+                    for (int j = 0; j < EC; ++j) rr[j] = *reinterpret_cast<const f32x4*>(res + mo + 16 * (j0 + j));
+#pragma unroll
+                    for (int j = 0; j < EC; ++j) acc[j0 + j] += rr[j];
+                }
+#pragma unroll
+                for (int j = j0; j < j0 + EC; ++j) *reinterpret_cast<f32x4*>(out + mo + 16 * j) = acc[j];
+                if (EC < NCT) __builtin_amdgcn_sched_barrier(0);
+            }
         }
         }   // ranges of the span
         XS_STAMP(5);

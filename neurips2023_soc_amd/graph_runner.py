@@ -592,8 +592,25 @@ class QuadPipelinedClipGraph(PairPipelinedClipGraph):
     CLIPS = 4
 
 
+class OctPipelinedClipGraph(PairPipelinedClipGraph):
+    """Eight clips per launch group: what bench.py times up to 360x640.  Same box, bench.py, 48-64 steps: Swin-T 4.84-4.85 ms per
+    clip against 5.02 for fours; Swin-B 360p 10.25-10.27 against 10.50-10.55 (every clip still within 5e-5 of its single-clip
+    logits, no flips).  A result arrives one replay (~40 ms) behind its group."""
+    CLIPS = 8
+
+
 PIPELINES = {"two-stream": TwoStreamClipGraph, "one-graph": PipelinedClipGraph, "pairs": PairPipelinedClipGraph,
-             "quads": QuadPipelinedClipGraph}
+             "quads": QuadPipelinedClipGraph, "octs": OctPipelinedClipGraph}
+
+
+def group_pipeline_class(clips: int):
+    """The launch-group pipeline for `clips` clips per replay (any count >= 2; 2 / 4 / 8 are the named classes)."""
+    named = {c.CLIPS: c for c in (PairPipelinedClipGraph, QuadPipelinedClipGraph, OctPipelinedClipGraph)}
+    if clips in named:
+        return named[clips]
+    if clips < 2:
+        raise ValueError("a launch group has at least two clips")
+    return type(f"Group{clips}PipelinedClipGraph", (PairPipelinedClipGraph,), {"CLIPS": int(clips)})
 
 
 def pipeline_class(name: Optional[str] = None):
@@ -602,4 +619,7 @@ def pipeline_class(name: Optional[str] = None):
     one process: 6.44-6.51 ms both; bench.py on one of three boxes: two-stream 0.2 ms slower); the two-stream form needs
     0.25 ms of host time per clip for its four single-branch launches where the one multi-branch launch blocks 1.2-4.8 ms."""
     import os
-    return PIPELINES[name or os.environ.get("SOC_PIPELINE", "one-graph")]
+    name = name or os.environ.get("SOC_PIPELINE", "one-graph")
+    if name.startswith("group") and name[5:].isdigit():          # "group10": ten clips per launch group
+        return group_pipeline_class(int(name[5:]))
+    return PIPELINES[name]

@@ -40,11 +40,11 @@ class ClipInferencer:
         oracle), which is what tokenizer(..., padding="longest") does to the shorter expressions of a batch."""
         self.model, self.device = model, torch.device(device)
         self.use_graphs, self.max_graphs, self.pad_tokens_to = use_graphs, max_graphs, pad_tokens_to
-        # group > 1 (2 or 4): the streaming form shares every launch between `group` consecutive clips of one geometry
+        # group > 1: the streaming form shares every launch between `group` consecutive clips of one geometry
         # (graph_runner.PairPipelinedClipGraph / QuadPipelinedClipGraph: each clip still gets its single-clip result); a
         # part-filled group -- geometry change, end of the stream -- runs with stale partner slots
-        if group not in (1, 2, 4):
-            raise ValueError("group must be 1, 2 or 4")
+        if int(group) != group or group < 1:
+            raise ValueError("group must be a positive clip count")
         self.group = group
         self._filling = []           # (tag, original_size) of the clips staged into the group that has not been replayed yet
         self._graphs: Dict[Tuple[int, int, int, int], ClipGraph] = {}
@@ -85,8 +85,8 @@ class ClipInferencer:
             while len(self._pipes) >= self.max_graphs:
                 torch.cuda.synchronize(self.device)
                 self._pipes.pop(next(iter(self._pipes)))
-            from .graph_runner import PairPipelinedClipGraph, QuadPipelinedClipGraph
-            cls = {1: pipeline_class(), 2: PairPipelinedClipGraph, 4: QuadPipelinedClipGraph}[self.group]
+            from .graph_runner import group_pipeline_class
+            cls = pipeline_class() if self.group == 1 else group_pipeline_class(self.group)
             self._pipes[key] = cls(self.model, *key, self.device)
         return self._pipes[key]
 
@@ -259,7 +259,7 @@ def parse_args(argv=None):
     ap.add_argument("--make-synthetic", type=int, default=0, metavar="N",
                     help="first write an N-video synthetic dataset (720x1280 JPEGs) under --root")
     ap.add_argument("--graphs", action="store_true", help="hipGraph replay per clip geometry in the dataset drivers")
-    ap.add_argument("--group", type=int, default=1, choices=[1, 2, 4],
+    ap.add_argument("--group", type=int, default=1,
                     help="--graphs: consecutive clips of one geometry per launch group (each gets its single-clip result); "
                          "pays where many clips share a geometry (DAVIS chunks, several expressions per video)")
     ap.add_argument("--words", type=int, default=0, help="--make-synthetic: fixed number of words per expression")

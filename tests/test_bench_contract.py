@@ -114,3 +114,16 @@ def test_committed_bench_line_keeps_the_driver_contract():
     assert line["n_gpus"] == 1
     assert line["stream_ms_per_step"] > 0 and line["f32_mfma_only_ms_per_step"] > line["ms_per_step"]
     assert line["detail"].endswith(".json")
+
+
+def test_default_pipeline_takes_the_largest_group_that_divides_the_clip_count():
+    """bench.default_pipeline: a part-filled launch group costs a whole replay, so the group size divides --steps (the driver's
+    20 clips: two groups of ten); above 360x640 pairs."""
+    import bench
+    assert bench.default_pipeline(20, 8, 360, 640) == "group10"
+    assert bench.default_pipeline(200, 8, 360, 640) == "octs" and bench.default_pipeline(12, 8, 360, 640) == "group12"
+    assert bench.default_pipeline(13, 8, 360, 640) == "quads" and bench.default_pipeline(1, 8, 360, 640) == "one-graph"
+    assert bench.default_pipeline(20, 8, 720, 1280) == "pairs"
+    from neurips2023_soc_amd import graph_runner
+    for name, clips in (("group10", 10), ("octs", 8), ("quads", 4), ("pairs", 2), ("group3", 3), ("one-graph", 1)):
+        assert graph_runner.pipeline_class(name).CLIPS == clips

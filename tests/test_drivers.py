@@ -64,7 +64,7 @@ def gpu_model():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("use_graphs", [False, True, 4, 2])
+@pytest.mark.parametrize("use_graphs", [False, True, 4, 2, 8])
 def test_refytb_driver_matches_reference_recipe(gpu_model, tmp_path, use_graphs):
     """use_graphs=True: the driver streams through the software-pipelined hipGraph (results one clip late, drained
     at the end) -- the same PNGs must come out.  4 / 2: through the group pipelines (four / two clips per launch group: the four

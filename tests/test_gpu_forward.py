@@ -402,14 +402,14 @@ def test_pipelined_graph_full_config_matches_reference(gpu_model, golden, pipeli
         assert maxdiff(other, recs[order.index(seed)].cpu()) > 1e-2       # a different clip gave a different record
 
 
-@pytest.mark.parametrize("group", [4, 2])
+@pytest.mark.parametrize("group", [4, 2, 8])
 def test_group_pipeline_gives_every_clip_its_single_clip_result(gpu_model, golden, group):
-    """QuadPipelinedClipGraph (what bench.py times) / PairPipelinedClipGraph: four / two independent clips per launch group, the
+    """QuadPipelinedClipGraph / OctPipelinedClipGraph (what bench.py times) / PairPipelinedClipGraph: four / eight / two independent clips per launch group, the
     VOC module per clip.  Every clip's record equals the one-clip ClipGraph's to f32 rounding -- whichever slot it sits in, whoever
     its partners are, with a part-filled last group -- and the golden clip meets the reference's output.  (The reference's own
     B = 2 forward does NOT give a clip its B = 1 result: its VOC couples the batch.)"""
     from neurips2023_soc_amd import clip_parallel as CP
-    from neurips2023_soc_amd.graph_runner import ClipGraph, PairPipelinedClipGraph, QuadPipelinedClipGraph
+    from neurips2023_soc_amd.graph_runner import ClipGraph, OctPipelinedClipGraph, PairPipelinedClipGraph, QuadPipelinedClipGraph
     g = golden("full_forward.npz")
     seed, T, H, Wd, L = (int(v) for v in g["cfg"])
     hm, wm = -(-H // 4), -(-Wd // 4)
@@ -420,7 +420,7 @@ def test_group_pipeline_gives_every_clip_its_single_clip_result(gpu_model, golde
     for c, t_ in zip(clips, ids):
         plain.run(c, t_)
         want.append(plain.record.clone())
-    pipe = {2: PairPipelinedClipGraph, 4: QuadPipelinedClipGraph}[group](gpu_model, T, H, Wd, L, "cuda")
+    pipe = {2: PairPipelinedClipGraph, 4: QuadPipelinedClipGraph, 8: OctPipelinedClipGraph}[group](gpu_model, T, H, Wd, L, "cuda")
     assert pipe.CLIPS == group and pipe.flush() == []
 
     def through(order):

@@ -174,7 +174,7 @@ def test_derived_cache_keys_on_the_tensors_and_dies_with_them():
 
 
 def test_clip_inferencer_group_bookkeeping_with_a_stub_pipeline(monkeypatch):
-    """ClipInferencer.submit / drain with launch groups (group = 1 / 2 / 4), on CPU with a stub pipeline: every clip's result
+    """ClipInferencer.submit / drain with launch groups (group = 1 / 2 / 4 / 8), on CPU with a stub pipeline: every clip's result
     comes back exactly once, under its own tag and original size, in submission order, one replay late; a geometry change and
     the end of the stream drain a part-filled group; group = 1 keeps the one-clip behaviour."""
     import torch
@@ -210,7 +210,7 @@ def test_clip_inferencer_group_bookkeeping_with_a_stub_pipeline(monkeypatch):
     class Model:
         num_queries = 1
 
-    for group in (1, 2, 4):
+    for group in (1, 2, 3, 4, 8, 10):
         eng = infer.ClipInferencer(Model(), "cpu", use_graphs=True, group=group)
         made = []
 
@@ -235,4 +235,4 @@ def test_clip_inferencer_group_bookkeeping_with_a_stub_pipeline(monkeypatch):
         assert len(made) == 2 and eng.drain() == []
     import pytest
     with pytest.raises(ValueError):
-        infer.ClipInferencer(Model(), "cpu", group=3)
+        infer.ClipInferencer(Model(), "cpu", group=0)

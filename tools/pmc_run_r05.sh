@@ -5,7 +5,7 @@
 set -x
 cd "$GRAFT_REPO_ROOT"
 export TMPDIR=/tmp
-GROUP=4                                 # bench.py's default pipeline runs four clips per launch group: the trace / PMC tools count per group
+GROUP=10                                # bench.py's default at the driver's 20 clips: two launch groups of ten (default_pipeline()); the trace / PMC tools count per group
 export SOC_TRACE_CLIPS_PER_GROUP=$GROUP
 P=gpurun_out/r05
 mkdir -p $P
@@ -14,9 +14,9 @@ for part in $PARTS; do
 case $part in
 trace)
   # ---- (a) the headline command, plain and under the kernel tracer
-  python3 bench.py --detail $P/bench_r05_n1_detail.json > $P/bench_r05_n1.json 2> $P/bench_r05_n1.err
-  python3 bench.py --steps 200 --warmup 5 --no-cpu-baseline --no-stream --no-f32-pass --detail $P/bench_r05_n1_200steps_detail.json > $P/bench_r05_n1_200steps.json 2> /dev/null
-  rocprofv3 --kernel-trace --stats --output-format csv -d $P/trace -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --detail $P/trace_bench_detail.json > $P/trace_bench.json 2> $P/trace_bench.err
+  python3 bench.py --steps 20 --warmup 5 --detail $P/bench_r05_n1_detail.json > $P/bench_r05_n1.json 2> $P/bench_r05_n1.err
+  python3 bench.py --steps 200 --warmup 8 --no-cpu-baseline --no-stream --no-f32-pass --detail $P/bench_r05_n1_200steps_detail.json > $P/bench_r05_n1_200steps.json 2> /dev/null
+  rocprofv3 --kernel-trace --stats --output-format csv -d $P/trace -- python3 bench.py --steps 60 --warmup 10 --pipeline group$GROUP --no-cpu-baseline --detail $P/trace_bench_detail.json > $P/trace_bench.json 2> $P/trace_bench.err
   T=$(ls $P/trace/*/*kernel_trace.csv | head -1)
   cp $(ls $P/trace/*/*kernel_stats.csv | head -1) $P/r05_bench_kernel_stats.csv
   python3 tools/analyze_trace.py $T --top 30 > $P/r05_forward_breakdown.txt
@@ -30,8 +30,8 @@ trace)
   ;;
 traffic)
   # ---- (b) HBM traffic per kernel and clip: FETCH_SIZE and WRITE_SIZE in separate passes
-  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $P/pmc_fetch -- python3 bench.py --eager --steps 8 --warmup 4 --no-cpu-baseline --no-stream --no-f32-pass --detail $P/pmc_fetch_detail.json > $P/pmc_fetch.log 2>&1
-  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $P/pmc_write -- python3 bench.py --eager --steps 8 --warmup 4 --no-cpu-baseline --no-stream --no-f32-pass --detail $P/pmc_write_detail.json > $P/pmc_write.log 2>&1
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $P/pmc_fetch -- python3 bench.py --eager --steps $GROUP --warmup $GROUP --no-cpu-baseline --no-stream --no-f32-pass --detail $P/pmc_fetch_detail.json > $P/pmc_fetch.log 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $P/pmc_write -- python3 bench.py --eager --steps $GROUP --warmup $GROUP --no-cpu-baseline --no-stream --no-f32-pass --detail $P/pmc_write_detail.json > $P/pmc_write.log 2>&1
   python3 tools/pmc_traffic.py $(ls $P/pmc_fetch/*/*counter_collection.csv | head -1) $(ls $P/pmc_write/*/*counter_collection.csv | head -1) $GROUP > $P/r05_hbm_traffic_pmc.json
   ;;
 k2)
@@ -46,16 +46,16 @@ k2)
   ;;
 swinb)
   # ---- (d) BASELINE configs 4 / 5: Video-Swin-B at 720p and at 360p -- bench line with cpu_baseline + golden parity, kernel stats, HBM traffic
-  python3 bench.py --backbone video-swin-b --no-stream --detail $P/bench_r05_swinb_360p_detail.json > $P/bench_r05_swinb_360p.json 2> $P/bench_r05_swinb_360p.err
+  python3 bench.py --backbone video-swin-b --steps 20 --warmup 5 --no-stream --detail $P/bench_r05_swinb_360p_detail.json > $P/bench_r05_swinb_360p.json 2> $P/bench_r05_swinb_360p.err
   python3 bench.py --backbone video-swin-b --height 720 --width 1280 --steps 10 --no-stream --detail $P/bench_r05_swinb_720p_detail.json > $P/bench_r05_swinb_720p.json 2> $P/bench_r05_swinb_720p.err
   for geo in 360p 720p; do
     # 720p runs pairs (bench.py's default above 360x640), 360p groups of $GROUP
-    if [ $geo = 720p ]; then G="--height 720 --width 1280 --steps 6"; PERG=2; else G="--steps 12"; PERG=$GROUP; fi
+    if [ $geo = 720p ]; then G="--height 720 --width 1280 --steps 6"; PERG=2; E="--steps 8 --warmup 4"; else G="--steps 40 --pipeline group$GROUP"; PERG=$GROUP; E="--steps $GROUP --warmup $GROUP"; fi
     rocprofv3 --kernel-trace --stats --output-format csv -d $P/trace_swinb_$geo -- python3 bench.py --backbone video-swin-b $G --warmup 2 --no-cpu-baseline --no-stream --no-f32-pass --detail $P/trace_swinb_${geo}_detail.json > $P/trace_swinb_$geo.json 2> $P/trace_swinb_$geo.err
     cp $(ls $P/trace_swinb_$geo/*/*kernel_stats.csv | head -1) $P/r05_swinb_${geo}_kernel_stats.csv
     SOC_TRACE_CLIPS_PER_GROUP=$PERG python3 tools/analyze_trace.py $(ls $P/trace_swinb_$geo/*/*kernel_trace.csv | head -1) --top 25 > $P/r05_swinb_${geo}_forward_breakdown.txt
-    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $P/pmc_fetch_swinb_$geo -- python3 bench.py --backbone video-swin-b $G --eager --steps 8 --warmup 4 --no-cpu-baseline --no-stream --no-f32-pass --detail $P/x.json > $P/pmc_fetch_swinb_$geo.log 2>&1
-    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $P/pmc_write_swinb_$geo -- python3 bench.py --backbone video-swin-b $G --eager --steps 8 --warmup 4 --no-cpu-baseline --no-stream --no-f32-pass --detail $P/x.json > $P/pmc_write_swinb_$geo.log 2>&1
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $P/pmc_fetch_swinb_$geo -- python3 bench.py --backbone video-swin-b $G --eager $E --no-cpu-baseline --no-stream --no-f32-pass --detail $P/x.json > $P/pmc_fetch_swinb_$geo.log 2>&1
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $P/pmc_write_swinb_$geo -- python3 bench.py --backbone video-swin-b $G --eager $E --no-cpu-baseline --no-stream --no-f32-pass --detail $P/x.json > $P/pmc_write_swinb_$geo.log 2>&1
     python3 tools/pmc_traffic.py $(ls $P/pmc_fetch_swinb_$geo/*/*counter_collection.csv | head -1) $(ls $P/pmc_write_swinb_$geo/*/*counter_collection.csv | head -1) $PERG > $P/r05_swinb_${geo}_hbm_traffic_pmc.json
   done
   ;;
@@ -75,7 +75,7 @@ import glob, json, os
 out = {"command": "tools/pmc_run_r05.sh counters: rocprofv3 --kernel-trace --pmc <8 SQ counters> | <LDS / co-execution counters, GRBM_GUI_ACTIVE> "
                   "(two separate passes) -- python3 tools/run_kernel.py <site> 12 <clips per launch group>; tools/pmc_agg.py: mean per launch.  "
                   "matrix_pipe_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 128); wait_share = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES"}
-for f in sorted(glob.glob("gpurun_out/r05/*_x[14]_counters.json")):
+for f in sorted(glob.glob("gpurun_out/r05/*_x*_counters.json")):
     d = json.load(open(f))
     for k, c in d.items():
         if not isinstance(c, dict) or "SQ_INSTS_MFMA" not in c:
