@@ -9,9 +9,16 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 import os  # noqa: E402
 PER = int(os.environ.get("SOC_TRACE_CLIPS_PER_GROUP", "1"))      # pair pipeline: a replay (2 clips) ends with two dyn_mask launches
 idx = [i for i, r in enumerate(rows) if "dyn_mask" in r["Kernel_Name"]][PER - 1::PER]
-# a steady-state forward of the timed region: forward 10 (bench.py: 3 warm-up + 20 timed steps, then the streamed and
-# f32 passes and the back-to-back K1 / K20 replays, which are not forwards); short traces fall back to the last one
-k = (10 if PER == 1 else max(2, 12 // PER)) if len(idx) > (12 if PER == 1 else 12 // PER + 2) else len(idx) - 1
+# a steady-state replay: of the segments between two delimiters that hold a whole replay's kernels (head of one group beside
+# the tail of the previous one; the passes of bench.py begin with a head-only replay, end with a tail-only one and are
+# separated by host work), the one that took the least wall time (delimiter to delimiter)
+_segs = [(idx[j] - idx[j - 1], int(rows[idx[j]]["End_Timestamp"]) - int(rows[idx[j - 1]]["End_Timestamp"]), j) for j in range(1, len(idx))]
+if "--segments" in sys.argv:            # every segment between two delimiters: kernels, wall ms
+    for n, w, j in _segs:
+        print(f"segment {j:3d}: {n:5d} kernels  {w / 1e6:8.2f} ms")
+    sys.exit(0)
+_med = sorted(n for n, _, _ in _segs)[len(_segs) // 2]
+k = min((w, j) for n, w, j in _segs if n >= 0.9 * _med)[1]
 seg = rows[idx[k - 1] + 1: idx[k] + 1]
 t0, t1 = int(seg[0]["Start_Timestamp"]), int(seg[-1]["End_Timestamp"])
 

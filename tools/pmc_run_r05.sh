@@ -20,6 +20,7 @@ trace)
   T=$(ls $P/trace/*/*kernel_trace.csv | head -1)
   cp $(ls $P/trace/*/*kernel_stats.csv | head -1) $P/r05_bench_kernel_stats.csv
   python3 tools/analyze_trace.py $T --top 30 > $P/r05_forward_breakdown.txt
+  python3 tools/analyze_trace.py $T --segments > $P/r05_trace_segments.txt
   python3 tools/timeline.py $T > $P/r05_timeline.txt
   python3 tools/launch_sequence.py $T > $P/r05_launch_sequence.txt
   # the one-clip-per-launch pipeline of rounds 1-4 under the same tracer (same box)

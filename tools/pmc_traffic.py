@@ -1,5 +1,5 @@
 """Aggregate two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE, collected SEPARATELY as MI355X_MICROARCH.md's
-HBM section prescribes) of `bench.py --eager --steps 2 --warmup 1 --no-cpu-baseline` into HBM bytes per clip for
+HBM section prescribes) of `bench.py --eager --steps G --warmup G --no-cpu-baseline` (G = clips per launch group) into HBM bytes per clip for
 every hand-written kernel.  usage: python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_...csv> > json
 Counter unit = KiB; on gfx950 FETCH_SIZE reports half of the bytes of wide (16 B/lane) reads, so it is doubled
 (all these kernels read 16 B per lane); WRITE_SIZE is exact for 16-B stores."""
@@ -50,7 +50,8 @@ fetch = per_forward(*load(sys.argv[1], "FETCH_SIZE"))
 write = per_forward(*load(sys.argv[2], "WRITE_SIZE"))
 res = {"clips_per_launch_group": PER,
        "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (two separate runs) -- python3 bench.py --eager "
-                  "--steps 2 --warmup 1 --no-cpu-baseline --no-stream --no-f32-pass; tools/pmc_traffic.py",
+                  "--steps G --warmup G --no-cpu-baseline --no-stream --no-f32-pass (G = clips_per_launch_group; tools/pmc_run_r05.sh); "
+                  "tools/pmc_traffic.py",
        "note": "counter unit = KiB; per MI355X_MICROARCH.md (HBM section) FETCH_SIZE on gfx950 reports 1/2 of the bytes of "
                "wide (16 B/lane) coalesced reads, so fetch bytes are doubled; WRITE_SIZE is exact for 16-B stores. "
                "Second timed forward of the run (steady state).",

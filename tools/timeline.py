@@ -11,16 +11,22 @@ PER = int(os.environ.get("SOC_TRACE_CLIPS_PER_GROUP", "1"))
 
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if "spin_kernel" not in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-ends = [int(r["End_Timestamp"]) for r in rows if "dyn_mask" in r["Kernel_Name"]][PER - 1::PER]
+idx = [i for i, r in enumerate(rows) if "dyn_mask" in r["Kernel_Name"]][PER - 1::PER]
+ends = [int(rows[i]["End_Timestamp"]) for i in idx]
 SPAN = 10 if PER == 1 else max(2, 14 // PER)       # launch groups in the window
 if len(ends) < SPAN + 2:
     sys.exit("too few clips in the trace")
 if len(sys.argv) > 2:
     skip = int(sys.argv[2])
 else:
-    # the SPAN consecutive launch groups that took the least wall time: a steady-state stretch of one timed pass (the passes
-    # of bench.py are separated by host work, and a group pipeline has few groups per pass)
-    skip = min(range(1, len(ends) - SPAN), key=lambda s_: ends[s_ + SPAN] - ends[s_])
+    # the SPAN consecutive whole replays that took the least wall time: a steady-state stretch of one timed pass (the passes of
+    # bench.py are separated by host work; a pass begins with a head-only replay and ends with a tail-only one, whose segments
+    # hold fewer kernels than a whole replay's)
+    counts = [idx[j] - idx[j - 1] for j in range(1, len(idx))]             # kernels of segment j - 1 -> j
+    med = sorted(counts)[len(counts) // 2]
+    whole = [c >= 0.9 * med for c in counts]
+    cands = [s_ for s_ in range(0, len(ends) - SPAN) if all(whole[s_:s_ + SPAN])]
+    skip = min(cands or range(1, len(ends) - SPAN), key=lambda s_: ends[s_ + SPAN] - ends[s_])
 t_lo, t_hi = ends[skip], ends[skip + SPAN]
 n_clips = SPAN * PER
 ev = []
