@@ -586,7 +586,7 @@ class PairPipelinedClipGraph(PipelinedClipGraph):
 
 
 class QuadPipelinedClipGraph(PairPipelinedClipGraph):
-    """Four clips per launch group: what bench.py times.  Same box, bench.py, 20 / 200 steps: 5.74-5.80 / 5.59 ms per clip against
+    """Four clips per launch group (bench.py takes the largest group that divides its clip count: default_pipeline()).  Same box, bench.py, 20 / 200 steps: 5.74-5.80 / 5.59 ms per clip against
     5.89-5.93 / 5.76 for pairs and 6.25-6.39 / 6.24 for one clip per launch; three clips per group lose a slot whenever the clip
     count is not a multiple of three (6.21 at 20 steps)."""
     CLIPS = 4
