@@ -529,8 +529,9 @@ assert worst < 2e-4 and worst_late <= worst, (worst, worst_late)
     assert r.returncode == 0 and "SOAK_OK" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
 
 
-def test_group_pipeline_soak_full_config():
-    """400 back-to-back replays (1 600 clips) of the four-clip launch-group pipeline that bench.py times, at the BASELINE size:
+@pytest.mark.parametrize("group,replays", [(4, 400), (10, 160)])
+def test_group_pipeline_soak_full_config(group, replays):
+    """400 / 160 back-to-back replays (1 600 clips) of the four- / ten-clip launch-group pipelines that bench.py times, at the BASELINE size:
     no hang (child process, killed after the timeout) and no drift -- every time a clip comes round, in whichever slot, its record
     equals the first one to within the run-to-run noise of the library kernels, and the noise does not grow."""
     import os
@@ -542,18 +543,18 @@ import sys, torch
 sys.path.insert(0, %r)
 import neurips2023_soc_amd as S
 from neurips2023_soc_amd import weights as W
-from neurips2023_soc_amd.graph_runner import QuadPipelinedClipGraph
-T, H, Wd, L, N = 8, 360, 640, 10, 400
+from neurips2023_soc_amd.graph_runner import group_pipeline_class
+T, H, Wd, L, N, G = 8, 360, 640, 10, %d, %d
 model, _, _ = S.build_model(S.default_args(text_encoder_random_init=True))
 W.load_synthetic(model, 2023)
 model = model.cuda().eval()
-clips = [W.synthetic_clip(1 + i, T, H, Wd).cuda() for i in range(5)]       # 5 clips over 4 slots: every clip visits every slot
-ids = [W.synthetic_token_ids(1 + i %% 2, L).cuda() for i in range(5)]
-pg = QuadPipelinedClipGraph(model, T, H, Wd, L, "cuda")
+clips = [W.synthetic_clip(1 + i, T, H, Wd).cuda() for i in range(G + 1)]       # G + 1 clips over G slots: every clip visits every slot
+ids = [W.synthetic_token_ids(1 + i %% 2, L).cuda() for i in range(G + 1)]
+pg = group_pipeline_class(G)(model, T, H, Wd, L, "cuda")
 first, worst, worst_late = {}, torch.zeros((), device="cuda"), torch.zeros((), device="cuda")
 order = []
 for r in range(N):
-    group = [(4 * r + b) %% 5 for b in range(4)]
+    group = [(G * r + b) %% (G + 1) for b in range(G)]
     for b, c in enumerate(group):
         pg.stage_inputs(clips[c], ids[c], slot=b)
     rec = pg.replay()
@@ -570,10 +571,10 @@ for r in range(N):
 last = pg.flush()
 torch.cuda.synchronize()
 worst, worst_late = float(worst), float(worst_late)
-assert len(last) == 1 and last[0].shape[0] == 4 and len(first) == 5
+assert len(last) == 1 and last[0].shape[0] == G and len(first) == G + 1
 assert bool(torch.isfinite(last[0]).all())
-print("SOAK_OK replays", N, "max deviation from the first record", worst, "in the second half", worst_late)
+print("SOAK_OK clips per group", G, "replays", N, "max deviation from the first record", worst, "in the second half", worst_late)
 assert worst < 2e-4 and worst_late <= worst, (worst, worst_late)
-""" % root
+""" % (root, replays, group)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=420)
     assert r.returncode == 0 and "SOAK_OK" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
