@@ -351,14 +351,19 @@ def main():
         the HBM-resident pool."""
         m = out.shape[0]
         feeder, host = feed if feed is not None else (None, None)
-        if feeder is not None and n > 0:
-            feeder.submit(host[0])
+        per = getattr(graph, "CLIPS", 1) if graph is not None else clips_per_group      # clips per replay of THIS pass's pipeline
+        # copies run `ahead` clips in front of the compute stream: one clip, or -- with launch groups -- a whole group, so that
+        # the next group crosses PCIe while this one computes (a slot is free again once its clip has been staged into the
+        # graph's static input, and that staging is queued behind the running replay)
+        ahead = min(per, feeder.depth - 1) if feeder is not None else 1
+        submitted = [0]
 
         def next_clip(i):
             if feeder is None:
                 return clips[i % n_pool]
-            if i + 1 < n:
-                feeder.submit(host[(i + 1) % len(host)])
+            while submitted[0] < min(n, i + 1 + ahead):
+                feeder.submit(host[submitted[0] % len(host)])
+                submitted[0] += 1
             if _STREAM_MODE == "nowait":        # diagnostic: the copies run, the compute stream neither waits for them nor reads them
                 feeder._ready[feeder._acquired % feeder.depth] = None
                 feeder.acquire()
@@ -366,7 +371,6 @@ def main():
             return feeder.acquire()
 
         done = 0
-        per = getattr(graph, "CLIPS", 1) if graph is not None else clips_per_group      # clips per replay of THIS pass's pipeline
         in_flight = []                                                    # clips carried by each replay whose records are still due
         for i in range(n):
             clip = next_clip(i)
@@ -433,7 +437,7 @@ def main():
         host = [h.pin_memory() for h in host]
         if _STREAM_MODE == "d2d":               # diagnostic: the same feeder and events, device-resident sources (no PCIe)
             host = [h.to(dev) for h in host]
-        feeder = DoubleBufferedH2D((T, 3, H, Wd), torch.float32, dev, depth=_FEED_DEPTH)
+        feeder = DoubleBufferedH2D((T, 3, H, Wd), torch.float32, dev, depth=max(_FEED_DEPTH, clips_per_group + 1))
         # A driver recycles a few pinned buffers (clip_io.PinnedPool), so every buffer it copies from has been through the
         # DMA engine before; the first transfer out of a fresh pinned allocation is several times slower than the 0.41 ms
         # (54 GB/s) of the later ones.  Each host clip is therefore copied once, untimed, before the pass.
