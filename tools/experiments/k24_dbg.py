@@ -1,6 +1,8 @@
 """K24 at K = 768 with a LayerNorm in front: do the builds with 18 and with 12 column tiles per range give the same bits, with
 and without the accumulation-register pin of the row fragments (tools/experiments/libsoc_hip_nopin.so = -DSOC_K24_NO_PIN)?
-Identity weights: the output IS the kernel's normalised row.   python tools/experiments/k24_dbg.py [nopin]"""
+Identity weights: the output IS the kernel's normalised row.   python tools/experiments/k24_dbg.py [nopin]
+The second library is not kept in the tree: compile xs_linear_split.hip and xs_linear_split_wide.hip with -DSOC_K24_NO_PIN and link
+them with the other objects of csrc/_obj into tools/experiments/libsoc_hip_nopin.so first."""
 import os
 import subprocess
 import sys
