@@ -223,3 +223,27 @@ def test_msda_fused_rejects_maps_beyond_32_bit_tap_offsets():
     for S in (1 << 24, (1 << 31) // (M * 128)):
         code = lib.soc_msda_fused_fwd_f32(p, None, None, p, p, p, 2, p, p, p, 1, S, M, D, L, 5, P, None)
         assert code == _lib.SOC_EUNSUPPORTED, (S, code)
+
+
+def test_k24_plan_cuts_rows_and_column_spans_legally():
+    """soc_xs_linear_plan is a host function (256 CUs without a device): the cut it returns is one soc_xs_linear_f32 accepts --
+    ncr column spans of N / 16 / ncr tiles that a built range width (4 / 6 / 8 / 12 / 16 / 18; K <= 256: even; K = 1024: <= 8)
+    divides, at most 2048 columns per span (the span's bias waits in LDS), no more workgroup rows than row tiles -- and at the
+    row counts of a launch group the rows alone fill the chip, so N is not cut finer than the span limit asks (round 5)."""
+    import ctypes as C
+    from neurips2023_soc_amd import _lib
+    lib = _lib.load()
+    built = {192: (4, 6, 8, 12, 16, 18), 256: (4, 6, 8, 12, 16, 18), 384: (4, 6, 8, 12, 16, 18), 512: (4, 6, 8, 12, 16, 18),
+             768: (4, 6, 8, 12, 16, 18), 1024: (4, 6, 8)}
+    for M in (17, 1920, 7360, 29440, 73600, 115200, 385600):
+        for N, K in ((1152, 384), (384, 384), (2304, 768), (768, 768), (3072, 768), (384, 768), (576, 192), (256, 256), (256, 384),
+                     (1536, 512), (3072, 1024), (4096, 1024)):
+            nrg, ncr, span = C.c_int(0), C.c_int(0), C.c_int(0)
+            assert lib.soc_xs_linear_plan(M, N, K, C.byref(nrg), C.byref(ncr), C.byref(span), None) == 0, (M, N, K)
+            nrg, ncr, span = nrg.value, ncr.value, span.value
+            assert ncr * span == N // 16 and span * 16 <= 2048, (M, N, K, nrg, ncr, span)
+            assert any(span % t == 0 and (K > 256 or t % 2 == 0) for t in built[K]), (M, N, K, span)
+            assert 1 <= nrg <= (M + 15) // 16, (M, N, K, nrg)
+            if M >= 29440 and N <= 2048 and K <= 768:
+                assert ncr <= 2, (M, N, K, nrg, ncr, span)          # a group's rows fill 256 CUs: whole-width (or half) spans
+    assert lib.soc_xs_linear_plan(100, 40, 384, C.byref(C.c_int()), C.byref(C.c_int()), C.byref(C.c_int()), None) != 0   # N % 32
