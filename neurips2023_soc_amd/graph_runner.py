@@ -64,7 +64,7 @@ class ClipGraph:
         self.record = torch.zeros(CP.record_size(T, Q, hm, wm), device=self.device)
         self.out: Optional[Dict[str, torch.Tensor]] = None
         self.graph = torch.cuda.CUDAGraph()
-        assert hot_ops._prof is None, "do not capture while kernel profiling is on"
+        assert not hot_ops.op_profile.active(), "do not capture while kernel profiling is on"
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):  # warm-up off the capture: lazy inits, algorithm finds
@@ -139,7 +139,7 @@ class PipelinedClipGraph:
         self.targets = [[{"size": (H, W)}] for _ in range(T)]
         hm, wm = -(-H // 4), -(-W // 4)
         self.record = torch.zeros(CP.record_size(T, model.num_queries, hm, wm), device=dev)
-        assert hot_ops._prof is None, "do not capture while kernel profiling is on"
+        assert not hot_ops.op_profile.active(), "do not capture while kernel profiling is on"
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
@@ -323,7 +323,7 @@ class TwoStreamClipGraph(PipelinedClipGraph):
         self.targets = [[{"size": (H, W)}] for _ in range(T)]
         hm, wm = -(-H // 4), -(-W // 4)
         self.record = torch.zeros(CP.record_size(T, model.num_queries, hm, wm), device=dev)
-        assert hot_ops._prof is None, "do not capture while kernel profiling is on"
+        assert not hot_ops.op_profile.active(), "do not capture while kernel profiling is on"
         self.main, self.aux = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
         caller = torch.cuda.current_stream(dev)
         self.main.wait_stream(caller)
@@ -520,7 +520,7 @@ class PairPipelinedClipGraph(PipelinedClipGraph):
     def _finish_init(self, warmup):
         """PipelinedClipGraph.__init__ behind the static buffers: warm-up, double-buffered state, the four captures."""
         dev = self.device
-        assert hot_ops._prof is None, "do not capture while kernel profiling is on"
+        assert not hot_ops.op_profile.active(), "do not capture while kernel profiling is on"
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):

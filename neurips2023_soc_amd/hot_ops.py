@@ -17,98 +17,36 @@ Tensor = torch.Tensor
 
 
 # ---------------------------------------------------------------------------------------------
-# optional per-kernel timing (bench.py roofline): HIP events on the stream the kernels run on
-_prof = None
-
-
-_k1_calls = None   # bench.py: when a list, window_attention3d appends its arguments (tensors are kept alive)
+# measurement hooks (per-kernel event timing, recording of a forward's launches): op_profile.py; the names bench.py and the tests
+# use are kept here
+from . import op_profile  # noqa: E402
+from .op_profile import profile_begin, profile_end  # noqa: E402,F401
+from .op_profile import timed as _timed  # noqa: E402
 
 
 def record_window_attention_calls(on: bool):
-    """Start (True) / stop (False, returns the list) recording the arguments of every K1 call, so that
-    bench.py can replay exactly the launches of a forward -- same tensors, same geometry -- back to back
-    between ONE pair of HIP events (per-launch event pairs add host/queue latency to ~50 us kernels)."""
-    global _k1_calls
-    if on:
-        _k1_calls = []
-        return None
-    calls, _k1_calls = _k1_calls, None
-    return calls
-
-
-_k20_calls = None  # bench.py: when a list, linear_split appends its arguments (row statistics included)
+    """K1: the recorded tuples are the arguments of window_attention3d (op_profile.record_calls)."""
+    return op_profile.record_calls("k1", on)
 
 
 def record_linear_split_calls(on: bool):
-    """As record_window_attention_calls, for K20: the recorded dicts are keyword arguments of linear_split."""
-    global _k20_calls
-    if on:
-        _k20_calls = []
-        return None
-    calls, _k20_calls = _k20_calls, None
-    return calls
-
-
-_k13_calls = None  # bench.py: when a list, ws_linear appends its arguments
+    """K20: the recorded dicts are keyword arguments of linear_split."""
+    return op_profile.record_calls("k20", on)
 
 
 def record_ws_linear_calls(on: bool):
-    """As record_linear_split_calls, for K13 / K13b: the recorded dicts are keyword arguments of ws_linear."""
-    global _k13_calls
-    if on:
-        _k13_calls = []
-        return None
-    calls, _k13_calls = _k13_calls, None
-    return calls
-
-
-_k23_calls = None  # bench.py: when a list, mlp_split appends its arguments
+    """K13 / K13b: the recorded dicts are keyword arguments of ws_linear."""
+    return op_profile.record_calls("k13", on)
 
 
 def record_mlp_split_calls(on: bool):
-    """As record_linear_split_calls, for K23: the recorded dicts are keyword arguments of mlp_split."""
-    global _k23_calls
-    if on:
-        _k23_calls = []
-        return None
-    calls, _k23_calls = _k23_calls, None
-    return calls
+    """K23: the recorded dicts are keyword arguments of mlp_split."""
+    return op_profile.record_calls("k23", on)
 
 
-def profile_begin() -> None:
-    global _prof
-    _prof = {}
-
-
-def profile_end() -> dict:
-    """-> {kernel: {"launches", "ms", "work", "unit"}} summed over everything since profile_begin()."""
-    global _prof
-    rec, _prof = _prof or {}, None
-    torch.cuda.synchronize()
-    out = {}
-    for name, items in rec.items():
-        ms = sum(s.elapsed_time(e) for s, e, _ in items)
-        out[name] = {"launches": len(items), "ms": ms, "work": float(sum(w for _, _, w in items)),
-                     "unit": "flop" if name == "win_attn3d" else "byte"}
-    return out
-
-
-class _timed:
-    def __init__(self, name: str, work: float):
-        self.name, self.work = name, work
-
-    def __enter__(self):
-        if _prof is not None:
-            self.s = torch.cuda.Event(enable_timing=True)
-            self.e = torch.cuda.Event(enable_timing=True)
-            self.s.record()
-        return self
-
-    def __exit__(self, *exc):
-        if _prof is not None:
-            self.e.record()
-            _prof.setdefault(self.name, []).append((self.s, self.e, self.work))
-        return False
+def record_xs_linear_calls(on: bool):
+    """K24: the recorded dicts are keyword arguments of xs_linear."""
+    return op_profile.record_calls("k24", on)
 
 
 def _need_gpu(*ts: Tensor) -> None:
@@ -451,8 +389,9 @@ def window_attention3d(qkv: Tensor, qkv_bias: Tensor, bias_table: Tensor, n_head
     _need_gpu(qkv, qkv_bias, bias_table)
     lib = _lib.load()
     qkv, qkv_bias, bias_table = _f32c(qkv), _f32c(qkv_bias), _f32c(bias_table)
-    if _k1_calls is not None:
-        _k1_calls.append((qkv, qkv_bias, bias_table, n_heads, tuple(window), tuple(shift)))
+    _rec = op_profile.recording("k1")
+    if _rec is not None:
+        _rec.append((qkv, qkv_bias, bias_table, n_heads, tuple(window), tuple(shift)))
     B, D, H, W, C3 = qkv.shape
     C = C3 // 3
     win, sh = clamp_window((D, H, W), window, shift)
@@ -854,10 +793,6 @@ WS_LINEAR_K = (96, 128, 192, 256, 384, 512)
 WS_SPLIT_LN_K = (96, 128, 192)      # widths K13b (bf16 matrix cores) covers with a LayerNorm in front; 384 / 512 without
 
 
-def k13_split_enabled() -> bool:
-    return split_enabled() and "k13" not in _SPLIT_OFF
-
-
 def ws_linear_supported(x: Tensor, weight: Tensor, has_ln: bool) -> bool:
     """True when K13 takes linear(x, weight): CUDA fp32, K one of its widths (LayerNorm: K <= 256), N % 16 == 0."""
     N, K = weight.shape
@@ -886,8 +821,9 @@ def ws_linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, ln: Opti
     b = _f32c(bias) if bias is not None else None
     code = {"none": 0, "relu": 1, "gelu": 2}[act]
     work = 2.0 * M * N * K
-    if _k13_calls is not None:
-        _k13_calls.append(dict(x=x, weight=weight, bias=bias, ln=ln, residual=residual, act=act))
+    _rec = op_profile.recording("k13")
+    if _rec is not None:
+        _rec.append(dict(x=x, weight=weight, bias=bias, ln=ln, residual=residual, act=act))
     with _timed("ws_linear", work):
         rc = lib.soc_ws_linear_f32(x.data_ptr(), g.data_ptr() if g is not None else None,
                                    be.data_ptr() if be is not None else None, eps, weight.data_ptr(),
@@ -902,113 +838,11 @@ def ws_linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, ln: Opti
 # K20: f32 linear layers on the bf16 matrix cores by exact operand splitting
 import os as _os
 
-# "split" (default): the pixel-sized linear layers listed in split_wins() run on K20; "f32": every GEMM stays on the f32
-# MFMA path (K13 / K12 / library), i.e. the round-2 arithmetic.  bench.py reports both.
-#
-# The mode is NOT process state: it belongs to a model (SOC.matmul_mode) and reaches the ops through a thread-local that the
-# model's forward sets for its own duration (use_matmul_mode), and it reaches the C ABI as an argument of each launch.  Two
-# models with different modes can therefore run from two threads of one process (tests/test_gpu_forward.py).  The environment
-# variable only supplies the default a model is built with.
-import contextlib as _contextlib
-import threading as _threading
-
-DEFAULT_MATMUL_MODE = _os.environ.get("SOC_MATMUL", "split")
-_mode_tls = _threading.local()
-
-
-def matmul_mode() -> str:
-    """The arithmetic of the calling thread's current forward: "split" or "f32"."""
-    return getattr(_mode_tls, "mode", None) or DEFAULT_MATMUL_MODE
-
-
-@_contextlib.contextmanager
-def use_matmul_mode(mode):
-    """`with use_matmul_mode("f32"):` -- the ops called from THIS thread inside the block run in that arithmetic (None =
-    leave it as it is).  Nests; other threads are unaffected."""
-    if mode is None:
-        yield
-        return
-    if mode not in ("split", "f32"):
-        raise ValueError(f"matmul mode {mode!r}: expected 'split' or 'f32'")
-    prev = getattr(_mode_tls, "mode", None)
-    _mode_tls.mode = mode
-    try:
-        yield
-    finally:
-        _mode_tls.mode = prev
-
-
-def split_enabled() -> bool:
-    return matmul_mode() == "split"
-
-
-def k1_split_enabled() -> bool:
-    """K1 (full 8x7x7 windows) on the bf16 matrix cores with the exact three-way split; SOC_SPLIT_OFF=k1 or
-    SOC_MATMUL=f32 keep the f32-input MFMA form."""
-    return split_enabled() and "k1" not in _os.environ.get("SOC_SPLIT_OFF", "").split(",")
-
-
-_SPLIT_OFF = set(filter(None, _os.environ.get("SOC_SPLIT_OFF", "").split(",")))   # debugging: sites forced back to f32
-
-
-def split_wins(rows: int, N: int, K: int, fused_passes: int = 0, site: str = "plain") -> bool:
-    """Does K20 beat the f32 path for a [rows, K] x [N, K]^T layer?  From tools/split_probe.py on MI355X (round 3): K20
-    runs at 100-125 TFLOP/s f32-equivalent once the grid fills the chip and K is short, about what the tuned f32 library
-    GEMM reaches, so it wins where it also removes separate passes (`fused_passes`: LayerNorm, GELU, residual / mul /
-    positional adds), and loses on long-K layers with few row tiles (K >= 768 with < 30 000 rows)."""
-    if not split_enabled() or K % 8 or N % 4 or rows < 1024 or K > 768 or site in _SPLIT_OFF:
-        return False
-    if rows * N < 5_500_000:                    # too few tiles to fill 256 CUs (stage-2/3 proj, stage-3 qkv, coarse levels)
-        return False
-    if K > 512:                                 # K = 768: only the wide, GELU-fused fc1 of stage 3 (1920 x 768 -> 3072)
-        return fused_passes >= 1 and N >= 1024
-    if fused_passes == 0 and rows < 16384:      # bare GEMM on a short token map: a tie at best
-        return False
-    return True
-
-
-class DerivedCache:
-    """Values derived from parameter tensors (packed weight images, stacked layers): built once per (tensors, versions),
-    rebuilt after an in-place update (load_state_dict bumps `_version`), and dropped when a keyed tensor dies.
-
-    The key is what the tensors ARE, not a temporary made from them: (data_ptr, storage offset, shape, strides, device) of each,
-    so that views created per call (`in_proj_weight[:E]`) hit, and a contiguous copy made on the way never enters the key.  An
-    entry holds only WEAK references to the tensors' owners (the view's base, i.e. the nn.Parameter): the model can be freed,
-    and when it is, the entry -- and the device memory of the image -- goes with it.  Nothing is ever bulk-cleared: a captured
-    hipGraph that has a packed image's address baked in keeps its model alive, and with the model the entry.
-
-    Update weights in place under no_grad (`p.copy_(w)`, `load_state_dict`): that bumps `_version` and the image is rebuilt.
-    A write through `p.data` (`p.data.copy_(w)`) does NOT bump the version and cannot be seen here -- do not load weights that
-    way.  Re-pointing a parameter (`p.data = new`) is seen: an entry is only hit while each owner still sits at the address it
-    was keyed under, so a later tensor that happens to reuse the freed address (same shape, same version) cannot hit a stale
-    image."""
-
-    def __init__(self):
-        self._d = {}
-
-    @staticmethod
-    def _ident(t: Tensor):
-        return (t.data_ptr(), t.storage_offset(), tuple(t.shape), tuple(t.stride()), str(t.dtype), t.device.index)
-
-    def get(self, tensors, build, extra=()):
-        import weakref
-        ts = [t for t in tensors if t is not None]
-        key = tuple(self._ident(t) for t in ts) + tuple(extra)
-        version = tuple(t._version for t in ts)
-        hit = self._d.get(key)
-        if hit is not None and hit[0] == version:
-            owners = [r() for r in hit[2]]
-            if all(o is not None and o.data_ptr() == ptr for o, ptr in zip(owners, hit[3])):
-                return hit[1]
-            self._d.pop(key, None)      # an owner died or was re-pointed (`p.data = new`): the address may belong to someone else
-        value = build()
-        owners = [t._base if t._base is not None else t for t in ts]
-        refs = tuple(weakref.ref(o, lambda _r, k=key: self._d.pop(k, None)) for o in owners)
-        self._d[key] = (version, value, refs, tuple(o.data_ptr() for o in owners))
-        return value
-
-    def __len__(self):
-        return len(self._d)
+# The arithmetic mode of a forward and the routing rules that hang on it live in matmul_mode.py, the cache of packed weight images
+# in derived_cache.py; both are re-exported here (callers and tests use hot_ops.<name>).
+from .derived_cache import DerivedCache  # noqa: E402,F401
+from .matmul_mode import (DEFAULT_MATMUL_MODE, _SPLIT_OFF, _mode_tls, k1_split_enabled, k13_split_enabled,  # noqa: E402,F401
+                          matmul_mode, split_enabled, split_wins, use_matmul_mode)
 
 
 _SPLIT_ACT = {"none": 0, "relu": 1, "gelu": 2}
@@ -1121,19 +955,6 @@ def small_attention(q: Tensor, k: Tensor, v: Tensor, n_heads: int, mask: Optiona
 XS_LINEAR_K = (192, 256, 384, 512, 768, 1024)      # input widths K24 is built for
 _XS_NCT = (18, 16, 12, 8, 6, 4)         # column tiles per range it is built for
 _xs_cache = DerivedCache()
-_k24_calls = None  # bench.py: when a list, xs_linear appends its arguments
-
-
-def record_xs_linear_calls(on: bool):
-    """As record_linear_split_calls, for K24: the recorded dicts are keyword arguments of xs_linear."""
-    global _k24_calls
-    if on:
-        _k24_calls = []
-        return None
-    calls, _k24_calls = _k24_calls, None
-    return calls
-
-
 def xs_linear_supported(x, weight) -> bool:
     """K24 takes act(LN(x) weight^T + bias) + residual: CUDA fp32, input width 192 / 256 / 384 / 512 / 768 / 1024, an output width whose 16-
     column tiles divide into ranges of a built size, split arithmetic on (SOC_SPLIT_OFF=k24 switches it off)."""
@@ -1177,8 +998,9 @@ def xs_linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, ln: Opti
     if ln is not None:
         g, be, eps = _f32c(ln[0]), _f32c(ln[1]), float(ln[2])
     b = _f32c(bias) if bias is not None else None
-    if _k24_calls is not None:
-        _k24_calls.append(dict(x=x, weight=weight, bias=bias, ln=ln, residual=residual, act=act, cut=cut))
+    _rec = op_profile.recording("k24")
+    if _rec is not None:
+        _rec.append(dict(x=x, weight=weight, bias=bias, ln=ln, residual=residual, act=act, cut=cut))
     ptr = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
     nrg, ncr = cut if cut is not None else (0, 0)
     with _timed("xs_linear", 2.0 * M * N * K):
@@ -1297,8 +1119,9 @@ def mlp_split(x: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor, act: st
     if residual_ln and residual.data_ptr() != x.data_ptr():
         raise _lib.SocHipError("mlp_split: residual_ln means 'the shortcut is LN(x)': residual must be x itself")
     osum = torch.empty_like(x) if return_sum else None
-    if _k23_calls is not None:
-        _k23_calls.append(dict(x=x, w1=w1, b1=b1, w2=w2, b2=b2, act=act, ln=ln, residual=residual, post_ln=post_ln, cut=cut,
+    _rec = op_profile.recording("k23")
+    if _rec is not None:
+        _rec.append(dict(x=x, w1=w1, b1=b1, w2=w2, b2=b2, act=act, ln=ln, residual=residual, post_ln=post_ln, cut=cut,
                                return_sum=return_sum, residual_ln=residual_ln))
     if cut is None:
         nbytes = lib.soc_mlp_split_workspace_bytes(M, C_, F_, _stream())
@@ -1373,8 +1196,9 @@ def linear_split(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None,
     if M == 0:
         return out if out2 is None else (out, out2)
     cfg = split_tile_for(M, N, K) if tile is None else int(tile)
-    if _k20_calls is not None:
-        _k20_calls.append(dict(x=x, weight=weight, bias=bias_in, ln=ln, residual=residual, act=act, add=add, mul=mul,
+    _rec = op_profile.recording("k20")
+    if _rec is not None:
+        _rec.append(dict(x=x, weight=weight, bias=bias_in, ln=ln, residual=residual, act=act, add=add, mul=mul,
                                tile=cfg, stats=stats, split_at=split_at))
     ptr = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
     with _timed("linear_split", 2.0 * M * N * K):
