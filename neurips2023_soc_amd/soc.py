@@ -477,17 +477,20 @@ class SOC(nn.Module):
         each clip what a B = 1 head gives it (to f32 rounding).  The REFERENCE's tail does not: its B = 2 outputs of a clip
         differ from its B = 1 outputs by 5 % of the logit scale (measured on the reference itself), so a
         clip-parallel caller that wants the reference's per-clip (B = 1) results batches the head only."""
-        B, T = state["B"], state["T"]
+        B = state["B"]
         if B == 1:
             return [state]
+        return [SOC.slice_state(state, b, b + 1) for b in range(B)]
+
+    @staticmethod
+    def slice_state(state, b0: int, b1: int):
+        """Clips b0 .. b1 - 1 of a batched head's hand-over state (views, no copies): a sub-group forward_tail can run on."""
+        T = state["T"]
         memory, spatial_shapes, level_start, ratios, mask, pad_flag, shapes = state["ctx"]
-        out = []
-        for b in range(B):
-            rows = slice(b * T, (b + 1) * T)
-            ctx = (memory[rows], spatial_shapes, level_start, ratios[rows], mask[rows], pad_flag, shapes)
-            out.append({"ctx": ctx, "feats0": state["feats0"][rows], "lang_last": state["lang_last"][:, b:b + 1],
-                        "word_pad": state["word_pad"][b:b + 1], "sentence": state["sentence"][b:b + 1], "B": 1, "T": T})
-        return out
+        rows = slice(b0 * T, b1 * T)
+        ctx = (memory[rows], spatial_shapes, level_start, ratios[rows], mask[rows], pad_flag, shapes)
+        return {"ctx": ctx, "feats0": state["feats0"][rows], "lang_last": state["lang_last"][:, b0:b1],
+                "word_pad": state["word_pad"][b0:b1], "sentence": state["sentence"][b0:b1], "B": b1 - b0, "T": T}
 
     def num_parameters(self):
         return sum(p.numel() for p in self.parameters() if p.requires_grad)
