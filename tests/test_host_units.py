@@ -236,3 +236,27 @@ def test_clip_inferencer_group_bookkeeping_with_a_stub_pipeline(monkeypatch):
     import pytest
     with pytest.raises(ValueError):
         infer.ClipInferencer(Model(), "cpu", group=0)
+
+
+def test_slice_state_gives_views_of_a_sub_group():
+    """SOC.slice_state / split_state: clips b0 .. b1 - 1 of a batched head's hand-over state as views (no copies), frames of a
+    clip contiguous in the '(b t)' rows; B = 1 passes through."""
+    import torch
+    from neurips2023_soc_amd.soc import SOC
+    B, T, S, C, L = 4, 3, 10, 8, 5
+    memory = torch.arange(B * T * S * C, dtype=torch.float32).view(B * T, S, C)
+    ratios, mask = torch.rand(B * T, 4, 2), torch.zeros(B * T, S, dtype=torch.bool)
+    state = {"ctx": (memory, "shapes", "starts", ratios, mask, False, [(2, 5)]), "feats0": torch.rand(B * T, 6, 7, C),
+             "lang_last": torch.rand(L, B, C), "word_pad": torch.zeros(B, L, dtype=torch.bool), "sentence": torch.rand(B, C),
+             "B": B, "T": T}
+    sub = SOC.slice_state(state, 1, 3)
+    assert sub["B"] == 2 and sub["T"] == T
+    assert sub["ctx"][0].data_ptr() == memory[T:].data_ptr() and sub["ctx"][0].shape[0] == 2 * T
+    assert torch.equal(sub["ctx"][3], ratios[T:3 * T]) and sub["ctx"][1:3] == ("shapes", "starts") and sub["ctx"][5:] == (False, [(2, 5)])
+    assert torch.equal(sub["lang_last"], state["lang_last"][:, 1:3]) and torch.equal(sub["sentence"], state["sentence"][1:3])
+    assert sub["feats0"].data_ptr() == state["feats0"][T:].data_ptr() and sub["word_pad"].shape == (2, L)
+    singles = SOC.split_state(state)
+    assert len(singles) == B and all(s["B"] == 1 for s in singles)
+    assert torch.equal(singles[3]["ctx"][0], memory[3 * T:]) and torch.equal(singles[0]["lang_last"], state["lang_last"][:, :1])
+    one = dict(state, B=1)
+    assert SOC.split_state(one) == [one]
