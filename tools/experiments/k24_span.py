@@ -1,7 +1,7 @@
 """K24 column spans (round 5): a workgroup keeps its split rows for several column ranges.  Times every legal cut
 (workgroup rows x column spans) of the model's K24 shapes at the row counts of one clip and of a launch group of four, checks
 that all cuts give the same bits, and prints the library's plan.
-    python tools/experiments/k24_span.py [reps]"""
+    python tools/experiments/k24_span.py [reps [clips ...]]"""
 import sys
 import torch
 sys.path.insert(0, ".")
@@ -28,7 +28,7 @@ SHAPES = [("s2.qkv", 7360, 1152, 384, True, False, "none"), ("s2.proj", 7360, 38
           ("s3.proj", 1920, 768, 768, False, True, "none"), ("s3.fc1", 1920, 3072, 768, True, False, "gelu"),
           ("merge0", 28800, 192, 384, True, False, "none"), ("inproj2", 7360, 256, 384, False, False, "none"),
           ("vlf.q2", 7360, 256, 256, False, False, "none")]
-for clips in (4, 1):
+for clips in ([int(v) for v in sys.argv[2:]] or [4, 1]):
     for name, M1, N, K, ln, res, act in SHAPES:
         M = M1 * clips
         x = torch.randn(M, K, generator=g).cuda(); w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda(); b = torch.randn(N, generator=g).cuda()
