@@ -9,10 +9,11 @@ clip_parallel.spawn_ranks = the reference's mp.Process fan-out, infer_refytb.py:
 
 A step = one eval forward of Video-Swin-T SOC on one synthetic clip [T=8,3,360,640] (random
 deterministic weights, pre-tokenised 10-token expression) + query selection, i.e. the body of
-the reference's inference loop (infer_refytb.py:206-227).  Since round 5 four independent clips share each launch of the
-forward (graph_runner.QuadPipelinedClipGraph; eight when --steps is a multiple of eight); the VOC module -- the one place where the reference's forward couples the clips
-of a batch -- runs per clip, so every clip gets its single-clip (B = 1) result; `single_clip_ms_per_step` is the
-one-clip-per-launch pipeline of rounds 1-4 beside it.  Inputs are resident in HBM before the
+the reference's inference loop (infer_refytb.py:206-227).  Since round 5 a group of independent clips shares each launch of the
+forward (graph_runner.group_pipeline_class: DEFAULT_GROUP = 10 clips, fixed since round 6); the VOC module -- the one place where the
+reference's forward couples the clips of a batch -- runs per clip, so every clip gets its single-clip (B = 1) result, and EVERY
+timed record is checked against the same clip's one-clip-per-launch record (every slot of a group holds a different clip);
+`single_clip_ms_per_step` is the one-clip-per-launch pipeline of rounds 1-4 beside it.  Inputs are resident in HBM before the
 timed region.  Clips shard over ranks (weak scaling: K clips per rank, no data-path collective);
 the single result all_gather sits inside the timed region.  Rank 0 prints ONE JSON line.
 """
@@ -156,22 +157,26 @@ def headline(a, world, timed, workload, launch):
                    "parallelism": f"clip-parallel x{world}, one result all_gather", "launch": launch}}
 
 
-_ROOFLINE_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "frac_of_ceiling", "traffic", "launches", "clips_per_replay",
+_ROOFLINE_KEYS = ("kernel", "bound", "achieved", "peak", "peak_basis", "vs_f32_mfma_peak", "unit", "frac", "frac_of_ceiling", "traffic", "launches", "clips_per_replay",
                   "algorithmic_flop_per_clip", "algorithmic_bytes_per_clip", "avg_launch_us", "ms_per_clip", "source")
+
+
+DEFAULT_GROUP = 10             # clips per launch group up to 360 x 640 (same box, Swin-T: 4.81-4.85 ms per clip in eights / tens / twelves)
 
 
 def default_pipeline(steps: int, frames: int, height: int, width: int) -> str:
     """The pipeline bench.py times when --pipeline is not given.  Up to 360x640 several independent clips share every launch
     (graph_runner.group_pipeline_class): per clip 5.13 ms in fours, 4.81-4.84 in eights / tens / twelves, 4.89 in sixteens (same
-    box, Swin-T) -- and a part-filled group costs a whole replay, so the group is the first of 8, 10, 12, 9, 6, 7, 5, 4 that
-    divides the clip count (20 clips: two groups of ten), fours otherwise.  Above 360x640 a clip nearly fills the chip by itself:
-    pairs (Swin-B 720p: 42.1 ms per clip in pairs, 42.6 alone, 49.2 in fours)."""
+    box, Swin-T).  The group is FIXED -- DEFAULT_GROUP clips, whatever --steps is (round 5 took the first of 8, 10, 12, ... that
+    divided --steps, i.e. a group tuned to the driver's step count): a clip count that is not a multiple runs a part-filled last
+    group at the cost of a whole replay, inside the timed region.  Fewer clips than a group: one group of all of them.  Above
+    360x640 a clip nearly fills the chip by itself: pairs (Swin-B 720p: 42.1 ms per clip in pairs, 42.6 alone, 49.2 in fours)."""
+    if steps <= 1:
+        return "one-graph"
     if frames * height * width > 8 * 360 * 640:
         return "pairs"
-    for g in (8, 10, 12, 9, 6, 7, 5, 4):
-        if steps % g == 0:
-            return {8: "octs", 4: "quads"}.get(g, f"group{g}")
-    return "quads" if steps > 3 else ("pairs" if steps == 2 else "one-graph" if steps == 1 else "group3")
+    g = min(DEFAULT_GROUP, steps)
+    return {8: "octs", 4: "quads", 2: "pairs"}.get(g, f"group{g}")
 
 
 def compact_line(full):
@@ -181,7 +186,7 @@ def compact_line(full):
     keep = ("metric", "value", "unit", "n_gpus", "ranks_seen", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
             "vs_baseline", "dtype", "data", "seconds_per_rank", "config", "matmul", "stub", "records_ok",
             "f32_mfma_only_ms_per_step", "stream_ms_per_step", "single_clip_ms_per_step", "clips_per_head_launch",
-            "kernels_per_forward", "switches")
+            "long_run_ms_per_step", "long_run_steps", "kernels_per_forward", "switches")
     line = {k: full[k] for k in keep if k in full}
     if "roofline" in full:
         line["roofline"] = {k: full["roofline"][k] for k in _ROOFLINE_KEYS if k in full["roofline"]}
@@ -207,9 +212,15 @@ def compact_line(full):
                  "d": p["timed_path_mask_logit_max_abs_diff"]}]
         recs += [{"flips": e["thresholded_mask_flips"], "at": e["max_abs_oracle_logit_at_flips"], "d": e["mask_logit_max_abs_diff"]}
                  for e in p.get("timed_path_other_records_vs_cpu_oracle", [])]
+        sc = full.get("slot_check")
         line["parity"] = {
-            "checked": "records of the timed region: 0 vs the reference golden, 1.. vs the CPU oracle",
-            "records": len(recs),
+            "checked": "records of the timed region: 0 vs the reference golden, 1..3 vs the CPU oracle"
+                       + (f"; ALL {sc['records']} (distinct clips, one per group slot) vs the same clip's one-clip-per-launch record"
+                          if sc else ""),
+            "records": sc["records"] if sc else len(recs),
+            "records_vs_golden_or_oracle": len(recs),
+            **({"all_records_max_abs_diff_vs_single_clip": sc["max_abs_diff"], "all_records_selected_query_equal": sc["selected_query_equal"],
+                "distinct_clips": sc["distinct_clips"]} if sc else {}),
             "selected_query_matches": bool(p["timed_path_selected_query"] == p["timed_path_selected_query_ref"] and all(
                 e["selected_query"] == e["selected_query_oracle"] for e in p.get("timed_path_other_records_vs_cpu_oracle", []))),
             "mask_logit_max_abs_diff": max(r["d"] for r in recs),
@@ -233,7 +244,19 @@ def emit(line, full, detail_path):
         except OSError as e:          # a read-only tree must not cost the run its line
             line["detail"] = f"not written: {e}"
     text = json.dumps(line)
-    assert len(text) < MAX_LINE_BYTES, len(text)
+    # a finished multi-minute run must not end in an AssertionError over a few bytes: optional blocks go (they are in the detail
+    # file) until the line fits, and the line says so
+    for drop in ("switches", "kernels_per_forward", "roofline_families", "seconds_per_rank", "matmul"):
+        if len(text) < MAX_LINE_BYTES:
+            break
+        if drop in line:
+            del line[drop]
+            line["truncated"] = line.get("truncated", []) + [drop]
+            text = json.dumps(line)
+    if len(text) >= MAX_LINE_BYTES and "config" in line:
+        line["config"] = {k: (v[:200] if isinstance(v, str) else v) for k, v in line["config"].items()}
+        line["truncated"] = line.get("truncated", []) + ["config"]
+        text = json.dumps(line)
     sys.stderr.flush()
     print(text, flush=True)
 
@@ -294,7 +317,10 @@ def main():
     model = model.to(dev).eval()
 
     T, H, Wd, L, Q = a.frames, a.height, a.width, 10, 20
-    n_pool = 4
+    # Distinct clips: every timed clip its own (seed 1 + 1000 rank + i) up to 32 clips, a pool of 29 beyond that (a prime: over a
+    # long run every pool clip then visits every slot of a launch group).  Round 5 cycled FOUR clips, so a ten-clip group held
+    # clips 0,1,2,3,0,1,... and a record returned from slot b - 4 instead of slot b could not have been seen.
+    n_pool = a.steps if a.steps <= 32 else 29
     clips_cpu = [W.synthetic_clip(1 + 1000 * rank + i, T, H, Wd) for i in range(n_pool)]
     clips = [c.to(dev) for c in clips_cpu]
     # the expression of the configuration's reference golden (seed 1 for the headline one; the 720p golden was made with seed 3
@@ -425,6 +451,7 @@ def main():
     timed = CP.timed_sharded_run(lambda out: run_steps(a.steps, out), results, dev)
     gathered, dt = timed["gathered"], timed["seconds"]
     timed_records = results[:min(a.steps, n_pool)].cpu()      # clip i of the pool <-> record i
+    all_timed_records = results.cpu()                         # record i <-> pool clip i % n_pool: every one is checked below
 
     # Second timed pass, H2D-inclusive (SURVEY 8d config 5 "stream with per-clip seeds seed0 + i", 8e "pinned,
     # double-buffered H2D"): the same loop, but every clip is copied from a pinned host buffer inside the timed region.
@@ -432,9 +459,8 @@ def main():
     stream = None
     if not a.no_stream:
         from neurips2023_soc_amd.clip_io import DoubleBufferedH2D
-        n_host = min(a.steps, 24)                        # distinct host clips (22 MB pinned each), cycled beyond that
-        host = [clips_cpu[i] if i < n_pool else W.synthetic_clip(1 + 1000 * rank + i, T, H, Wd) for i in range(n_host)]
-        host = [h.pin_memory() for h in host]
+        n_host = n_pool                                  # the pool's clips as pinned host buffers (22 MB each), cycled like the pool
+        host = [h.pin_memory() for h in clips_cpu]
         if _STREAM_MODE == "d2d":               # diagnostic: the same feeder and events, device-resident sources (no PCIe)
             host = [h.to(dev) for h in host]
         feeder = DoubleBufferedH2D((T, 3, H, Wd), torch.float32, dev, depth=max(_FEED_DEPTH, clips_per_group + 1))
@@ -451,7 +477,8 @@ def main():
         torch.cuda.synchronize()
         sres.zero_()
         st = CP.timed_sharded_run(lambda out: run_steps(a.steps, out, (feeder, host)), sres, dev)
-        stream = {"seconds": st["seconds"], "records": sres[:min(a.steps, n_pool)].cpu(), "n_host": n_host}
+        stream = {"seconds": st["seconds"], "records": sres[:min(a.steps, n_pool)].cpu(), "n_host": n_host,
+                  "max_abs_diff_all_records": float((sres.cpu() - all_timed_records).abs().max())}
         del host, feeder
     if graph is None:
         prof = hot_ops.profile_end()
@@ -497,9 +524,40 @@ def main():
         run_steps(min(a.warmup, 2), r1)
         torch.cuda.synchronize()
         t1 = CP.timed_sharded_run(lambda out: run_steps(a.steps, out), r1, dev)
-        single_pass = {"seconds": t1["seconds"],
-                       "max_abs_diff": float((r1[:min(a.steps, n_pool)].cpu() - timed_records).abs().max())}
+        single_pass = {"seconds": t1["seconds"], "records": r1.cpu(),
+                       "max_abs_diff": float((r1.cpu() - all_timed_records).abs().max())}
         graph = main_graph
+
+    # Long run (short --steps only): the timed region of the driver's command is two replays; the same loop over ten launch
+    # groups is the steadier figure, reported beside the headline (never instead of it).
+    long_run = None
+    if graph is not None and pipelined and per > 1 and a.steps < 40 and world == 1 and not a.no_single_pass:
+        n_long = 10 * per
+        rl = torch.zeros(n_long, results.shape[1], device=dev)
+        tl = CP.timed_sharded_run(lambda out: run_steps(n_long, out), rl, dev)
+        long_run = {"seconds": tl["seconds"], "steps": n_long}
+        del rl
+
+    # Every record of the timed region against the SAME clip through the one-clip-per-launch path (the single-clip pass above when
+    # it ran, eager single-clip forwards otherwise): whichever slot of whichever group a clip sat in, it must come back with its
+    # own B = 1 result (selected query equal, record within 1e-4).  Records 0..3 are additionally checked against the reference
+    # golden / the CPU oracle further down.
+    slot_check = None
+    if per > 1 and world == 1:
+        if single_pass is not None:
+            ref_recs, how = single_pass["records"], "single-clip pipeline pass (PipelinedClipGraph)"
+        else:
+            ref_dev = torch.zeros_like(results)
+            for i in range(a.steps):
+                step(i, ref_dev[i])
+            ref_recs, how = ref_dev.cpu(), "eager single-clip forwards"
+        d_each = (ref_recs - all_timed_records).abs().amax(1)
+        q_same = bool((ref_recs[:, 0] == all_timed_records[:, 0]).all())
+        distinct = float((all_timed_records[1:min(a.steps, n_pool)] - all_timed_records[0]).abs().amax(1).min()) if min(a.steps, n_pool) > 1 else None
+        slot_check = {"records": int(a.steps), "against": how, "max_abs_diff": float(d_each.max()), "selected_query_equal": q_same,
+                      "distinct_clips": min(a.steps, n_pool), "min_abs_diff_between_different_clips": distinct}
+        assert q_same and slot_check["max_abs_diff"] < 1e-4, slot_check
+        assert distinct is None or distinct > 1e-2, slot_check      # the pool's clips really differ: a swapped slot would show
 
     # The dominant kernel families: replay the launches of ONE forward back to back between one HIP-event pair on the launch
     # stream (per-launch event pairs add host / queue latency to 30-400 us kernels), with the forward's own tensors.  Every
@@ -596,12 +654,16 @@ def main():
                                "1-4) on the same box; its records differ from the timed ones by single_clip_max_abs_diff",
                 "single_clip_max_abs_diff": single_pass["max_abs_diff"]} if single_pass is not None else {}),
             "clips_per_head_launch": per,
+            **({"long_run_ms_per_step": 1e3 * long_run["seconds"] / long_run["steps"], "long_run_steps": long_run["steps"]}
+               if long_run is not None else {}),
+            **({"slot_check": slot_check} if slot_check is not None else {}),
             **({"stream_ms_per_step": 1e3 * stream["seconds"] / a.steps, "stream_value": world * a.steps / stream["seconds"],
                 "stream": f"same loop with every clip copied host->device inside the timed region: {stream['n_host']} "
                           "pinned host clips (seeds seed0 + i; each buffer DMA-ed once before the pass, as a recycled pinned pool is), "
                           "two device slots (a slot is released right behind the copy into the graph's static input), copy stream one clip ahead "
                           "(clip_io.DoubleBufferedH2D); 22 MB per clip at 360x640",
-                "stream_record0_max_abs_diff_vs_resident": float((stream["records"][0] - timed_records[0]).abs().max())}
+                "stream_record0_max_abs_diff_vs_resident": float((stream["records"][0] - timed_records[0]).abs().max()),
+                "stream_all_records_max_abs_diff_vs_resident": stream["max_abs_diff_all_records"]}
                if stream is not None else {}),
         }
         # HBM bytes per clip from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE collected
@@ -682,6 +744,9 @@ def main():
                 "kernel_long": desc[fam], "launches": f["launches"], "clips_per_replay": per,
                 "bound": "mfma" if mfma_bound else "hbm",
                 "achieved": ach, "peak": mf if mfma_bound else PEAK_HBM_GBS, "unit": "TFLOP/s" if mfma_bound else "GB/s",
+                "peak_basis": ("HBM3E 8 TB/s" if not mfma_bound else
+                               "2.5 PFLOP/s dense bf16 MFMA / 6 bf16 products per f32 product (exact 3-way operand split); the f32-input "
+                               "MFMA peak is 157.3" if split_on[fam] else "157.3 TFLOP/s f32-input MFMA"),
                 "frac": ach / (mf if mfma_bound else PEAK_HBM_GBS),
                 "frac_of_ceiling": t_c / sec,
                 "ceiling": "per launch max(algorithmic FLOPs / matrix-core peak, algorithmic bytes / 6.3 TB/s achievable HBM rate), "

@@ -20,19 +20,23 @@ extern "C" const char* soc_hip_error_string(int code) {
 #include <atomic>
 
 // CUs a launch on `st` can use: the device's count, cut down to the stream's CU mask when the caller created the stream with
-// hipExtStreamCreateWithCUMask (graph_runner.PartitionedClipGraph runs the head of a clip and the tail of the previous one on
-// two disjoint CU sets).  A one-workgroup-per-CU grid sized for the whole chip on a stream that owns 240 CUs runs in two
-// rounds (measured: K23 320 -> 513 us, tools/experiments/cu_mask_probe.py), so every persistent kernel sizes itself from here.
-// The mask is a property of the stream argument -- nothing the library remembers.
+// hipExtStreamCreateWithCUMask (tools/experiments/cu_mask_probe.py, partition_probe.py: a head on one CU set, a tail on another --
+// measured slower at every split and not shipped, DESIGN.md section 3 "Launch structure"; the query stays so that a caller who
+// does partition the chip gets grids of the right size).  A one-workgroup-per-CU grid sized for the whole chip on a stream that
+// owns 240 CUs runs in two rounds (measured: K23 320 -> 513 us), so every persistent kernel sizes itself from here.  The mask is a
+// property of the stream argument -- nothing the library remembers; the words queried follow the device's CU count (ADVICE r5:
+// a fixed 8 words sent devices with more than 256 CUs down the error path on every launch).
 int soc_num_cus(hipStream_t st) {
     const int n = soc_device_cus();
-    uint32_t mask[SOC_CU_MASK_WORDS] = {0};
-    if (hipExtStreamGetCUMask(st, SOC_CU_MASK_WORDS, mask) != hipSuccess) {
+    constexpr int MAXW = 32;                                   // up to 1024 CUs
+    const int words = (n + 31) / 32 < MAXW ? (n + 31) / 32 : MAXW;
+    uint32_t mask[MAXW] = {0};
+    if (hipExtStreamGetCUMask(st, (uint32_t)words, mask) != hipSuccess) {
         (void)hipGetLastError();               // not a launch error: leave nothing behind for soc_check_launch()
         return n;
     }
     int c = 0;
-    for (int i = 0; i < SOC_CU_MASK_WORDS; ++i) c += __builtin_popcount(mask[i]);
+    for (int i = 0; i < words; ++i) c += __builtin_popcount(mask[i]);
     return c > 0 && c < n ? c : n;
 }
 

@@ -1044,15 +1044,18 @@ _MLP_ACT = {"relu": 1, "gelu": 2}
 _mlp_cache = DerivedCache()
 
 
-_mlp_max_hidden = {}
+
+
+# soc_mlp_split_max_hidden(C) of csrc/mlp_split.hip as a table: routing predicates read shapes only and must not need the
+# native library (routes.table() runs on a CPU-only checkout).  tests/test_c_abi.py and the GPU suite check the
+# table against the library whenever it is there.
+MLP_SPLIT_MAX_HIDDEN = {96: 16192, 128: 16128, 192: 9856, 256: 3584, 384: 3328, 512: 3072}
 
 
 def mlp_split_max_hidden(Cw: int) -> int:
     """Largest hidden width K23 holds at model width Cw (its b1 range shares the 160 KB of LDS with the weight ring): beyond it
-    the launch would return SOC_EUNSUPPORTED, so the router must not send the layer there."""
-    if Cw not in _mlp_max_hidden:
-        _mlp_max_hidden[Cw] = int(_lib.load().soc_mlp_split_max_hidden(int(Cw)))
-    return _mlp_max_hidden[Cw]
+    the launch would return SOC_EUNSUPPORTED, so the router must not send the layer there.  Shape-only: a table."""
+    return MLP_SPLIT_MAX_HIDDEN.get(int(Cw), 0)
 
 
 def mlp_split_supported(x: Tensor, w1: Tensor, w2: Tensor) -> bool:

@@ -178,7 +178,7 @@ class ClipInferencer:
         return res
 
 
-def load_checkpoint(model, path: str):
+def load_checkpoint(model, path: str, require_text_encoder: bool = True):
     """The reference's on-disk contract (infer_refytb.py:143-156): `torch.load(path)["model_state_dict"]`, strict=False,
     the profiler's `total_params` / `total_ops` buffers ignored, anything else missing or unexpected printed.
     Returns (missing, unexpected) after that filter."""
@@ -187,6 +187,15 @@ def load_checkpoint(model, path: str):
     unexpected = [k for k in unexpected if not k.endswith(("total_params", "total_ops"))]
     if missing or unexpected:
         print(f"Missing Keys: {missing}\nUnexpected Keys: {unexpected}")
+    # The drivers build the model with a randomly initialised RoBERTa (no download offline) and rely on the checkpoint to
+    # overwrite it, as the reference's checkpoint overwrites its from_pretrained weights.  A checkpoint WITHOUT text_encoder.*
+    # tensors would leave the random ones in place and write plausible-looking, wrong masks: refuse it.
+    # position_ids is a derived buffer some transformers versions keep out of the state_dict.
+    text_missing = [k for k in missing if k.startswith("text_encoder.") and not k.endswith("position_ids")]
+    if text_missing and require_text_encoder:
+        raise RuntimeError(f"{path}: the checkpoint has no weights for {len(text_missing)} text-encoder tensors "
+                           f"(first: {text_missing[0]}); the model's text encoder is randomly initialised, so its masks would be "
+                           "meaningless -- pass a checkpoint that carries text_encoder.*")
     return missing, unexpected
 
 

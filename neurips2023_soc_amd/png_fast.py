@@ -108,8 +108,25 @@ def encode(img: np.ndarray, binarize: bool = False, palette: Optional[Sequence[i
     return buf[:n].tobytes()
 
 
+_fallback = None                       # None: not tried yet; True: libsoc_host.so could not be built / loaded -> Pillow
+
+
 def use_pillow() -> bool:
-    return os.environ.get("SOC_PNG", "runs") == "pillow"
+    """True when the PNG files are to be written by Pillow: SOC_PNG=pillow, or libsoc_host.so cannot be built or loaded on this
+    box (no gcc, a read-only package directory).  The drivers ask BEFORE the forwards run, so a missing library costs a warning
+    and the slower writer, not the whole inference run at the first f.result() of the writer pool."""
+    global _fallback
+    if os.environ.get("SOC_PNG", "runs") == "pillow":
+        return True
+    if _fallback is None:
+        try:
+            load()
+            _fallback = False
+        except (OSError, subprocess.CalledProcessError, RuntimeError) as exc:      # FileNotFoundError (no gcc) is an OSError
+            import warnings
+            warnings.warn(f"libsoc_host.so unavailable ({exc}); PNG files are written by Pillow (slower, same pixels)")
+            _fallback = True
+    return _fallback
 
 
 def pillow_save_kwargs() -> dict:

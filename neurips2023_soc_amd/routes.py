@@ -118,9 +118,10 @@ def table(backbone: str, T: int, H: int, W: int, clips: int = 1) -> Dict[str, st
     return out
 
 
-# what bench.py runs by default: groups of four clips up to 360 x 640, pairs above
+# what bench.py runs by default: groups of ten clips up to 360 x 640 (round 5: fours / eights), pairs above
 GROUPED = (("video-swin-t", 8, 360, 640, 4), ("video-swin-b", 8, 360, 640, 4), ("video-swin-b", 8, 720, 1280, 2),
-           ("video-swin-t", 8, 360, 640, 8), ("video-swin-b", 8, 360, 640, 8))
+           ("video-swin-t", 8, 360, 640, 8), ("video-swin-b", 8, 360, 640, 8),
+           ("video-swin-t", 8, 360, 640, 10), ("video-swin-b", 8, 360, 640, 10))
 
 
 def all_tables() -> Dict[str, Dict[str, str]]:

@@ -68,7 +68,11 @@ def _check_compact(line, text):
     assert c["kind"] in ("reference", "port") and c["unit"] == "clips/s" and c["cores"] >= 1 and c["sample"]
     assert c["value"] > 0 and line["value"] / c["value"] > 100
     p = line["parity"]
-    assert p["records"] == 4 and p["selected_query_matches"] is True
+    # rounds 4-5: four records (golden + three oracle forwards); round 6: EVERY timed record (distinct clips per group slot)
+    assert p["records"] >= 4 and p["selected_query_matches"] is True
+    if "all_records_max_abs_diff_vs_single_clip" in p:
+        assert p["records"] == line["steps"] and p["distinct_clips"] >= min(line["steps"], line["clips_per_head_launch"])
+        assert p["all_records_selected_query_equal"] is True and p["all_records_max_abs_diff_vs_single_clip"] < 1e-4
     assert p["mask_logit_max_abs_diff"] < 1e-3
     assert p["flip_window"] == bench.FLIP_WINDOW == 6e-5
     # "bit-exact masks": a thresholded pixel may differ only inside the reference's own thread-count noise of zero
@@ -101,12 +105,15 @@ def test_stub_line_is_the_same_bounded_form():
     _check_contract(line)
 
 
-def test_committed_bench_line_keeps_the_driver_contract():
-    """The line this round's bench.py printed on an MI355X (committed as it came off stdout)."""
-    path = os.path.join(ROOT, "profiles", "bench_r05_n1.json")
+import pytest
+
+
+@pytest.mark.parametrize("name", ["bench_r05_n1.json", "bench_r06_n1.json"])
+def test_committed_bench_line_keeps_the_driver_contract(name):
+    """The line a round's bench.py printed on an MI355X (committed as it came off stdout)."""
+    path = os.path.join(ROOT, "profiles", name)
     if not os.path.exists(path):
-        import pytest
-        pytest.skip("no round-5 line committed yet")
+        pytest.skip(f"{name}: no line committed yet")
     with open(path) as f:
         text = f.read().strip().splitlines()[-1]
     line = json.loads(text)
@@ -114,15 +121,33 @@ def test_committed_bench_line_keeps_the_driver_contract():
     assert line["n_gpus"] == 1
     assert line["stream_ms_per_step"] > 0 and line["f32_mfma_only_ms_per_step"] > line["ms_per_step"]
     assert line["detail"].endswith(".json")
+    if name >= "bench_r06":
+        # round 6: every timed record checked, the roofline says what its peak is, the group does not hang on --steps
+        assert line["parity"]["records"] == line["steps"] and "peak_basis" in line["roofline"] and "vs_f32_mfma_peak" in line["roofline"]
+        assert line["clips_per_head_launch"] == 10
 
 
-def test_default_pipeline_takes_the_largest_group_that_divides_the_clip_count():
-    """bench.default_pipeline: a part-filled launch group costs a whole replay, so the group size divides --steps (the driver's
-    20 clips: two groups of ten); above 360x640 pairs."""
+def test_emit_drops_optional_blocks_instead_of_failing(capsys):
+    """A line that grew past the driver's bound loses optional blocks (they are in the detail file) and says so; it never costs
+    a finished run its JSON line."""
+    bench = _bench()
+    line = {"metric": "m", "value": 1.0, "config": {"workload": "w" * 300}, "roofline_families": {str(i): "x" * 100 for i in range(90)},
+            "switches": ["s" * 50] * 10, "kernels_per_forward": {"a": 1}}
+    bench.emit(dict(line), None, None)
+    out = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    assert "roofline_families" not in out and "roofline_families" in out["truncated"] and out["value"] == 1.0
+    assert len(json.dumps(out)) < bench.MAX_LINE_BYTES
+
+
+def test_default_pipeline_is_a_fixed_group():
+    """bench.default_pipeline: DEFAULT_GROUP = 10 clips per launch group whatever --steps is (round 5 picked the first of 8, 10, 12,
+    ... that divided --steps -- a group tuned to the driver's 20); fewer clips than a group: one group of them; above 360x640 pairs."""
     import bench
-    assert bench.default_pipeline(20, 8, 360, 640) == "group10"
-    assert bench.default_pipeline(200, 8, 360, 640) == "octs" and bench.default_pipeline(12, 8, 360, 640) == "group12"
-    assert bench.default_pipeline(13, 8, 360, 640) == "quads" and bench.default_pipeline(1, 8, 360, 640) == "one-graph"
+    assert bench.DEFAULT_GROUP == 10
+    assert bench.default_pipeline(20, 8, 360, 640) == "group10" and bench.default_pipeline(200, 8, 360, 640) == "group10"
+    assert bench.default_pipeline(23, 8, 360, 640) == "group10" and bench.default_pipeline(12, 8, 360, 640) == "group10"
+    assert bench.default_pipeline(8, 8, 360, 640) == "octs" and bench.default_pipeline(3, 8, 360, 640) == "group3"
+    assert bench.default_pipeline(1, 8, 360, 640) == "one-graph"
     assert bench.default_pipeline(20, 8, 720, 1280) == "pairs"
     from neurips2023_soc_amd import graph_runner
     for name, clips in (("group10", 10), ("octs", 8), ("quads", 4), ("pairs", 2), ("group3", 3), ("one-graph", 1)):

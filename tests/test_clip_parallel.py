@@ -3,6 +3,7 @@ every rank reassembles the stream in the original order."""
 import os
 import socket
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -153,6 +154,37 @@ def test_bench_rank_loop_under_torch_distributed_run():
                             "--master-port", str(port), "bench.py", "--stub", "--gpus", "2", "--steps", "4", "--warmup", "1"],
                            timeout=300))
     assert line["stub"] is True and line["records_ok"] is True and line["n_gpus"] == 2 and line["ranks_seen"] == [0, 1]
+
+
+def test_bench_rank_loop_eight_ranks():
+    """World 8 -- the node the north_star's scaling curve is quoted on -- over gloo with the stub step, self-launched: eight
+    ranks seen, one gather, every rank's records in rank order.  (No 8-GPU node has been leased to a round yet; this keeps the
+    rank loop honest at that width.)"""
+    line = _stub_line(_run(["bench.py", "--stub", "--gpus", "8", "--steps", "5", "--warmup", "1"], timeout=600))
+    assert line["stub"] is True and line["records_ok"] is True
+    assert line["n_gpus"] == 8 and line["ranks_seen"] == list(range(8)) and len(line["seconds_per_rank"]) == 8
+    assert abs(line["value"] * line["ms_per_step"] / 1e3 - 8) < 1e-6            # whole-job clips/s x s per clip = ranks
+
+
+def test_eight_ranks_share_a_sixteen_cpu_quota_two_each():
+    shares = [CP.rank_cpu_share(r, 8, list(range(256)), 16) for r in range(8)]
+    assert sorted(c for s in shares for c in s) == list(range(16)) and all(len(s) == 2 for s in shares)
+
+
+@pytest.mark.gpu
+def test_bench_under_torch_distributed_run_on_one_gpu():
+    """The driver's multi-GPU launch line at the width a 1-GPU lease allows: `python -m torch.distributed.run --nproc-per-node 1
+    bench.py --gpus 1`.  RCCL initialises, the warm-up gather and the timed region's one all_gather run on the GPU, the line
+    carries the rank-loop keys -- exercised every round while the 8-GPU run waits for a node."""
+    port = CP.free_port()
+    r = _run(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+              "--master-port", str(port), "bench.py", "--gpus", "1", "--steps", "4", "--warmup", "1", "--no-cpu-baseline",
+              "--all-passes", "--no-stream", "--no-f32-pass", "--detail", ""], timeout=1500)
+    line = _stub_line(r)
+    assert "stub" not in line and line["n_gpus"] == 1 and line["ranks_seen"] == [0] and line["steps"] == 4
+    assert line["value"] > 50 and line["clips_per_head_launch"] == 4
+    assert "all_gather" in line["config"]["parallelism"]
+    assert line["parity"]["records"] == 4 and line["parity"]["all_records_selected_query_equal"] is True
 
 
 def test_rank_environment_is_the_same_in_both_launch_modes(monkeypatch):

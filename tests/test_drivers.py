@@ -209,6 +209,14 @@ def test_reference_checkpoint_file_contract(tmp_path, synthetic_sd):
     model2, _, _ = S.build_model(S.default_args(text_encoder_random_init=True))
     missing, unexpected = load_checkpoint(model2, path)
     assert "class_embed.0.bias" in missing and unexpected == ["not_a_key"]
+    # a checkpoint without the text encoder would leave the drivers' randomly initialised RoBERTa in place: refused
+    no_text = {k: v for k, v in state.items() if not k.startswith("text_encoder.")}
+    torch.save({"model_state_dict": no_text}, path)
+    model3, _, _ = S.build_model(S.default_args(text_encoder_random_init=True))
+    with pytest.raises(RuntimeError, match="text-encoder"):
+        load_checkpoint(model3, path)
+    missing, _ = load_checkpoint(model3, path, require_text_encoder=False)
+    assert any(k.startswith("text_encoder.") for k in missing)
 
 
 @pytest.mark.gpu

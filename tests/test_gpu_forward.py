@@ -402,25 +402,29 @@ def test_pipelined_graph_full_config_matches_reference(gpu_model, golden, pipeli
         assert maxdiff(other, recs[order.index(seed)].cpu()) > 1e-2       # a different clip gave a different record
 
 
-@pytest.mark.parametrize("group", [4, 2, 8])
+@pytest.mark.parametrize("group", [4, 2, 8, 10])
 def test_group_pipeline_gives_every_clip_its_single_clip_result(gpu_model, golden, group):
-    """QuadPipelinedClipGraph / OctPipelinedClipGraph (what bench.py times) / PairPipelinedClipGraph: four / eight / two independent clips per launch group, the
-    VOC module per clip.  Every clip's record equals the one-clip ClipGraph's to f32 rounding -- whichever slot it sits in, whoever
-    its partners are, with a part-filled last group -- and the golden clip meets the reference's output.  (The reference's own
-    B = 2 forward does NOT give a clip its B = 1 result: its VOC couples the batch.)"""
+    """The group pipelines (graph_runner.group_pipeline_class: two / four / eight / TEN clips per launch group -- ten is what bench.py
+    times), the VOC module per clip.  Every clip's record equals the one-clip ClipGraph's to f32 rounding -- whichever slot it sits
+    in, whoever its partners are, with a part-filled last group -- and the golden clip meets the reference's output.  Every slot of a
+    group holds a DIFFERENT clip (group + 1 distinct clips, two expressions), so a record that came back from the wrong slot fails.
+    (The reference's own B = 2 forward does NOT give a clip its B = 1 result: its VOC couples the batch.)"""
     from neurips2023_soc_amd import clip_parallel as CP
-    from neurips2023_soc_amd.graph_runner import ClipGraph, OctPipelinedClipGraph, PairPipelinedClipGraph, QuadPipelinedClipGraph
+    from neurips2023_soc_amd.graph_runner import ClipGraph, group_pipeline_class
     g = golden("full_forward.npz")
     seed, T, H, Wd, L = (int(v) for v in g["cfg"])
     hm, wm = -(-H // 4), -(-Wd // 4)
-    clips = [W.synthetic_clip(seed + i, T, H, Wd).cuda() for i in range(5)]
-    ids = [W.synthetic_token_ids(seed + (i % 2), L).cuda() for i in range(5)]          # two different expressions
+    n = max(5, group + 1)
+    clips = [W.synthetic_clip(seed + i, T, H, Wd).cuda() for i in range(n)]
+    ids = [W.synthetic_token_ids(seed + (i % 2), L).cuda() for i in range(n)]          # two different expressions
     plain = ClipGraph(gpu_model, T, H, Wd, L, "cuda")
     want = []
     for c, t_ in zip(clips, ids):
         plain.run(c, t_)
         want.append(plain.record.clone())
-    pipe = {2: PairPipelinedClipGraph, 4: QuadPipelinedClipGraph, 8: OctPipelinedClipGraph}[group](gpu_model, T, H, Wd, L, "cuda")
+    for i in range(1, n):                                                   # the clips really are distinct
+        assert maxdiff(want[i], want[0].cpu()) > 1e-2
+    pipe = group_pipeline_class(group)(gpu_model, T, H, Wd, L, "cuda")
     assert pipe.CLIPS == group and pipe.flush() == []
 
     def through(order):
@@ -438,7 +442,8 @@ def test_group_pipeline_gives_every_clip_its_single_clip_result(gpu_model, golde
             got += [x.clone() for x in r[:counts.pop(0)]]
         return got
 
-    for order in ([0, 1, 2, 3, 4], [1, 0], [4], [3, 0, 2], [4, 3, 2, 1, 0, 1, 2, 3, 4]):
+    everyone = list(range(n))
+    for order in (everyone, [1, 0], [4], [3, 0, 2], everyone[::-1] + everyone[1:], everyone[3:] + everyone[:3] + everyone[5:]):
         got = through(order)
         assert len(got) == len(order)
         for i, rec in zip(order, got):

@@ -205,6 +205,10 @@ def test_c_abi_library_exports_every_declared_symbol():
     assert not [n for n in declared if re.search(r"_(set|get)_", n)], declared
     assert lib.soc_mlp_split_max_hidden(512) >= 2048 and lib.soc_mlp_split_max_hidden(256) >= 2048      # the BASELINE layers
     assert lib.soc_mlp_split_max_hidden(100) == 0
+    # the routing predicates read a Python table instead of the library (they must work on a CPU-only checkout): same numbers
+    from neurips2023_soc_amd import hot_ops
+    for c in (64, 96, 100, 128, 192, 256, 384, 512, 768, 1024):
+        assert hot_ops.mlp_split_max_hidden(c) == lib.soc_mlp_split_max_hidden(c), c
     assert lib.soc_xattn_workspace_bytes(240, 10, 1, 8, 32) == 0
     assert lib.soc_xattn_workspace_bytes(10, 1920, 1, 8, 32) == 0
 

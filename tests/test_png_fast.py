@@ -108,3 +108,21 @@ def test_thread_safe_from_a_writer_pool():
     for t in threads:
         t.join()
     assert not errors
+
+
+def test_missing_host_library_falls_back_to_pillow(monkeypatch):
+    """No gcc / a read-only package directory: the drivers are told to write with Pillow (one warning) BEFORE any forward runs,
+    instead of raising inside the writer pool at the end of the run."""
+    import warnings
+    from neurips2023_soc_amd import png_fast
+
+    def no_gcc(*a, **k):
+        raise FileNotFoundError("gcc")
+    monkeypatch.setattr(png_fast, "_fallback", None)
+    monkeypatch.setattr(png_fast, "load", no_gcc)
+    monkeypatch.delenv("SOC_PNG", raising=False)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert png_fast.use_pillow() is True and png_fast.use_pillow() is True
+    assert len(w) == 1 and "Pillow" in str(w[0].message)
+    monkeypatch.setattr(png_fast, "_fallback", None)

@@ -21,6 +21,20 @@ def test_route_table_matches_the_golden():
                                              for k in set(got[cfg]) | set(want[cfg]) if got[cfg].get(k) != want[cfg].get(k)})
 
 
+def test_route_table_needs_no_native_library(monkeypatch):
+    """Routing reads shapes, dtypes and devices only: on a checkout without libsoc_hip.so (it is git-ignored) and without hipcc the
+    table still comes out (mlp_split_supported used to load the library for soc_mlp_split_max_hidden)."""
+    from neurips2023_soc_amd import _lib
+
+    def no_library(*a, **k):
+        raise _lib.SocHipError("libsoc_hip.so is missing (test)")
+    monkeypatch.setattr(_lib, "load", no_library)
+    with open(routes.GOLDEN) as f:
+        want = json.load(f)
+    assert routes.table("video-swin-t", 8, 360, 640) == want["video-swin-t T=8 360x640"]
+    assert routes.table("video-swin-t", 8, 360, 640, 10) == want["video-swin-t T=8 360x640 x10 clips"]
+
+
 def test_headline_config_keeps_its_hand_written_kernels():
     """The BASELINE headline (Swin-T, T = 8, 360 x 640): every MLP of stages 0-2 and the encoder's feed-forward block on K23,
     qkv / proj of stages 0-1 on K13b, of stages 2-3 and the encoder's value / output projections on K24; what is left to the library is the
