@@ -28,6 +28,7 @@
 #include <map>
 #include <mutex>
 #include <tuple>
+#include <type_traits>
 #include <vector>
 
 namespace {
@@ -1338,6 +1339,640 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_split_kernel(
     STAMP_RT(31);
 }
 
+// =============================================================================================
+// K1, round 6: the STREAMING form of the split kernel (what split_arith = 1 launches now).
+// Round 3's win_attn3d_split_kernel above keeps a 16-query tile's whole 16 x 400 score block in registers and does the softmax
+// between two MFMA phases; its counters say the vector ALU (40 M instructions per stage-0 launch against 7 M MFMAs) and not
+// the matrix pipe sets its time, and tools/microbench/mfma_valu_roles.hip says why: beside a stream of v_mfma_f32_16x16x32_bf16
+// a SIMD issues NO vector instruction.  tools/microbench/mfma32_valu.hip (round 6): beside v_mfma_f32_32x32x16_bf16 it does --
+// about four softmax-mix instructions per MFMA ride for free, two waves per SIMD -- if the two kinds are INTERLEAVED in the
+// instruction stream.  So:
+//   * MFMA shape 32x32x16: a wave owns a 32-query tile and walks the keys in chunks of 32.  S^T = K.Q^T of a chunk is
+//     2 k-steps x 6 products on ONE 16-register accumulator tile (lane = query l & 31, half h = l >> 5 holds keys
+//     8 j + 4 h + e of the chunk in register 4 j + e), O^T = V^T.P^T likewise 2 k-steps x 6 on one accumulator tile
+//     (dims x queries); a lane's 16 scores are one query's: row sums stay in the lane (+ one xor-32 shuffle per tile).
+//   * No score block: the chunk's scores are exponentiated, summed, split and fed to P.V while the next chunk's Q.K^T
+//     MFMAs run -- the vector work sits BETWEEN MFMAs instead of in a phase of its own.  Software pipeline per chunk c:
+//     phase 1 = [Q.K^T(c+1) k-step 0 | P.V(c-1) k-step 1] beside exp / sum / split of scores 0..7 of chunk c,
+//     phase 2 = [Q.K^T(c+1) k-step 1 | P.V(c) k-step 0] beside scores 8..15.
+//   * Softmax without a max: 2^score is taken as it comes (scale and log2 e are folded into Q and the bias column) and the
+//     row SUM says afterwards whether that was legal (sum in [2^-60, 2^60] => the largest term is a normal number and
+//     nothing overflowed); a tile that fails the test (scores beyond +-60 in log2 units: never with trained or the synthetic
+//     weights, test_window_attention_large_scores) is redone by the two-pass form with the row max subtracted.
+//   * The bias gather needs no per-group code fetch: with the chunk's column a compile-time constant the address is a
+//     per-lane base minus a constant, i.e. the offset field of the ds_read.
+//   * 392 queries = 12 tiles of 32 + 8: waves 0..3 take two tiles, waves 4..7 (their SIMD partners) one, and the 8-query
+//     tile is shared between waves 4..7 by key chunks, merged through LDS (as the 25th tile was).
+// K / V planes, their swizzle, the bias column and the staging code are the split kernel's: the K operand of a 32-key chunk
+// (lane = key l & 31, 16-B piece 2 kk + h) and the transposing V reads (a 16-lane group = 4 keys x 16 dims) are conflict-free
+// on the same image.
+// =============================================================================================
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int SNC = 13;                          // key chunks of 32 slots: 12 full + one with 8
+constexpr int SNQ = 13;                          // query tiles of 32: 12 full + one with 8
+constexpr int SCHB = 32 * KROWB;                 // bytes of a chunk in a plane
+constexpr int SQ_PRS = 36;                       // shared-tile scratch: row stride of a wave's O partial [8 queries][32 dims]
+constexpr int SQ_PWS = 8 * SQ_PRS + 16;          // + row max [8] + row sum [8]
+static_assert(4 * SQ_PWS * 4 <= 3 * PLANEB, "shared-tile scratch aliases the K planes");
+__host__ __device__ constexpr int kc_of(int col) { return 60 * (13 * (col / 7) + col % 7); }   // bias-address term of a key column
+
+#define MFMA6_BIG(acc, a, b)                                                                  \
+    do {                                                                                      \
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc, 0, 0, 0);              \
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc, 0, 0, 0);              \
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc, 0, 0, 0);              \
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);              \
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);              \
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);              \
+    } while (0)
+
+// The vector work of the streaming kernel is written instruction by instruction: left to itself hipcc packs the residual
+// subtractions into v_pk_add_f32 (twice the issue cost of two v_sub_f32 beside MFMAs, MI355X_MICROARCH.md) and converts some
+// elements one at a time.  A pair of f32 -> three packed bf16 pairs, exact (8 + 8 + 8 significand bits, round-to-nearest at
+// each level): 3 converts + 4 unpacks + 4 subtractions.
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+// Compiler-visible (v_cvt_pk_bf16_f32): what reads a v_exp_f32 result must be an instruction hipcc knows, or its hazard
+// recogniser does not keep the one wait state a VALU read needs behind a transcendental -- with the convert and the row-sum
+// add as inline assembly, queries in lanes with bit 2 clear read stale exponentials (round 6, found with P == 1).
+__device__ __forceinline__ unsigned cvt_pk_bf16(float x, float y) {
+    const f32x2 v = {x, y};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ float sub_f32(float a, float b) {
+    float r;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// s += x where it is written (hipcc sinks a chain of plain adds to the end of the tile and spills the 196 terms until then).  `after`
+// is a value computed FROM x by a compiler-visible instruction: the dependence keeps this add behind it, i.e. at least one
+// instruction behind the v_exp_f32 that made x (see cvt_pk_bf16).
+__device__ __forceinline__ void acc_f32(float& s, float x, unsigned after) {
+    asm("v_add_f32 %0, %0, %1" : "+v"(s) : "v"(x), "v"(after));
+}
+__device__ __forceinline__ void split_rest(float x, float y, unsigned c0, unsigned& c1, unsigned& c2) {
+    float rx = sub_f32(x, __builtin_bit_cast(float, c0 << 16));
+    float ry = sub_f32(y, __builtin_bit_cast(float, c0 & 0xffff0000u));
+    c1 = cvt_pk_bf16(rx, ry);
+    rx = sub_f32(rx, __builtin_bit_cast(float, c1 << 16));
+    ry = sub_f32(ry, __builtin_bit_cast(float, c1 & 0xffff0000u));
+    c2 = cvt_pk_bf16(rx, ry);
+}
+__device__ __forceinline__ void split_pair(float x, float y, unsigned& c0, unsigned& c1, unsigned& c2) {
+    c0 = cvt_pk_bf16(x, y);
+    split_rest(x, y, c0, c1, c2);
+}
+__device__ __forceinline__ void split8p(const float (&v)[8], bf16x8& h0, bf16x8& h1, bf16x8& h2) {
+    u32x4 a, b, c;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        unsigned c0, c1, c2;
+        split_pair(v[2 * i], v[2 * i + 1], c0, c1, c2);
+        a[i] = c0; b[i] = c1; c[i] = c2;
+    }
+    h0 = __builtin_bit_cast(bf16x8, a); h1 = __builtin_bit_cast(bf16x8, b); h2 = __builtin_bit_cast(bf16x8, c);
+}
+
+template <bool SHIFTED>
+__global__ __launch_bounds__(THREADS, 2) void win_attn3d_stream_kernel(
+    const float* __restrict__ qkv, const float* __restrict__ qkv_bias,
+    const float* __restrict__ table, float* __restrict__ out, const WinParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    // owns its CUs like every bf16-MFMA kernel of the package (see win_attn3d_split_kernel)
+    asm volatile("v_mov_b32 v255, 0" ::: "v255");
+    float* Tb = reinterpret_cast<float*>(smem_raw + SP_TB);
+    char* Kp = smem_raw + SP_K;
+    int* wflag = reinterpret_cast<int*>(smem_raw + SP_MISC);
+    int* gtab = wflag + 8;                                      // [2 col + half]: 4 * c | region << 16 (the region is what is read here)
+    float* Pw = reinterpret_cast<float*>(Kp);                   // shared-tile scratch, aliases the K planes (behind a barrier)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bid = blockIdx.x;
+    int qpart = 0, qsplit = 1;
+    if (bid >= p.n_main) {
+        const int rem = bid - p.n_main;
+        qsplit = p.qsplit;
+        qpart = rem % qsplit;
+        bid = p.n_main + rem / qsplit;
+    }
+    const int head = bid % p.nH; bid /= p.nH;
+    const int wx = bid % p.nww; bid /= p.nww;
+    const int wy = bid % p.nwh; bid /= p.nwh;
+    const int wz = bid % p.nwd; bid /= p.nwd;
+    const int b = bid;
+    const int C3 = 3 * p.C;
+    STAMP_RT(30);
+    STAMP_HWID(29);
+    STAMP(0);
+
+    // slot = col*8 + dz, col = dy*7 + dx (temporal index fastest)
+    auto slot_info = [&](int i, int& reg, int& ccode) -> int {
+        const int col = i >> 3, dz = i & 7;
+        const int dy = (col * 37) >> 8, dx = col - dy * 7;     // col / 7 for col < 64
+        const int zs = wz * 8 + dz, ys = wy * 7 + dy, xs = wx * 7 + dx;  // shifted frame
+        int z = zs + p.sd; if (z >= p.Dp) z -= p.Dp;
+        int y = ys + p.sh; if (y >= p.Hp) y -= p.Hp;
+        int x = xs + p.sw; if (x >= p.Wp) x -= p.Wp;
+        reg = (region1d(zs, p.Dp, 8, p.sd) * 3 + region1d(ys, p.Hp, 7, p.sh)) * 3 + region1d(xs, p.Wp, 7, p.sw);
+        ccode = ((dy * 13 + dx) * 15 - dz + 8) * 4;
+        return (z < p.D && y < p.H && x < p.W) ? ((b * p.D + z) * p.H + y) * p.W + x : -1;
+    };
+
+    // ---- staging (the split kernel's): K and V rows (8 dims per thread) split into three bf16 planes each, bias column, group table
+    {
+        int differs = 0, reg0, c0;
+        (void)slot_info(0, reg0, c0);
+        constexpr int ITEMS = FN * 4;                       // (slot, 8-dim chunk)
+        constexpr int PASSES = (ITEMS + THREADS - 1) / THREADS;
+        float4 kv[PASSES][2], vv[PASSES][2];
+        const int c = tid & 3;
+#pragma unroll
+        for (int it = 0; it < PASSES; ++it) {
+            const int i = (tid + THREADS * it) >> 2;
+            int s = -2, reg = 0, cc = 0;
+            if (i < FN) {
+                s = slot_info(i, reg, cc);
+                differs |= (reg != reg0);
+            }
+            if (s >= 0) {
+                const float4* row = reinterpret_cast<const float4*>(qkv + (long)s * C3 + head * HD + 8 * c);
+                kv[it][0] = row[p.C / 4]; kv[it][1] = row[p.C / 4 + 1];
+                vv[it][0] = row[p.C / 2]; vv[it][1] = row[p.C / 2 + 1];
+            } else {
+                const float4* kb = reinterpret_cast<const float4*>(qkv_bias + p.C + head * HD + 8 * c);
+                const float4* vb = reinterpret_cast<const float4*>(qkv_bias + 2 * p.C + head * HD + 8 * c);
+                kv[it][0] = kb[0]; kv[it][1] = kb[1];
+                vv[it][0] = vb[0]; vv[it][1] = vb[1];
+            }
+        }
+        constexpr int TPASS = (TBL + THREADS - 1) / THREADS;
+        float tv[TPASS];
+#pragma unroll
+        for (int it = 0; it < TPASS; ++it) {
+            const int i = it * THREADS + tid;
+            const int yx = i / 15, zz = i - yx * 15;
+            tv[it] = i < TBL ? table[(long)(zz * 169 + yx) * p.nH + head] : 0.f;
+        }
+        const int wave_differs = __any(differs);
+        if (SHIFTED && lane == 0) wflag[wave] = wave_differs ? 1 : 0;
+        STAMP(1);
+        if (tid < FNT * 4) {                                // key-group codes: group = slots 8 col + 4 half .. +3, index 2 col + half
+            const int t = tid >> 2, gg = tid & 3;
+            const int col = 2 * t + (gg >> 1);
+            const int dy = (col * 37) >> 8, dx = col - dy * 7;
+            int reg = 0;
+            if (SHIFTED) {
+                const int zs = wz * 8 + 4 * (gg & 1), ys = wy * 7 + dy, xs = wx * 7 + dx;
+                reg = (region1d(zs, p.Dp, 8, p.sd) * 3 + region1d(ys, p.Hp, 7, p.sh)) * 3 + region1d(xs, p.Wp, 7, p.sw);
+            }
+            gtab[tid] = (((dy * 13 + dx) * 15 - 4 * (gg & 1) + 8) * 4) | (reg << 16);
+        }
+#pragma unroll
+        for (int it = 0; it < PASSES; ++it) {
+            const int i = (tid + THREADS * it) >> 2;
+            if (i < FN) {
+                const float kf[8] = {kv[it][0].x, kv[it][0].y, kv[it][0].z, kv[it][0].w, kv[it][1].x, kv[it][1].y, kv[it][1].z, kv[it][1].w};
+                const float vf[8] = {vv[it][0].x, vv[it][0].y, vv[it][0].z, vv[it][0].w, vv[it][1].x, vv[it][1].y, vv[it][1].z, vv[it][1].w};
+                bf16x8 h0, h1, h2;
+                char* dst = Kp + i * KROWB + ((c ^ swz(i)) << 4);
+                split8v(kf, h0, h1, h2);
+                *reinterpret_cast<bf16x8*>(dst) = h0;
+                *reinterpret_cast<bf16x8*>(dst + PLANEB) = h1;
+                *reinterpret_cast<bf16x8*>(dst + 2 * PLANEB) = h2;
+                split8v(vf, h0, h1, h2);
+                *reinterpret_cast<bf16x8*>(dst + 3 * PLANEB) = h0;
+                *reinterpret_cast<bf16x8*>(dst + 4 * PLANEB) = h1;
+                *reinterpret_cast<bf16x8*>(dst + 5 * PLANEB) = h2;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < TPASS; ++it) {
+            const int i = it * THREADS + tid;
+            const int yx = i / 15, zz = i - yx * 15;
+            if (i < TBL) Tb[yx * 15 + 14 - zz] = tv[it] * LOG2E;
+        }
+    }
+    STAMP(2);
+    __syncthreads();
+    bool has_mask = false;
+    if (SHIFTED) {
+        int f = 0;
+#pragma unroll
+        for (int w8 = 0; w8 < THREADS / 64; ++w8) f |= wflag[w8];
+        has_mask = f != 0;
+    }
+    STAMP(3);
+    int stamp_slot = 4;
+    (void)stamp_slot;
+
+    const int n32 = lane & 31, hh = lane >> 5;
+    const unsigned tbase = (unsigned)(uintptr_t)(lds_cfloat*)Tb;
+    const unsigned kaddr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)Kp;
+    const unsigned vaddr = kaddr + 3 * PLANEB;
+    const unsigned gaddr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) int*)gtab + 4u * (unsigned)hh;
+    // The scale lives in a vector register (no SGPR operand in packed f32 code beside bf16 MFMA + LDS waves).
+    float scale;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(scale) : "v"(0.17677669529663687f * LOG2E));
+    const int C0 = ((6 * 13 + 6) * 15 + 7) * 4;
+    // K operand of chunk c, plane pl, k-step kk: lane (key n32, dims 16 kk + 8 hh ..); + SCHB c.  Two base registers per k-step:
+    // planes 0 / 1 ride on the instruction's 16-bit offset, plane 2 would not fit beside the chunk offset.
+    unsigned kb01[2], kb2[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        kb01[kk] = kaddr + (unsigned)(n32 * KROWB + (((2 * kk + hh) ^ swz(n32)) << 4));
+        kb2[kk] = kb01[kk] + 2u * PLANEB;
+    }
+    // V operand of chunk c, k-step s, plane pl, key quartet jj: a 16-lane group (dims 16 dhalf ..) reads keys 16 s + 8 jj + 4 hh + vq;
+    // + SCHB c + 1024 s
+    unsigned vb01[2], vb2[2];
+    {
+        const int li = lane & 15, vq = li >> 2, pp = li & 3, dhalf = (lane >> 4) & 1;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int row = 8 * jj + 4 * hh + vq;
+            vb01[jj] = vaddr + (unsigned)(row * KROWB + (((2 * dhalf + (pp >> 1)) ^ swz(row)) << 4) + 8 * (pp & 1));
+            vb2[jj] = vb01[jj] + 2u * PLANEB;
+        }
+    }
+    auto kbase = [&](int pl, int kk) -> unsigned { return pl == 2 ? kb2[kk] : kb01[kk] + (unsigned)(pl * PLANEB); };
+    auto vbase = [&](int pl, int jj) -> unsigned { return pl == 2 ? vb2[jj] : vb01[jj] + (unsigned)(pl * PLANEB); };
+
+    // Q of a tile: lane (query n32, dims 8 hh .. + 7 and 16 + 8 hh ..), raw; + the query's token / bias code / region
+    auto load_q = [&](int qt, float (&qf)[16], int& qsrc, int& qcode) {
+        int reg, cc;
+        const int slot = qt * 32 + n32;
+        qsrc = -2; qcode = 0;
+        if (slot < FN) {
+            qsrc = slot_info(slot, reg, cc);
+            qcode = cc | (reg << 16);
+        }
+        if (qsrc >= 0) {
+            const float4* qrow = reinterpret_cast<const float4*>(qkv + (long)qsrc * C3 + head * HD + 8 * hh);
+            const float4 a = qrow[0], c = qrow[1], d = qrow[4], e = qrow[5];
+            qf[0] = a.x; qf[1] = a.y; qf[2] = a.z; qf[3] = a.w; qf[4] = c.x; qf[5] = c.y; qf[6] = c.z; qf[7] = c.w;
+            qf[8] = d.x; qf[9] = d.y; qf[10] = d.z; qf[11] = d.w; qf[12] = e.x; qf[13] = e.y; qf[14] = e.z; qf[15] = e.w;
+        } else if (qsrc == -1) {
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                qf[kk] = qkv_bias[head * HD + 8 * hh + kk];
+                qf[8 + kk] = qkv_bias[head * HD + 16 + 8 * hh + kk];
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) qf[kk] = 0.f;
+        }
+    };
+    auto split_q = [&](const float (&qf)[16], bf16x8 (&qs)[2][3]) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            float t8[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) t8[i] = qf[8 * kk + i] * scale;
+            split8p(t8, qs[kk][0], qs[kk][1], qs[kk][2]);
+        }
+    };
+    auto k_frag = [&](int pl, int kk, unsigned off) -> bf16x8 {
+        return *(const __attribute__((address_space(3))) bf16x8*)(uintptr_t)(kbase(pl, kk) + off);
+    };
+    auto v_frag = [&](int pl, unsigned off_lo, unsigned off_hi) -> bf16x8 {
+        const bf16x4 lo = tr_read(vbase(pl, 0) + off_lo);
+        const bf16x4 hi = tr_read(vbase(pl, 1) + off_hi);
+        return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    };
+    const float PEN = -100.0f * LOG2E;
+
+    // ------------------------------------------------------------------------------------------------------------------
+    // The pipelined tile: all 13 key chunks, no max subtraction.  Returns the lane's part of the row sum; O^T in `O`.
+    // ------------------------------------------------------------------------------------------------------------------
+    auto fast_tile = [&](auto masked_tag, const bf16x8 (&qs)[2][3], const unsigned qb, const int qreg, f32x16& O) -> float {
+        constexpr bool MASKED = decltype(masked_tag)::value;
+        f32x16 S[2];
+        bf16x8 Pa[3], Pb[3];
+        float sum = 0.f, sum2 = 0.f;
+        // scores of chunk c start from the gathered bias (+ the shift-mask penalty)
+        auto init = [&](auto c_tag, f32x16& s) {
+            constexpr int c = decltype(c_tag)::value;
+            constexpr int NJ = c == SNC - 1 ? 1 : 4;
+            constexpr int KCMAX = kc_of(4 * c + NJ - 1);
+            lds_cfloat* bp = (lds_cfloat*)(uintptr_t)(qb - (unsigned)KCMAX);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    s[4 * j + e] = j < NJ ? bp[(KCMAX - kc_of(4 * c + (j < NJ ? j : 0))) / 4 + e] : 0.f;
+            if (MASKED) {
+                const __attribute__((address_space(3))) int* gp = (const __attribute__((address_space(3))) int*)(uintptr_t)gaddr;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const float pen = ((gp[8 * c + 2 * j] >> 16) != qreg) ? PEN : 0.f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) s[4 * j + e] += pen;
+                }
+            }
+        };
+        auto qk_half = [&](int c, int kk, f32x16& s) {
+            bf16x8 kf[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) kf[pl] = k_frag(pl, kk, (unsigned)(c * SCHB));
+            MFMA6_BIG(s, kf, qs[kk]);
+        };
+        // scores 8 half .. + 7 of a chunk -> exp2, row sum, three bf16 planes (nreal < 8: the rest are keys that do not exist)
+        auto soft_half = [&](const f32x16& s, int half, int nreal, bf16x8 (&ps)[3]) {
+            u32x4 a, b, c;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (2 * i < nreal) {
+                    const float x = __builtin_amdgcn_exp2f(s[8 * half + 2 * i]), y = __builtin_amdgcn_exp2f(s[8 * half + 2 * i + 1]);
+                    unsigned c1, c2;
+                    const unsigned c0 = cvt_pk_bf16(x, y);
+                    acc_f32(sum, x, c0);
+                    acc_f32(sum2, y, c0);
+                    split_rest(x, y, c0, c1, c2);
+                    a[i] = c0; b[i] = c1; c[i] = c2;
+                } else {
+                    a[i] = b[i] = c[i] = 0u;
+                }
+            }
+            ps[0] = __builtin_bit_cast(bf16x8, a); ps[1] = __builtin_bit_cast(bf16x8, b); ps[2] = __builtin_bit_cast(bf16x8, c);
+        };
+#pragma unroll
+        for (int i = 0; i < 16; ++i) O[i] = 0.f;
+        init(std::integral_constant<int, 0>{}, S[0]);
+        qk_half(0, 0, S[0]);
+        qk_half(0, 1, S[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        // c is a compile-time constant after unrolling
+#define SOC_K1_STEP(c)                                                                                        \
+        {                                                                                                     \
+            constexpr bool LAST = (c) == SNC - 1;                                                             \
+            /* phase 1 */                                                                                     \
+            if constexpr (!LAST) {                                                                            \
+                init(std::integral_constant<int, LAST ? (c) : (c) + 1>{}, S[((c) + 1) & 1]);                  \
+                qk_half((c) + 1, 0, S[((c) + 1) & 1]);                                                        \
+            }                                                                                                 \
+            if constexpr ((c) >= 1) {                                                                         \
+                bf16x8 vf[3];                                                                                 \
+                const unsigned off = (unsigned)(((c) - 1) * SCHB + 1024);                                     \
+                _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) vf[pl] = v_frag(pl, off, off);               \
+                MFMA6_BIG(O, vf, Pb);                                                                         \
+            }                                                                                                 \
+            soft_half(S[(c) & 1], 0, LAST ? 4 : 8, Pa);                                                       \
+            __builtin_amdgcn_sched_barrier(0);                                                                \
+            /* phase 2 */                                                                                     \
+            if constexpr (!LAST) qk_half((c) + 1, 1, S[((c) + 1) & 1]);                                       \
+            {                                                                                                 \
+                bf16x8 vf[3];                                                                                 \
+                const unsigned off = (unsigned)((c) * SCHB);                                                  \
+                /* the last chunk has no second key quartet: P is 0 there, its V operand re-reads the first */\
+                _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                              \
+                    vf[pl] = LAST ? (bf16x8)__builtin_shufflevector(tr_read(vbase(pl, 0) + off), tr_read(vbase(pl, 0) + off), 0, 1, 2, 3, 4, 5, 6, 7) \
+                                  : v_frag(pl, off, off);                                                     \
+                MFMA6_BIG(O, vf, Pa);                                                                         \
+            }                                                                                                 \
+            if constexpr (!LAST) soft_half(S[(c) & 1], 1, 8, Pb);                                             \
+            __builtin_amdgcn_sched_barrier(0);                                                                \
+        }
+        SOC_K1_STEP(0) SOC_K1_STEP(1) SOC_K1_STEP(2) SOC_K1_STEP(3) SOC_K1_STEP(4) SOC_K1_STEP(5) SOC_K1_STEP(6)
+        SOC_K1_STEP(7) SOC_K1_STEP(8) SOC_K1_STEP(9) SOC_K1_STEP(10) SOC_K1_STEP(11) SOC_K1_STEP(12)
+#undef SOC_K1_STEP
+        return sum + sum2;
+    };
+
+    // ------------------------------------------------------------------------------------------------------------------
+    // The generic chunk forms (runtime chunk index): the two-pass tile for scores outside the safe range, the shared tile.
+    // ------------------------------------------------------------------------------------------------------------------
+    auto chunk_scores = [&](int c, const bf16x8 (&qs)[2][3], unsigned qb, int qreg) -> f32x16 {
+        const int nj = c == SNC - 1 ? 1 : 4;
+        f32x16 s;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = 4 * c + (j < nj ? j : 0);
+            const int dy = (col * 37) >> 8, dx = col - dy * 7;
+            lds_cfloat* bp = (lds_cfloat*)(uintptr_t)(qb - (unsigned)(60 * (13 * dy + dx)));
+            float pen = 0.f;
+            if (SHIFTED && has_mask) {
+                const int gc = gtab[2 * col + hh];
+                pen = ((gc >> 16) != qreg) ? PEN : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[4 * j + e] = j < nj ? bp[e] + pen : -INFINITY;
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 kf[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) kf[pl] = k_frag(pl, kk, (unsigned)(c * SCHB));
+            MFMA6_BIG(s, kf, qs[kk]);
+        }
+        if (nj < 4) {                                          // keys that do not exist
+#pragma unroll
+            for (int i = 4; i < 16; ++i) s[i] = -INFINITY;
+        }
+        return s;
+    };
+    // P = 2^(s - m), row sum, O^T += V^T . P^T for one chunk
+    auto chunk_apply = [&](int c, const f32x16& s, float m, float& sum, f32x16& O) {
+        const bool last = c == SNC - 1;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            if (half == 1 && last) break;
+            float pv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) pv[i] = __builtin_amdgcn_exp2f(s[8 * half + i] - m);      // -inf -> 0
+            sum += ((pv[0] + pv[1]) + (pv[2] + pv[3])) + ((pv[4] + pv[5]) + (pv[6] + pv[7]));
+            bf16x8 ps[3], vf[3];
+            split8p(pv, ps[0], ps[1], ps[2]);
+            const unsigned off = (unsigned)(c * SCHB + half * 1024);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                const bf16x4 lo = tr_read(vbase(pl, 0) + off);
+                const bf16x4 hi = tr_read((last ? vbase(pl, 0) : vbase(pl, 1)) + off);
+                vf[pl] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+            MFMA6_BIG(O, vf, ps);
+        }
+    };
+    auto row_max = [&](const f32x16& s, float mx) -> float {
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) mx = fmaxf(fmaxf(mx, s[i]), s[i + 1]);      // compiler-visible (v_max3_f32): reads MFMA results
+        return mx;
+    };
+    auto slow_tile = [&](const bf16x8 (&qs)[2][3], unsigned qb, int qreg, f32x16& O) -> float {
+        float mx = -INFINITY;
+#pragma unroll 1
+        for (int c = 0; c < SNC; ++c) mx = row_max(chunk_scores(c, qs, qb, qreg), mx);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) O[i] = 0.f;
+#pragma unroll 1
+        for (int c = 0; c < SNC; ++c) {
+            const f32x16 s = chunk_scores(c, qs, qb, qreg);
+            chunk_apply(c, s, mx, sum, O);
+        }
+        return sum;
+    };
+    auto store_tile = [&](int qsrc, const f32x16& O, float tot) {
+        if (qsrc >= 0) {
+            const float inv = 1.f / tot;
+            float* orow = out + (long)qsrc * p.C + head * HD + 4 * hh;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                *reinterpret_cast<float4*>(orow + 8 * k) =
+                    make_float4(O[4 * k] * inv, O[4 * k + 1] * inv, O[4 * k + 2] * inv, O[4 * k + 3] * inv);
+        }
+    };
+
+    // ---- tiles of this wave.  Unsplit workgroup: waves 0..3 own tiles w and w + 4, waves 4..7 tile w + 4 (8..11), tile 12
+    //      (8 queries) is shared below.  A part of a split pair: tiles qpart + qsplit k, dealt k = wave, wave + 8, ...
+    const bool share_last = qsplit == 1;
+    int qt, qstep, qend;
+    if (share_last) {
+        qt = wave < 4 ? wave : wave + 4;
+        qstep = 4;
+        qend = wave < 4 ? 8 : SNQ - 1;
+    } else {
+        qt = qpart + qsplit * wave;
+        qstep = (THREADS / 64) * qsplit;
+        qend = SNQ;
+    }
+    // `carry`: the NEXT tile's raw Q in the waves that own two tiles (waves 0..3 of an unsplit workgroup, any wave of a part), and in
+    // waves 4..7 of an unsplit workgroup -- which own one tile and never prefetch -- their partial O of the shared tile: one set of
+    // 16 registers for both.
+    float carry[16];
+    float part_sum = 0.f, part_mx = 0.f;
+    float* xsum = reinterpret_cast<float*>(gtab + FNT * 4);          // [4 waves][8 queries], in the slack behind the group table
+    auto shared_partial = [&](const bool use_max) {
+        // tile 12 (queries 384..391 in lanes n32 < 8): wave w takes key chunks w - 4, w, w + 4 (, 12)
+        float qf[16];
+        int qsrc, qcode;
+        load_q(SNQ - 1, qf, qsrc, qcode);
+        bf16x8 qs[2][3];
+        split_q(qf, qs);
+        const unsigned sh_qb = tbase + (unsigned)((qcode & 0xFFFF) + C0 - 32 + 16 * hh);
+        const int sh_qreg = qcode >> 16;
+        f32x16 O;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) O[i] = 0.f;
+        float mx = 0.f, sum = 0.f;
+        if (use_max) {
+            mx = -INFINITY;
+#pragma unroll 1
+            for (int c = wave - 4; c < SNC; c += 4) mx = row_max(chunk_scores(c, qs, sh_qb, sh_qreg), mx);
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+        }
+#pragma unroll 1
+        for (int c = wave - 4; c < SNC; c += 4) {
+            const f32x16 sc = chunk_scores(c, qs, sh_qb, sh_qreg);
+            chunk_apply(c, sc, mx, sum, O);
+        }
+        part_sum = sum + __shfl_xor(sum, 32);
+        if (use_max) part_mx = mx;                          // (0 otherwise: not a value that lives across the tile loop)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) carry[i] = O[i];
+    };
+    const bool light = share_last && wave >= 4;
+    if (light) {
+        // FIRST, not last: these chunk-at-a-time passes stall on every LDS read and MFMA chain, which costs nothing while the SIMD's
+        // other wave streams its whole tiles -- at the end of the workgroup they were 12-17 k cycles with the other wave idle
+        shared_partial(false);
+        if (lane < 8) xsum[(wave - 4) * 8 + lane] = part_sum;
+    }
+    STAMP(stamp_slot); ++stamp_slot;
+    {
+        float q0[16];
+        int qsrc_n = -2, qcode_n = 0;
+        bf16x8 qs[2][3];
+        if (qt < qend) {
+            load_q(qt, q0, qsrc_n, qcode_n);
+            split_q(q0, qs);
+        }
+        for (; qt < qend; qt += qstep) {
+            const int qsrc = qsrc_n;
+            const unsigned qb = tbase + (unsigned)((qcode_n & 0xFFFF) + C0 - 32 + 16 * hh);
+            const int qreg = qcode_n >> 16;
+            const bool more = qt + qstep < qend;                             // never in waves 4..7 of an unsplit workgroup
+            if (more) load_q(qt + qstep, carry, qsrc_n, qcode_n);            // next tile's Q: in flight behind this tile
+            f32x16 O;
+            float sum = (SHIFTED && has_mask) ? fast_tile(std::true_type{}, qs, qb, qreg, O) : fast_tile(std::false_type{}, qs, qb, qreg, O);
+            float tot = sum + __shfl_xor(sum, 32);
+            // 2^score without a max is legal iff the row sum says so (NaN fails the test too); lanes of queries that do not exist
+            // (the 24 surplus lanes of tile 12 in a split pair: Q = 0, and with a shift mask possibly every key masked) do not vote
+#if defined(SOC_K1_DBG) && (SOC_K1_DBG == 1 || SOC_K1_DBG >= 3)
+            if (false) {
+#elif defined(SOC_K1_DBG) && SOC_K1_DBG == 2
+            if (true) {
+#else
+            if (!__all(qsrc == -2 || (tot > 0x1p-60f && tot < 0x1p60f))) {
+#endif
+                sum = slow_tile(qs, qb, qreg, O);
+                tot = sum + __shfl_xor(sum, 32);
+            }
+#if defined(SOC_K1_DBG) && SOC_K1_DBG == 3       // raw O, no normalisation
+            store_tile(qsrc, O, 1.0f);
+#elif defined(SOC_K1_DBG) && SOC_K1_DBG == 4     // the row sum in every dim
+            { f32x16 T; for (int i = 0; i < 16; ++i) T[i] = tot; store_tile(qsrc, T, 1.0f); }
+#else
+            store_tile(qsrc, O, tot);
+#endif
+            if (more) split_q(carry, qs);
+            STAMP(stamp_slot); ++stamp_slot;
+        }
+    }
+
+    if (share_last) {
+        // The shared tile's partial (O, sum) of waves 4..7 are merged through LDS (the scratch aliases the K planes: every wave must
+        // be done with them first).  Like the whole tiles it was done WITHOUT a max; the four partial row sums sit in a few words
+        // beside the group table, and only if their total says that was not legal the four waves redo their chunks with the max of
+        // THEIR chunks subtracted (the K / V planes are still intact then) and the merge rescales the parts.
+        __syncthreads();                                   // every wave has finished its whole tiles; the partial sums are there
+        bool legal = true;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float tq = (xsum[q] + xsum[8 + q]) + (xsum[16 + q] + xsum[24 + q]);
+            legal = legal && tq > 0x1p-60f && tq < 0x1p60f;             // (NaN fails too)
+        }
+        if (!legal) {                                      // block-uniform: every thread read the same 32 words
+            if (light) shared_partial(true);
+            __syncthreads();                               // ... and now every wave is done with the K planes
+        }
+        if (light && n32 < 8) {
+            float* pw = Pw + (wave - 4) * SQ_PWS;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                *reinterpret_cast<float4*>(pw + n32 * SQ_PRS + 8 * k + 4 * hh) = make_float4(carry[4 * k], carry[4 * k + 1], carry[4 * k + 2], carry[4 * k + 3]);
+            if (hh == 0) {
+                pw[8 * SQ_PRS + n32] = part_mx;
+                pw[8 * SQ_PRS + 8 + n32] = part_sum;
+            }
+        }
+        __syncthreads();
+        if (tid < 8 * 32) {
+            const int q = tid >> 5, d = tid & 31;
+            int reg, cc;
+            const int osrc = slot_info((SNQ - 1) * 32 + q, reg, cc);
+            if (osrc >= 0) {
+                float M = -INFINITY;
+#pragma unroll
+                for (int w4 = 0; w4 < 4; ++w4) M = fmaxf(M, Pw[w4 * SQ_PWS + 8 * SQ_PRS + q]);
+                float num = 0.f, den = 0.f;
+#pragma unroll
+                for (int w4 = 0; w4 < 4; ++w4) {
+                    const float f = __builtin_amdgcn_exp2f(Pw[w4 * SQ_PWS + 8 * SQ_PRS + q] - M);       // 1 when no max was taken
+                    num += f * Pw[w4 * SQ_PWS + q * SQ_PRS + d];
+                    den += f * Pw[w4 * SQ_PWS + 8 * SQ_PRS + 8 + q];
+                }
+                out[(long)osrc * p.C + head * HD + d] = num / den;
+            }
+        }
+    }
+    // The waves retire together (the co-residence rule of the bf16-MFMA kernels).
+    __syncthreads();
+    STAMP(stamp_slot);
+    STAMP_RT(31);
+}
+
 int launch_full(const float* qkv, const float* qkv_bias, const float* table, float* out,
                 const WinParams& p, long blocks, hipStream_t st) {
     const size_t lds = FULL_LDS_BYTES;
@@ -1380,6 +2015,29 @@ int launch_split(const float* qkv, const float* qkv_bias, const float* table, fl
                            qkv_bias, table, out, p);
     else
         hipLaunchKernelGGL((win_attn3d_split_kernel<false>), dim3((unsigned)blocks), dim3(THREADS), lds, st, qkv,
+                           qkv_bias, table, out, p);
+    return soc_check_launch();
+}
+
+int launch_stream(const float* qkv, const float* qkv_bias, const float* table, float* out,
+                  const WinParams& p, long blocks, hipStream_t st) {
+    const size_t lds = SPLIT_LDS_BYTES;
+    static std::atomic<bool> attr_set[SOC_MAX_DEVICES];
+    const int dev = soc_current_device();
+    if (dev < 0) return SOC_ELAUNCH;
+    if (!attr_set[dev].load(std::memory_order_acquire)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(win_attn3d_stream_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(win_attn3d_stream_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return SOC_ELAUNCH;
+        attr_set[dev].store(true, std::memory_order_release);
+    }
+    if (p.shifted)
+        hipLaunchKernelGGL((win_attn3d_stream_kernel<true>), dim3((unsigned)blocks), dim3(THREADS), lds, st, qkv,
+                           qkv_bias, table, out, p);
+    else
+        hipLaunchKernelGGL((win_attn3d_stream_kernel<false>), dim3((unsigned)blocks), dim3(THREADS), lds, st, qkv,
                            qkv_bias, table, out, p);
     return soc_check_launch();
 }
@@ -1430,11 +2088,15 @@ struct CostModel { double sigma, share; };
 constexpr CostModel COST_F32{0.86, 0.27};
 // split kernel: a tile-slot is ~2.6x shorter, staging (global-load latency + the operand split) is not
 constexpr CostModel COST_SPLIT{2.3, 0.6};
+// streaming kernel (round 6): the unit is one 32-query tile on one SIMD (13 chunks, ~11 k cycles); an unsplit workgroup is
+// staging + 3 tiles per SIMD + the shared 8-query tile
+constexpr CostModel COST_STREAM{1.2, 0.35};
 
 double simulate_tail(long pairs, int NT, int cus, int n_main, int q, bool shared_last, std::vector<double>& heap,
                      const CostModel& cm) {
     const double SIGMA = cm.sigma, SHARE = cm.share;
-    const double full = SIGMA + (shared_last ? NT / 4.0 + SHARE : (double)((NT + 3) / 4));
+    // an unsplit workgroup: the shared last tile is a fraction of a tile-slot on top of the whole ones
+    const double full = SIGMA + (shared_last ? (NT - 1) / 4 + ((NT - 1) % 4) / 4.0 + (NT == 25 ? 0.25 : 0.0) + SHARE : (double)((NT + 3) / 4));
     const long rounds = n_main / cus, extra = n_main % cus;
     heap.assign(cus, rounds * full);
     for (long i = 0; i < extra; ++i) heap[i] += full;
@@ -1457,11 +2119,11 @@ double simulate_tail(long pairs, int NT, int cus, int n_main, int q, bool shared
     return makespan + 1e-4 * (double)(n_main + (pairs - n_main) * q);
 }
 
-Plan plan_schedule(long pairs, int NT, int cus, bool shared_last, bool split) {
+Plan plan_schedule(long pairs, int NT, int cus, bool shared_last, int split) {      // split: 0 f32 form, 1 streaming, 2 round-3 split form
     static std::mutex mu;
-    static std::map<std::tuple<long, int, int, bool, bool>, Plan> cache;     // one entry per launch geometry
+    static std::map<std::tuple<long, int, int, bool, int>, Plan> cache;     // one entry per launch geometry
     const auto key = std::make_tuple(pairs, NT, cus, shared_last, split);
-    const CostModel& cm = split ? COST_SPLIT : COST_F32;
+    const CostModel& cm = split == 1 ? COST_STREAM : split == 2 ? COST_SPLIT : COST_F32;
     {
         std::lock_guard<std::mutex> lk(mu);
         auto it = cache.find(key);
@@ -1522,9 +2184,10 @@ extern "C" int soc_win_attn3d_f32(const float* qkv, const float* qkv_bias, const
     if ((long)B * D * H * W * 3 * C >= (1L << 31)) return SOC_EUNSUPPORTED;  // int token offsets
     const long pairs = (long)B * p.nwd * p.nwh * p.nww * n_heads;
     const bool full_window = win_d == 8 && win_h == 7 && win_w == 7 && tab_d == 8 && tab_h == 7 && tab_w == 7;
-    const bool split = full_window && split_arith != 0;     // full 8x7x7 windows only; a launch argument, not process state
+    // full 8x7x7 windows only; a launch argument, not process state: 1 = the streaming form (round 6), 2 = the round-3 split form
+    const int split = !full_window ? 0 : split_arith == 2 ? 2 : split_arith != 0 ? 1 : 0;
     {
-        const Plan pl = plan_schedule(pairs, p.NT, num_cus((hipStream_t)stream), full_window, split);
+        const Plan pl = plan_schedule(pairs, split == 1 ? SNQ : p.NT, num_cus((hipStream_t)stream), full_window, split);
         p.n_main = pl.n_main;
         p.qsplit = pl.qsplit;
     }
@@ -1539,7 +2202,9 @@ extern "C" int soc_win_attn3d_f32(const float* qkv, const float* qkv_bias, const
     hipStream_t st = (hipStream_t)stream;
     // key/query tiles are a compile-time constant (fully unrolled MFMA schedule); a window with
     // fewer tokens runs on the next larger instantiation with the surplus keys masked out.
-    if (split)
+    if (split == 1)
+        return launch_stream(qkv, qkv_bias, bias_table, out, p, blocks, st);
+    if (split == 2)
         return launch_split(qkv, qkv_bias, bias_table, out, p, blocks, st);
     if (full_window)
         return launch_full(qkv, qkv_bias, bias_table, out, p, blocks, st);

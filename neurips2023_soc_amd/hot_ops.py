@@ -382,6 +382,14 @@ def clamp_window(size: Sequence[int], window: Sequence[int], shift: Sequence[int
     return tuple(w), tuple(s)
 
 
+def _k1_form() -> int:
+    """The `split_arith` launch argument of K1: 0 = f32-input MFMA, 1 = the bf16-split STREAMING form (round 6: 32-query tiles,
+    key chunks of 32, softmax between the MFMAs), 2 = round 3's split form (SOC_K1_FORM=r3: kept for A/B runs and its tests)."""
+    if not k1_split_enabled():
+        return 0
+    return 2 if _os.environ.get("SOC_K1_FORM", "") == "r3" else 1
+
+
 def window_attention3d(qkv: Tensor, qkv_bias: Tensor, bias_table: Tensor, n_heads: int,
                        window: Sequence[int], shift: Sequence[int]) -> Tensor:
     """K1.  qkv [B,D,H,W,3C] (token layout, un-padded) -> attention output [B,D,H,W,C].
@@ -402,7 +410,7 @@ def window_attention3d(qkv: Tensor, qkv_bias: Tensor, bias_table: Tensor, n_head
     with _timed("win_attn3d", 4.0 * n_tok * n_tok * (C // n_heads) * n_win * n_heads):
         code = lib.soc_win_attn3d_f32(qkv.data_ptr(), qkv_bias.data_ptr(), bias_table.data_ptr(),
                                       out.data_ptr(), B, D, H, W, C, n_heads, *win, *sh, *window,
-                                      int(k1_split_enabled()), _stream())
+                                      _k1_form(), _stream())
     _lib.check(code, "soc_win_attn3d_f32")
     return out
 

@@ -137,6 +137,19 @@ def test_no_scratch_inside_the_mfma_stream(unit):
     src, kernels, meta = unit
     for name, body in kernels.items():
         ms = [m.start() for m in BF16_MFMA_ISA.finditer(body)]
+        if "win_attn3d_stream_kernel" in name:
+            # K1's streaming form (round 6) has no LDS-DMA ring; its MFMAs come in three places (the shared tile's chunks, the
+            # unrolled tile, the two-pass tile) with the tile loop's entry and exit between them, where a few values that live
+            # ACROSS the loop (the shared tile's partial row sum, lane ids) may pass through scratch.  Inside a run of MFMAs --
+            # the unrolled tile is ~300 of them within ~4 500 lines -- nothing may.
+            lines = body.splitlines()
+            mf = [i for i, ln in enumerate(lines) if BF16_MFMA_ISA.search(ln)]
+            for i, ln in enumerate(lines):
+                if "scratch_" in ln:
+                    near = sum(1 for j in mf if abs(j - i) <= 200)
+                    assert near <= 6, (src, name, i, ln.strip(), near)
+            assert meta[name]["private_segment_fixed_size"] <= 32, (src, name, meta[name])
+            continue
         assert "scratch_" not in body[ms[0]:ms[-1]], (src, name)
         # behind the last MFMA (the epilogue of a range, inside the span loop): nothing either, except K24's GELU epilogue at
         # K = 384 with 16 / 18 column tiles (no layer of the shipped configs: stage-2 fc1 runs in K23), whose erf polynomial

@@ -30,7 +30,8 @@ def build(flags, tag):
     so = f"/tmp/libk1_{tag}.so"
     subprocess.run(["hipcc", "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17", *flags,
                     "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "neurips2023_soc_amd/csrc"),
-                    "-o", so, os.path.join(ROOT, "neurips2023_soc_amd/csrc/win_attn3d.hip")], check=True)
+                    "-o", so, os.path.join(ROOT, "neurips2023_soc_amd/csrc/win_attn3d.hip"),
+                    os.path.join(ROOT, "neurips2023_soc_amd/csrc/soc_capi.hip")], check=True)
     return C.CDLL(so)
 
 
