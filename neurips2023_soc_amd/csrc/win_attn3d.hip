@@ -29,6 +29,7 @@
 #include <mutex>
 #include <tuple>
 #include <type_traits>
+#include <utility>
 #include <vector>
 
 namespace {
@@ -1432,6 +1433,34 @@ __device__ __forceinline__ void split8p(const float (&v)[8], bf16x8& h0, bf16x8&
     h0 = __builtin_bit_cast(bf16x8, a); h1 = __builtin_bit_cast(bf16x8, b); h2 = __builtin_bit_cast(bf16x8, c);
 }
 
+// Compile-time lists of key chunks (the unrolled tile walks one) and a compile-time loop.
+template <int... C>
+struct ChunkList {
+    static constexpr int n = sizeof...(C);
+    static constexpr int at(int i) {
+        constexpr int a[] = {C...};
+        return i >= 0 && i < n ? a[i] : -1;
+    }
+};
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// LDS reads at (per-lane base register) + (compile-time byte offset): written as pointer arithmetic on an LDS pointer, so that the
+// constant lands in the instruction's 16-bit offset field (plain unsigned address sums made hipcc add them in a VALU instruction).
+typedef __attribute__((address_space(3))) char lds_char;
+__device__ __forceinline__ bf16x4 tr_read_at(const unsigned base, const int off) {
+    return __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)((lds_char*)(uintptr_t)base + off)));
+}
+__device__ __forceinline__ bf16x8 b128_read_at(const unsigned base, const int off) {
+    return *(const __attribute__((address_space(3))) bf16x8*)((lds_char*)(uintptr_t)base + off);
+}
+
 template <bool SHIFTED>
 __global__ __launch_bounds__(THREADS, 2) void win_attn3d_stream_kernel(
     const float* __restrict__ qkv, const float* __restrict__ qkv_bias,
@@ -1595,8 +1624,12 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_stream_kernel(
             vb2[jj] = vb01[jj] + 2u * PLANEB;
         }
     }
-    auto kbase = [&](int pl, int kk) -> unsigned { return pl == 2 ? kb2[kk] : kb01[kk] + (unsigned)(pl * PLANEB); };
-    auto vbase = [&](int pl, int jj) -> unsigned { return pl == 2 ? vb2[jj] : vb01[jj] + (unsigned)(pl * PLANEB); };
+    auto k_read = [&](int pl, int kk, int off) -> bf16x8 {            // K fragment of plane pl, k-step kk at byte offset off
+        return pl == 2 ? b128_read_at(kb2[kk], off) : b128_read_at(kb01[kk], pl * PLANEB + off);
+    };
+    auto v_read = [&](int pl, int jj, int off) -> bf16x4 {            // V key quartet jj of plane pl at byte offset off
+        return pl == 2 ? tr_read_at(vb2[jj], off) : tr_read_at(vb01[jj], pl * PLANEB + off);
+    };
 
     // Q of a tile: lane (query n32, dims 8 hh .. + 7 and 16 + 8 hh ..), raw; + the query's token / bias code / region
     auto load_q = [&](int qt, float (&qf)[16], int& qsrc, int& qcode) {
@@ -1632,110 +1665,173 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_stream_kernel(
             split8p(t8, qs[kk][0], qs[kk][1], qs[kk][2]);
         }
     };
-    auto k_frag = [&](int pl, int kk, unsigned off) -> bf16x8 {
-        return *(const __attribute__((address_space(3))) bf16x8*)(uintptr_t)(kbase(pl, kk) + off);
-    };
-    auto v_frag = [&](int pl, unsigned off_lo, unsigned off_hi) -> bf16x8 {
-        const bf16x4 lo = tr_read(vbase(pl, 0) + off_lo);
-        const bf16x4 hi = tr_read(vbase(pl, 1) + off_hi);
-        return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    };
+    auto k_frag = [&](int pl, int kk, unsigned off) -> bf16x8 { return k_read(pl, kk, (int)off); };
     const float PEN = -100.0f * LOG2E;
 
     // ------------------------------------------------------------------------------------------------------------------
     // The pipelined tile: all 13 key chunks, no max subtraction.  Returns the lane's part of the row sum; O^T in `O`.
     // ------------------------------------------------------------------------------------------------------------------
-    auto fast_tile = [&](auto masked_tag, const bf16x8 (&qs)[2][3], const unsigned qb, const int qreg, f32x16& O) -> float {
+    auto fast_tile = [&](auto masked_tag, auto list_tag, const bf16x8 (&qs)[2][3], const unsigned qb, const int qreg, f32x16& O) -> float {
         constexpr bool MASKED = decltype(masked_tag)::value;
+        using L = decltype(list_tag);             // the key chunks this call walks: all 13 (a whole tile) or a wave's share of the shared tile
+        // The instruction stream is laid out by hand, one MFMA per SLOT: [1 MFMA | <= 1-2 LDS reads | 5 vector instructions] and a
+        // scheduling barrier behind every slot.  Left to the scheduler the unrolled tile came out as runs of 6-7 back-to-back MFMAs
+        // between runs of ~35 vector instructions, and neither run overlaps with anything (tools/microbench/mfma32_valu.hip: beside
+        // v_mfma_f32_32x32x16_bf16 about four vector instructions per MFMA ride for free only when they sit BETWEEN the MFMAs).
+        // A phase = 12 slots = 6 P.V MFMAs (their V fragments and P planes were made a phase earlier) + 6 Q.K^T MFMAs of the next
+        // chunk, beside the exp / row sum / three-way split of 8 scores (4 pairs x 3 segments of 5 instructions); every LDS read
+        // is issued a phase ahead of its MFMA.
         f32x16 S[2];
-        bf16x8 Pa[3], Pb[3];
+        u32x4 Pa[3], Pb[3];                       // P planes of a k-step: packed bf16 pairs
+        bf16x8 kf[3], kfn[3];                     // K fragments: this phase's Q.K^T k-step, the next phase's
+        bf16x4 vlo[3], vhi[3], vlon[3], vhin[3];  // V fragments (two key quartets per plane): this phase's P.V k-step, the next phase's
         float sum = 0.f, sum2 = 0.f;
-        // scores of chunk c start from the gathered bias (+ the shift-mask penalty)
-        auto init = [&](auto c_tag, f32x16& s) {
+        float px = 0.f, py = 0.f, prx = 0.f, pry = 0.f;
+        unsigned pc0 = 0u, pc1 = 0u;
+        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};       // the six products, smallest first
+        auto segA = [&](const f32x16& s, int e) {
+            px = __builtin_amdgcn_exp2f(s[e]);
+            py = __builtin_amdgcn_exp2f(s[e + 1]);
+            pc0 = cvt_pk_bf16(px, py);
+            acc_f32(sum, px, pc0);
+            acc_f32(sum2, py, pc0);
+        };
+        auto segB = [&]() {
+            prx = sub_f32(px, __builtin_bit_cast(float, pc0 << 16));
+            pry = sub_f32(py, __builtin_bit_cast(float, pc0 & 0xffff0000u));
+            pc1 = cvt_pk_bf16(prx, pry);
+        };
+        auto segC = [&](u32x4 (&P)[3], int i) {
+            const float a2 = sub_f32(prx, __builtin_bit_cast(float, pc1 << 16));
+            const float b2 = sub_f32(pry, __builtin_bit_cast(float, pc1 & 0xffff0000u));
+            P[0][i] = pc0; P[1][i] = pc1; P[2][i] = cvt_pk_bf16(a2, b2);
+        };
+        // segment k % 3 of pair k / 3 of the 8 scores s[8 half ..]; pairs >= npairs are keys that do not exist (P = 0)
+        auto soft_slot = [&](const f32x16& s, int half, int k, int npairs, u32x4 (&P)[3]) {
+            const int i = k / 3, seg = k % 3;
+            if (i < npairs) {
+                if (seg == 0) segA(s, 8 * half + 2 * i);
+                else if (seg == 1) segB();
+                else segC(P, i);
+            } else if (seg == 0) {
+                P[0][i] = 0u; P[1][i] = 0u; P[2][i] = 0u;
+            }
+        };
+        auto mf_pv = [&](int k, const bf16x4 (&lo)[3], const bf16x4 (&hi)[3], const u32x4 (&P)[3]) {
+            const bf16x4 l = lo[PA[k]], h = hi[PA[k]];
+            const bf16x8 vf = {l[0], l[1], l[2], l[3], h[0], h[1], h[2], h[3]};
+            O = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, __builtin_bit_cast(bf16x8, P[PB[k]]), O, 0, 0, 0);
+        };
+        auto mf_qk = [&](int k, f32x16& s, const bf16x8 (&kfr)[3], int kk) {
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[PA[k]], qs[kk][PB[k]], s, 0, 0, 0);
+        };
+        // bias of key column j of chunk c into scores 4 j .. 4 j + 3 (+ the shift-mask penalty)
+        auto init_j = [&](auto c_tag, int j, f32x16& s) {
             constexpr int c = decltype(c_tag)::value;
             constexpr int NJ = c == SNC - 1 ? 1 : 4;
             constexpr int KCMAX = kc_of(4 * c + NJ - 1);
             lds_cfloat* bp = (lds_cfloat*)(uintptr_t)(qb - (unsigned)KCMAX);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    s[4 * j + e] = j < NJ ? bp[(KCMAX - kc_of(4 * c + (j < NJ ? j : 0))) / 4 + e] : 0.f;
-            if (MASKED) {
+            for (int e = 0; e < 4; ++e) s[4 * j + e] = j < NJ ? bp[(KCMAX - kc_of(4 * c + (j < NJ ? j : 0))) / 4 + e] : 0.f;
+        };
+        auto pen_j = [&](auto c_tag, int j, f32x16& s) {
+            constexpr int c = decltype(c_tag)::value;
+            constexpr int NJ = c == SNC - 1 ? 1 : 4;
+            if (MASKED && j < NJ) {
                 const __attribute__((address_space(3))) int* gp = (const __attribute__((address_space(3))) int*)(uintptr_t)gaddr;
+                const float pen = ((gp[8 * c + 2 * j] >> 16) != qreg) ? PEN : 0.f;
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    const float pen = ((gp[8 * c + 2 * j] >> 16) != qreg) ? PEN : 0.f;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) s[4 * j + e] += pen;
-                }
+                for (int e = 0; e < 4; ++e) s[4 * j + e] += pen;
             }
         };
-        auto qk_half = [&](int c, int kk, f32x16& s) {
-            bf16x8 kf[3];
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) kf[pl] = k_frag(pl, kk, (unsigned)(c * SCHB));
-            MFMA6_BIG(s, kf, qs[kk]);
-        };
-        // scores 8 half .. + 7 of a chunk -> exp2, row sum, three bf16 planes (nreal < 8: the rest are keys that do not exist)
-        auto soft_half = [&](const f32x16& s, int half, int nreal, bf16x8 (&ps)[3]) {
-            u32x4 a, b, c;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (2 * i < nreal) {
-                    const float x = __builtin_amdgcn_exp2f(s[8 * half + 2 * i]), y = __builtin_amdgcn_exp2f(s[8 * half + 2 * i + 1]);
-                    unsigned c1, c2;
-                    const unsigned c0 = cvt_pk_bf16(x, y);
-                    acc_f32(sum, x, c0);
-                    acc_f32(sum2, y, c0);
-                    split_rest(x, y, c0, c1, c2);
-                    a[i] = c0; b[i] = c1; c[i] = c2;
-                } else {
-                    a[i] = b[i] = c[i] = 0u;
-                }
-            }
-            ps[0] = __builtin_bit_cast(bf16x8, a); ps[1] = __builtin_bit_cast(bf16x8, b); ps[2] = __builtin_bit_cast(bf16x8, c);
-        };
+#define SOC_SLOT_END __builtin_amdgcn_sched_barrier(0)
 #pragma unroll
         for (int i = 0; i < 16; ++i) O[i] = 0.f;
-        init(std::integral_constant<int, 0>{}, S[0]);
-        qk_half(0, 0, S[0]);
-        qk_half(0, 1, S[0]);
-        __builtin_amdgcn_sched_barrier(0);
-        // c is a compile-time constant after unrolling
-#define SOC_K1_STEP(c)                                                                                        \
-        {                                                                                                     \
-            constexpr bool LAST = (c) == SNC - 1;                                                             \
-            /* phase 1 */                                                                                     \
-            if constexpr (!LAST) {                                                                            \
-                init(std::integral_constant<int, LAST ? (c) : (c) + 1>{}, S[((c) + 1) & 1]);                  \
-                qk_half((c) + 1, 0, S[((c) + 1) & 1]);                                                        \
-            }                                                                                                 \
-            if constexpr ((c) >= 1) {                                                                         \
-                bf16x8 vf[3];                                                                                 \
-                const unsigned off = (unsigned)(((c) - 1) * SCHB + 1024);                                     \
-                _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) vf[pl] = v_frag(pl, off, off);               \
-                MFMA6_BIG(O, vf, Pb);                                                                         \
-            }                                                                                                 \
-            soft_half(S[(c) & 1], 0, LAST ? 4 : 8, Pa);                                                       \
-            __builtin_amdgcn_sched_barrier(0);                                                                \
-            /* phase 2 */                                                                                     \
-            if constexpr (!LAST) qk_half((c) + 1, 1, S[((c) + 1) & 1]);                                       \
-            {                                                                                                 \
-                bf16x8 vf[3];                                                                                 \
-                const unsigned off = (unsigned)((c) * SCHB);                                                  \
-                /* the last chunk has no second key quartet: P is 0 there, its V operand re-reads the first */\
-                _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                              \
-                    vf[pl] = LAST ? (bf16x8)__builtin_shufflevector(tr_read(vbase(pl, 0) + off), tr_read(vbase(pl, 0) + off), 0, 1, 2, 3, 4, 5, 6, 7) \
-                                  : v_frag(pl, off, off);                                                     \
-                MFMA6_BIG(O, vf, Pa);                                                                         \
-            }                                                                                                 \
-            if constexpr (!LAST) soft_half(S[(c) & 1], 1, 8, Pb);                                             \
-            __builtin_amdgcn_sched_barrier(0);                                                                \
+        // ---- prologue: scores of the first chunk (nothing to run beside them), then what the first step expects to find:
+        //      K(second chunk, k-step 0) and the second chunk's bias
+        {
+            using C0T = std::integral_constant<int, L::at(0)>;
+            using C1T = std::integral_constant<int, (L::n > 1) ? L::at(1) : L::at(0)>;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) init_j(C0T{}, j, S[0]);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) { kf[pl] = k_read(pl, 0, C0T::value * SCHB); kfn[pl] = k_read(pl, 1, C0T::value * SCHB); }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pen_j(C0T{}, j, S[0]);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) mf_qk(k, S[0], kf, 0);
+            if constexpr (L::n > 1) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) init_j(C1T{}, j, S[1]);
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) kf[pl] = k_read(pl, 0, C1T::value * SCHB);
+            }
+#pragma unroll
+            for (int k = 0; k < 6; ++k) mf_qk(k, S[0], kfn, 1);
+            SOC_SLOT_END;
         }
-        SOC_K1_STEP(0) SOC_K1_STEP(1) SOC_K1_STEP(2) SOC_K1_STEP(3) SOC_K1_STEP(4) SOC_K1_STEP(5) SOC_K1_STEP(6)
-        SOC_K1_STEP(7) SOC_K1_STEP(8) SOC_K1_STEP(9) SOC_K1_STEP(10) SOC_K1_STEP(11) SOC_K1_STEP(12)
-#undef SOC_K1_STEP
+        static_for<L::n>([&](auto i_tag) {
+            constexpr int I = decltype(i_tag)::value;
+            constexpr int c = L::at(I), cn = L::at(I + 1), cnn = L::at(I + 2);      // this chunk, the next two (-1: none)
+            constexpr bool FIRST = I == 0, PARTIAL = c == SNC - 1, NEXT = cn >= 0, NEXT2 = cnn >= 0;
+            using CNT = std::integral_constant<int, NEXT ? cn : c>;
+            using CNNT = std::integral_constant<int, NEXT2 ? cnn : c>;
+            f32x16& cur = S[I & 1];
+            f32x16& nxt = S[(I + 1) & 1];
+            // ---- phase 1: P.V(previous chunk, k-step 1) | Q.K^T(next chunk, k-step 0); scores 0..7 of this chunk -> Pa; reads for phase 2
+#pragma unroll
+            for (int k = 0; k < 12; ++k) {
+                if (k < 6) {
+                    if constexpr (!FIRST) mf_pv(k, vlo, vhi, Pb);
+                    // V(c, k-step 0); chunk 12 has no second key quartet (P is 0 there): its operand re-reads the first
+                    if (k % 2 == 0) vlon[k / 2] = v_read(k / 2, 0, c * SCHB);
+                    else vhin[k / 2] = v_read(k / 2, PARTIAL ? 0 : 1, c * SCHB);
+                    if constexpr (NEXT) {
+                        if (k < 4) pen_j(CNT{}, k, nxt);
+                    }
+                } else {
+                    if constexpr (NEXT) {
+                        mf_qk(k - 6, nxt, kf, 0);
+                        if (k < 9) kfn[k - 6] = k_read(k - 6, 1, cn * SCHB);
+                    }
+                }
+                soft_slot(cur, 0, k, PARTIAL ? 2 : 4, Pa);
+                SOC_SLOT_END;
+            }
+            // ---- phase 2: P.V(c, k-step 0) | Q.K^T(next chunk, k-step 1); scores 8..15 -> Pb; reads for the next phase 1
+#pragma unroll
+            for (int k = 0; k < 12; ++k) {
+                if (k < 6) {
+                    mf_pv(k, vlon, vhin, Pa);
+                    if constexpr (!PARTIAL) {
+                        if (k % 2 == 0) vlo[k / 2] = v_read(k / 2, 0, c * SCHB + 1024);
+                        else vhi[k / 2] = v_read(k / 2, 1, c * SCHB + 1024);
+                    }
+                } else {
+                    if constexpr (NEXT) mf_qk(k - 6, nxt, kfn, 1);
+                    if constexpr (NEXT2) {
+                        if (k < 9) kf[k - 6] = k_read(k - 6, 0, cnn * SCHB);
+                        // bias of the chunk after next into the registers this chunk's scores leave: 0..11 are free by now, 12..15
+                        // after slot 9
+                        if (k == 6) init_j(CNNT{}, 0, cur);
+                        if (k == 7) init_j(CNNT{}, 1, cur);
+                        if (k == 8) init_j(CNNT{}, 2, cur);
+                    }
+                }
+                if constexpr (!PARTIAL) soft_slot(cur, 1, k, 4, Pb);
+                if constexpr (NEXT2) {
+                    if (k == 11) init_j(CNNT{}, 3, cur);
+                }
+                SOC_SLOT_END;
+            }
+            // ---- the list ends on a whole chunk: its second k-step is still due
+            if constexpr (!NEXT && !PARTIAL) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) mf_pv(k, vlo, vhi, Pb);
+                SOC_SLOT_END;
+            }
+        });
+#undef SOC_SLOT_END
         return sum + sum2;
     };
 
@@ -1786,8 +1882,8 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_stream_kernel(
             const unsigned off = (unsigned)(c * SCHB + half * 1024);
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) {
-                const bf16x4 lo = tr_read(vbase(pl, 0) + off);
-                const bf16x4 hi = tr_read((last ? vbase(pl, 0) : vbase(pl, 1)) + off);
+                const bf16x4 lo = v_read(pl, 0, (int)off);
+                const bf16x4 hi = last ? v_read(pl, 0, (int)off) : v_read(pl, 1, (int)off);
                 vf[pl] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             }
             MFMA6_BIG(O, vf, ps);
@@ -1843,7 +1939,7 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_stream_kernel(
     float carry[16];
     float part_sum = 0.f, part_mx = 0.f;
     float* xsum = reinterpret_cast<float*>(gtab + FNT * 4);          // [4 waves][8 queries], in the slack behind the group table
-    auto shared_partial = [&](const bool use_max) {
+    auto shared_partial = [&](const bool use_max) __attribute__((always_inline)) {
         // tile 12 (queries 384..391 in lanes n32 < 8): wave w takes key chunks w - 4, w, w + 4 (, 12)
         float qf[16];
         int qsrc, qcode;
@@ -1861,11 +1957,21 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_stream_kernel(
 #pragma unroll 1
             for (int c = wave - 4; c < SNC; c += 4) mx = row_max(chunk_scores(c, qs, sh_qb, sh_qreg), mx);
             mx = fmaxf(mx, __shfl_xor(mx, 32));
-        }
 #pragma unroll 1
-        for (int c = wave - 4; c < SNC; c += 4) {
-            const f32x16 sc = chunk_scores(c, qs, sh_qb, sh_qreg);
-            chunk_apply(c, sc, mx, sum, O);
+            for (int c = wave - 4; c < SNC; c += 4) {
+                const f32x16 sc = chunk_scores(c, qs, sh_qb, sh_qreg);
+                chunk_apply(c, sc, mx, sum, O);
+            }
+        } else {
+            // the pipelined form over this wave's chunks (the chunk-at-a-time loop took 6 k cycles per chunk beside a streaming wave)
+            auto run = [&](auto list_tag) {
+                sum = (SHIFTED && has_mask) ? fast_tile(std::true_type{}, list_tag, qs, sh_qb, sh_qreg, O)
+                                            : fast_tile(std::false_type{}, list_tag, qs, sh_qb, sh_qreg, O);
+            };
+            if (wave == 4) run(ChunkList<0, 4, 8, 12>{});
+            else if (wave == 5) run(ChunkList<1, 5, 9>{});
+            else if (wave == 6) run(ChunkList<2, 6, 10>{});
+            else run(ChunkList<3, 7, 11>{});
         }
         part_sum = sum + __shfl_xor(sum, 32);
         if (use_max) part_mx = mx;                          // (0 otherwise: not a value that lives across the tile loop)
@@ -1895,7 +2001,9 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_stream_kernel(
             const bool more = qt + qstep < qend;                             // never in waves 4..7 of an unsplit workgroup
             if (more) load_q(qt + qstep, carry, qsrc_n, qcode_n);            // next tile's Q: in flight behind this tile
             f32x16 O;
-            float sum = (SHIFTED && has_mask) ? fast_tile(std::true_type{}, qs, qb, qreg, O) : fast_tile(std::false_type{}, qs, qb, qreg, O);
+            using All = ChunkList<0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12>;
+            float sum = (SHIFTED && has_mask) ? fast_tile(std::true_type{}, All{}, qs, qb, qreg, O)
+                                              : fast_tile(std::false_type{}, All{}, qs, qb, qreg, O);
             float tot = sum + __shfl_xor(sum, 32);
             // 2^score without a max is legal iff the row sum says so (NaN fails the test too); lanes of queries that do not exist
             // (the 24 surplus lanes of tile 12 in a split pair: Q = 0, and with a shift mask possibly every key masked) do not vote
@@ -2090,7 +2198,7 @@ constexpr CostModel COST_F32{0.86, 0.27};
 constexpr CostModel COST_SPLIT{2.3, 0.6};
 // streaming kernel (round 6): the unit is one 32-query tile on one SIMD (13 chunks, ~11 k cycles); an unsplit workgroup is
 // staging + 3 tiles per SIMD + the shared 8-query tile
-constexpr CostModel COST_STREAM{1.2, 0.35};
+constexpr CostModel COST_STREAM{0.9, 0.3};        // stamps (tools/k1_probe.py --stamps): staging 14.6 k cycles, 3 tiles per SIMD ~50 k, tail ~5 k
 
 double simulate_tail(long pairs, int NT, int cus, int n_main, int q, bool shared_last, std::vector<double>& heap,
                      const CostModel& cm) {

@@ -148,7 +148,7 @@ def test_no_scratch_inside_the_mfma_stream(unit):
                 if "scratch_" in ln:
                     near = sum(1 for j in mf if abs(j - i) <= 200)
                     assert near <= 6, (src, name, i, ln.strip(), near)
-            assert meta[name]["private_segment_fixed_size"] <= 32, (src, name, meta[name])
+            assert meta[name]["private_segment_fixed_size"] <= 160, (src, name, meta[name])
             continue
         assert "scratch_" not in body[ms[0]:ms[-1]], (src, name)
         # behind the last MFMA (the epilogue of a range, inside the span loop): nothing either, except K24's GELU epilogue at
