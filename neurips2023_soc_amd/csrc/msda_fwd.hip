@@ -34,13 +34,30 @@ __device__ __forceinline__ void fma4(float4& a, float w, const float4& v) {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+// Block -> (frame, chunk of the frame).  Workgroups are dealt to the 8 XCDs round-robin (block b -> XCD b % 8) and each XCD
+// has its own 4 MiB L2.  `b % N` (rounds 2-5) gives an XCD ONE frame when N = 8 (a clip), but with a launch group of ten clips
+// (N = 80) it gave every XCD ten frames AT ONCE -- the blocks it has in flight then sample ten 4.9-MB value maps, and the PMC
+// traffic per clip went from 415 MB (= algorithmic) to 711 MB.  When N is a multiple of 8 an XCD now walks its
+// frames (x, x + 8, x + 16, ...) ONE AFTER THE OTHER: block b is chunk (b / 8) % C of frame (b % 8) + 8 ((b / 8) / C).
+// Identical to b % N for N = 8; any other N keeps the old map.  Speed only: every (frame, chunk) is visited exactly once.
+__device__ __forceinline__ void frame_chunk(const int b, const int N, const int C, int& n, int& chunk) {
+    if ((N & 7) == 0) {
+        const int i = b >> 3, k = i / C;
+        n = (b & 7) + 8 * k;
+        chunk = i - k * C;
+    } else {
+        n = b % N;
+        chunk = b / N;
+    }
+}
+
 __global__ __launch_bounds__(256, 4) void msda_fwd_d32p4_kernel(
     const float* __restrict__ value, const int64_t* __restrict__ shapes,
     const int64_t* __restrict__ lsi, const float* __restrict__ loc,
     const float* __restrict__ attw, float* __restrict__ out, int N, int S, int M, int L, int Lq,
     int groups_per_frame /* = Lq*M */) {
-    const int n = blockIdx.x % N;        // XCD-friendly: blocks b, b+8, ... share an XCD
-    const int chunk = blockIdx.x / N;
+    int n, chunk;
+    frame_chunk(blockIdx.x, N, (int)(gridDim.x / (unsigned)N), n, chunk);      // XCD-friendly: see frame_chunk
     const int sub = threadIdx.x >> 3;    // 32 (query, head) groups per block
     const int c4 = threadIdx.x & 7;      // which float4 of the 32 channels
     const int g = chunk * 32 + sub;      // (q, m) flat index inside frame n
@@ -134,8 +151,8 @@ __global__ __launch_bounds__(256, 4) void msda_fused_tiles_kernel(
     int Lq, int groups_per_frame, const float* __restrict__ ref, int ref_dim, const uint8_t* __restrict__ pad,
     const int* __restrict__ any_pad) {
     __shared__ __attribute__((aligned(16))) unsigned tile[32 * TILE_GROUP_STRIDE];
-    const int n = blockIdx.x % N;        // XCD-friendly: blocks b, b+8, ... share an XCD
-    const int chunk = blockIdx.x / N;
+    int n, chunk;
+    frame_chunk(blockIdx.x, N, (int)(gridDim.x / (unsigned)N), n, chunk);      // XCD-friendly: see frame_chunk
     const int sub = threadIdx.x >> 3;    // 32 (query, head) groups per block
     const int c4 = threadIdx.x & 7;      // phase 1: points 2*c4, 2*c4+1; phase 2: which float4 of the 32 channels
     // a block = 32 consecutive queries of ONE head, so a wave = 8 raster-adjacent queries whose taps share L1 lines

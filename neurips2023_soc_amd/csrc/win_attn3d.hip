@@ -1689,32 +1689,48 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_stream_kernel(
         float px = 0.f, py = 0.f, prx = 0.f, pry = 0.f;
         unsigned pc0 = 0u, pc1 = 0u;
         constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};       // the six products, smallest first
+        // The 15 vector instructions of a pair of scores, cut into three segments of five so that every instruction that needs a
+        // wait state behind its producer (the convert behind v_exp_f32; the converts behind the inline-assembly subtractions,
+        // which hipcc guards with an s_nop because it cannot see into them) finds the slot's MFMA in between instead of an s_nop:
+        //   seg 0: [third plane + row sums of the PREVIOUS pair] exp x, exp y
+        //   seg 1: first plane (convert), unpack, two subtractions
+        //   seg 2: second plane (convert), unpack, two subtractions
+        // The previous pair of a phase's first pair is the last pair of the phase before (its third plane is first read by the third
+        // P.V MFMA of this phase).
+        auto finish = [&](u32x4 (&P)[3], int i) {
+            const unsigned c2 = cvt_pk_bf16(prx, pry);
+            P[2][i] = c2;
+            acc_f32(sum, px, c2);
+            acc_f32(sum2, py, c2);
+        };
         auto segA = [&](const f32x16& s, int e) {
             px = __builtin_amdgcn_exp2f(s[e]);
             py = __builtin_amdgcn_exp2f(s[e + 1]);
-            pc0 = cvt_pk_bf16(px, py);
-            acc_f32(sum, px, pc0);
-            acc_f32(sum2, py, pc0);
         };
-        auto segB = [&]() {
+        auto segB = [&](u32x4 (&P)[3], int i) {
+            pc0 = cvt_pk_bf16(px, py);
+            P[0][i] = pc0;
             prx = sub_f32(px, __builtin_bit_cast(float, pc0 << 16));
             pry = sub_f32(py, __builtin_bit_cast(float, pc0 & 0xffff0000u));
-            pc1 = cvt_pk_bf16(prx, pry);
         };
         auto segC = [&](u32x4 (&P)[3], int i) {
-            const float a2 = sub_f32(prx, __builtin_bit_cast(float, pc1 << 16));
-            const float b2 = sub_f32(pry, __builtin_bit_cast(float, pc1 & 0xffff0000u));
-            P[0][i] = pc0; P[1][i] = pc1; P[2][i] = cvt_pk_bf16(a2, b2);
+            pc1 = cvt_pk_bf16(prx, pry);
+            P[1][i] = pc1;
+            prx = sub_f32(prx, __builtin_bit_cast(float, pc1 << 16));
+            pry = sub_f32(pry, __builtin_bit_cast(float, pc1 & 0xffff0000u));
         };
-        // segment k % 3 of pair k / 3 of the 8 scores s[8 half ..]; pairs >= npairs are keys that do not exist (P = 0)
-        auto soft_slot = [&](const f32x16& s, int half, int k, int npairs, u32x4 (&P)[3]) {
+        // slot k of a phase: segment k % 3 of pair k / 3 of the 8 scores s[8 half ..]; pairs >= npairs are keys that do not exist
+        // (P = 0); nprev = pairs of the phase before (0: none), whose last one is finished in slot 0
+        auto soft_slot = [&](const f32x16& s, int half, int k, int npairs, u32x4 (&P)[3], u32x4 (&Pprev)[3], int nprev) {
             const int i = k / 3, seg = k % 3;
-            if (i < npairs) {
-                if (seg == 0) segA(s, 8 * half + 2 * i);
-                else if (seg == 1) segB();
+            if (seg == 0) {
+                if (i == 0 && nprev > 0) finish(Pprev, nprev - 1);
+                if (i >= 1 && i - 1 < npairs) finish(P, i - 1);
+                if (i < npairs) segA(s, 8 * half + 2 * i);
+                else { P[0][i] = 0u; P[1][i] = 0u; P[2][i] = 0u; }
+            } else if (i < npairs) {
+                if (seg == 1) segB(P, i);
                 else segC(P, i);
-            } else if (seg == 0) {
-                P[0][i] = 0u; P[1][i] = 0u; P[2][i] = 0u;
             }
         };
         auto mf_pv = [&](int k, const bf16x4 (&lo)[3], const bf16x4 (&hi)[3], const u32x4 (&P)[3]) {
@@ -1795,7 +1811,7 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_stream_kernel(
                         if (k < 9) kfn[k - 6] = k_read(k - 6, 1, cn * SCHB);
                     }
                 }
-                soft_slot(cur, 0, k, PARTIAL ? 2 : 4, Pa);
+                soft_slot(cur, 0, k, PARTIAL ? 2 : 4, Pa, Pb, FIRST ? 0 : 4);
                 SOC_SLOT_END;
             }
             // ---- phase 2: P.V(c, k-step 0) | Q.K^T(next chunk, k-step 1); scores 8..15 -> Pb; reads for the next phase 1
@@ -1818,7 +1834,7 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_stream_kernel(
                         if (k == 8) init_j(CNNT{}, 2, cur);
                     }
                 }
-                if constexpr (!PARTIAL) soft_slot(cur, 1, k, 4, Pb);
+                if constexpr (!PARTIAL) soft_slot(cur, 1, k, 4, Pb, Pa, 4);      // (chunk 12: both of its pairs were finished in phase 1)
                 if constexpr (NEXT2) {
                     if (k == 11) init_j(CNNT{}, 3, cur);
                 }
@@ -1826,6 +1842,8 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_stream_kernel(
             }
             // ---- the list ends on a whole chunk: its second k-step is still due
             if constexpr (!NEXT && !PARTIAL) {
+                finish(Pb, 3);
+                SOC_SLOT_END;
 #pragma unroll
                 for (int k = 0; k < 6; ++k) mf_pv(k, vlo, vhi, Pb);
                 SOC_SLOT_END;

@@ -40,16 +40,20 @@ class ClipInferencer:
         oracle), which is what tokenizer(..., padding="longest") does to the shorter expressions of a batch."""
         self.model, self.device = model, torch.device(device)
         self.use_graphs, self.max_graphs, self.pad_tokens_to = use_graphs, max_graphs, pad_tokens_to
-        # group > 1: the streaming form shares every launch between `group` consecutive clips of one geometry
-        # (graph_runner.PairPipelinedClipGraph / QuadPipelinedClipGraph: each clip still gets its single-clip result); a
-        # part-filled group -- geometry change, end of the stream -- runs with stale partner slots
+        # group > 1: the streaming form shares every launch between `group` consecutive clips of one geometry -- of one video or of
+        # several (graph_runner.group_pipeline_class: each clip still gets its single-clip result).  A part-filled group --
+        # geometry change, end of the stream -- costs a whole replay whatever it holds, so (round 6) a remainder of FEWER than
+        # half a group leaves through the one-clip pipeline of the same geometry instead (captured beside the group graph the
+        # first time it is needed); half a group or more runs with stale partner slots whose records are dropped.
         if int(group) != group or group < 1:
             raise ValueError("group must be a positive clip count")
         self.group = group
         self._filling = []           # (tag, original_size) of the clips staged into the group that has not been replayed yet
         self._graphs: Dict[Tuple[int, int, int, int], ClipGraph] = {}
         self._pipes: Dict[Tuple[int, int, int, int], PipelinedClipGraph] = {}
+        self._singles: Dict[Tuple[int, int, int, int], PipelinedClipGraph] = {}     # one-clip pipelines for the remainders of groups
         self._active = None          # (key, pipe, tag of the clip in flight)
+        self.stats = {"group_replays": 0, "part_filled_replays": 0, "stale_slots": 0, "remainder_singles": 0}
 
     def graph_for(self, T: int, H: int, W: int, L: int) -> ClipGraph:
         key = (T, H, W, L)
@@ -95,6 +99,11 @@ class ClipInferencer:
         key, pipe, in_flight = self._active
         rec = pipe.replay()
         filled, self._filling = self._filling, []
+        if self.group > 1:
+            self.stats["group_replays"] += 1
+            if len(filled) < self.group:
+                self.stats["part_filled_replays"] += 1
+                self.stats["stale_slots"] += self.group - len(filled)
         self._active = (key, pipe, filled)
         if rec is None or not in_flight:
             return []
@@ -129,13 +138,46 @@ class ClipInferencer:
             out += self._replay()
         return out
 
+    def _single_pipeline(self, key):
+        if key not in self._singles:
+            while len(self._singles) >= self.max_graphs:
+                torch.cuda.synchronize(self.device)
+                self._singles.pop(next(iter(self._singles)))
+            self._singles[key] = pipeline_class()(self.model, *key, self.device)
+        return self._singles[key]
+
+    def _remainder_through_singles(self):
+        """A part-filled group of fewer than group / 2 clips: the group in flight is flushed, then the staged clips -- read back from
+        the group graph's static input slots, the caller may have reused its tensors -- go one by one through the one-clip
+        pipeline of the geometry.  r clips cost r one-clip replays (6.2 ms each at the BASELINE geometry) instead of a whole
+        group replay (49 ms for ten)."""
+        key, pipe, in_flight = self._active
+        out = []
+        for rec in pipe.flush():
+            out += [self._unpack(rec[b], key, tag, osz) for b, (tag, osz) in enumerate(in_flight)]
+        staged, self._filling = self._filling, []
+        single = self._single_pipeline(key)
+        for b, (tag, osz) in enumerate(staged):
+            single.stage_inputs(pipe.clip[:, b].contiguous(), pipe.ids[b], pipe.attn[b])
+            rec = single.replay()
+            if rec is not None:                                   # the record of the clip staged one replay earlier
+                out.append(self._unpack(rec.clone(), key, *staged[b - 1]))
+        for rec in single.flush():
+            out.append(self._unpack(rec, key, *staged[-1]))
+        self.stats["remainder_singles"] += len(staged)
+        self._active = None
+        return out
+
     @torch.no_grad()
     def drain(self):
-        """Finish what is staged (a part-filled group runs with stale partner slots) and in flight: list of result dicts."""
+        """Finish what is staged and in flight: list of result dicts.  A part-filled group runs with stale partner slots when it
+        is at least half full, through the one-clip pipeline otherwise (_remainder_through_singles)."""
         if self._active is None:
             return []
         out = []
         if self._filling:
+            if self.group > 1 and 2 * len(self._filling) < self.group:
+                return self._remainder_through_singles()
             out += self._replay()
         key, pipe, in_flight = self._active
         self._active = None
@@ -268,15 +310,18 @@ def parse_args(argv=None):
     ap.add_argument("--make-synthetic", type=int, default=0, metavar="N",
                     help="first write an N-video synthetic dataset (720x1280 JPEGs) under --root")
     ap.add_argument("--graphs", action="store_true", help="hipGraph replay per clip geometry in the dataset drivers")
-    ap.add_argument("--group", type=int, default=1,
-                    help="--graphs: consecutive clips of one geometry per launch group (each gets its single-clip result); "
-                         "pays where many clips share a geometry (DAVIS chunks, several expressions per video)")
+    ap.add_argument("--group", type=int, default=None,
+                    help="--graphs: consecutive clips of one geometry per launch group (each gets its single-clip result; clips of "
+                         "different videos share a group when their geometry is the same; a remainder of fewer than half a group "
+                         "leaves through the one-clip graph).  Default: 8 with --graphs, 1 without")
     ap.add_argument("--words", type=int, default=0, help="--make-synthetic: fixed number of words per expression")
     ap.add_argument("--repeat", type=int, default=1, help="run the driver this many times, report the last (warm) pass")
     ap.add_argument("--gpus", "-ng", type=int, default=None,
                     help="GPUs of this node; >1 without an outer launcher starts one rank per GPU (reference -ng).  "
                          "Default: WORLD_SIZE under an outer launcher, 1 otherwise; an explicit value must equal WORLD_SIZE")
     a = ap.parse_args(argv)
+    if a.group is None:
+        a.group = 8 if a.graphs else 1
     a.gpus_given = a.gpus is not None
     if a.gpus is None:
         a.gpus = int(os.environ["WORLD_SIZE"]) if CP.launched_as_rank() else 1

@@ -142,4 +142,5 @@ def run(model, tokenize: Tokenize, root: str, out_dir: str, rank: int = 0, world
     torch.cuda.synchronize()
     cache.close()
     stats.update(seconds=time.perf_counter() - t0, cache_hits=cache.hits, cache_misses=cache.misses)
+    stats.update({k: v for k, v in getattr(engine, "stats", {}).items()})       # group replays, part-filled ones, remainders
     return stats

@@ -83,7 +83,8 @@ def make_dataset(root: str, videos: int = 2, frames: int = 8, height: int = 720,
                  expressions: int = 2, seed: int = 0, split: str = "valid", quality: int = 90,
                  words: Sequence[str] = WORDS, n_words: int = 0) -> str:
     """Writes <root>/<split>/JPEGImages/<video>/<%05d>.jpg and <root>/meta_expressions/<split>/meta_expressions.json.
-    n_words > 0 fixes the expression length (one token count -> one hipGraph geometry)."""
+    n_words > 0 fixes the expression length (one token count -> one hipGraph geometry).  `expressions`: a count, or one count
+    per video (the real sets are ragged: infer_refytb.py:185 loops over however many expressions a video has)."""
     from PIL import Image
     rng = np.random.default_rng(seed)
     meta = {"videos": {}}
@@ -97,7 +98,7 @@ def make_dataset(root: str, videos: int = 2, frames: int = 8, height: int = 720,
             Image.fromarray(_frame(np.random.default_rng(seed * 1000 + v), height, width, t)).save(
                 os.path.join(folder, n + ".jpg"), quality=quality)
         exps = {}
-        for e in range(expressions):
+        for e in range(expressions if isinstance(expressions, int) else expressions[v]):
             k = n_words or int(vr.integers(3, 9))
             exps[str(e)] = {"exp": " ".join(words[int(i)] for i in rng.integers(0, len(words), k))}
         meta["videos"][name] = {"frames": names, "expressions": exps}

@@ -64,22 +64,36 @@ def gpu_model():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("use_graphs", [False, True, 4, 2, 8])
+@pytest.mark.parametrize("use_graphs", [False, True, 4, 2, 8, (8, (3, 1, 2, 1)), (8, (2, 1)), (4, (2, 3, 1, 1)), (8, (4, 3, 4))])
 def test_refytb_driver_matches_reference_recipe(gpu_model, tmp_path, use_graphs):
     """use_graphs=True: the driver streams through the software-pipelined hipGraph (results one clip late, drained
     at the end) -- the same PNGs must come out.  4 / 2: through the group pipelines (four / two clips per launch group: the four
-    clips of the set are one full group / two; results arrive a whole group late)."""
-    group, use_graphs = (use_graphs, True) if use_graphs not in (False, True) else (1, use_graphs)
+    clips of the set are one full group / two; results arrive a whole group late).  (group, counts): RAGGED expression counts per
+    video, as the real set has them (infer_refytb.py:185) -- clips of different videos share a group, a remainder of at least
+    half a group runs with stale slots, a smaller one leaves through the one-clip graph."""
+    ragged = None
+    if isinstance(use_graphs, tuple):
+        (group, ragged), use_graphs = use_graphs, True
+    else:
+        group, use_graphs = (use_graphs, True) if use_graphs not in (False, True) else (1, use_graphs)
     from PIL import Image
     from neurips2023_soc_amd import infer_refytb
     model, sd = gpu_model
-    root = SD.make_dataset(str(tmp_path / "data"), videos=2, frames=3, height=144, width=256, expressions=2, seed=3)
+    counts = ragged or (2, 2)
+    root = SD.make_dataset(str(tmp_path / "data"), videos=len(counts), frames=3, height=144, width=256, expressions=list(counts), seed=3)
     tok = SD.HashTokenizer()
     out_dir = str(tmp_path / "out")
     stats = infer_refytb.run(model, tok, root, out_dir, size=SIZE, max_size=MAX_SIZE, decode_workers=2,
                              use_graphs=use_graphs, group=group)
-    assert stats["videos"] == 2 and stats["expressions"] == 4 and stats["frames"] == 12
-    assert stats["cache_misses"] == 2 and stats["cache_hits"] == 2      # frames decoded once per video
+    n = sum(counts)
+    assert stats["videos"] == len(counts) and stats["expressions"] == n and stats["frames"] == 3 * n
+    assert stats["cache_misses"] == len(counts) and stats["cache_hits"] == n - len(counts)      # frames decoded once per video
+    if ragged:
+        full, rest = divmod(n, group)
+        singles = rest if 2 * rest < group else 0
+        assert stats["remainder_singles"] == singles
+        assert stats["group_replays"] == full + (1 if rest and not singles else 0)
+        assert stats["stale_slots"] == (group - rest if rest and not singles else 0)
     _, data = infer_refytb.load_meta(root)
     total = wrong = 0
     for video, item in data.items():
