@@ -1508,6 +1508,54 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_stream_kernel(
         return (z < p.D && y < p.H && x < p.W) ? ((b * p.D + z) * p.H + y) * p.W + x : -1;
     };
 
+    const int n32 = lane & 31, hh = lane >> 5;
+    // Q of a tile: lane (query n32, dims 8 hh .. + 7 and 16 + 8 hh ..), raw; + the query's token / bias code / region
+    auto load_q = [&](int qt, float (&qf)[16], int& qsrc, int& qcode) {
+        int reg, cc;
+        const int slot = qt * 32 + n32;
+        qsrc = -2; qcode = 0;
+        if (slot < FN) {
+            qsrc = slot_info(slot, reg, cc);
+            qcode = cc | (reg << 16);
+        }
+        if (qsrc >= 0) {
+            const float4* qrow = reinterpret_cast<const float4*>(qkv + (long)qsrc * C3 + head * HD + 8 * hh);
+            const float4 a = qrow[0], c = qrow[1], d = qrow[4], e = qrow[5];
+            qf[0] = a.x; qf[1] = a.y; qf[2] = a.z; qf[3] = a.w; qf[4] = c.x; qf[5] = c.y; qf[6] = c.z; qf[7] = c.w;
+            qf[8] = d.x; qf[9] = d.y; qf[10] = d.z; qf[11] = d.w; qf[12] = e.x; qf[13] = e.y; qf[14] = e.z; qf[15] = e.w;
+        } else if (qsrc == -1) {
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                qf[kk] = qkv_bias[head * HD + 8 * hh + kk];
+                qf[8 + kk] = qkv_bias[head * HD + 16 + 8 * hh + kk];
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) qf[kk] = 0.f;
+        }
+    };
+    // ---- tiles of this wave.  Unsplit workgroup: waves 0..3 own tiles w and w + 4, waves 4..7 tile w + 4 (8..11), tile 12
+    //      (8 queries) is shared below.  A part of a split pair: tiles qpart + qsplit k, dealt k = wave, wave + 8, ...
+    const bool share_last = qsplit == 1;
+    int qt, qstep, qend;
+    if (share_last) {
+        qt = wave < 4 ? wave : wave + 4;
+        qstep = 4;
+        qend = wave < 4 ? 8 : SNQ - 1;
+    } else {
+        qt = qpart + qsplit * wave;
+        qstep = (THREADS / 64) * qsplit;
+        qend = SNQ;
+    }
+    // The first tile's Q (and, in waves 4..7 of an unsplit workgroup, the shared tile's) is requested BEFORE the K / V rows: its
+    // latency then hides under the staging instead of in front of the first tile (the first tile of a wave took ~3 k cycles more
+    // than its second, whose Q had been prefetched).
+    const bool light = share_last && wave >= 4;
+    float q_first[16], q_shared[16];
+    int qsrc_first = -2, qcode_first = 0, qsrc_shared = -2, qcode_shared = 0;
+    if (qt < qend) load_q(qt, q_first, qsrc_first, qcode_first);
+    if (light) load_q(SNQ - 1, q_shared, qsrc_shared, qcode_shared);
+
     // ---- staging (the split kernel's): K and V rows (8 dims per thread) split into three bf16 planes each, bias column, group table
     {
         int differs = 0, reg0, c0;
@@ -1541,7 +1589,11 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_stream_kernel(
         for (int it = 0; it < TPASS; ++it) {
             const int i = it * THREADS + tid;
             const int yx = i / 15, zz = i - yx * 15;
+#if defined(SOC_K1_VAR) && (SOC_K1_VAR & 8)          // diagnostic: no bias-table gather
+            tv[it] = 0.f;
+#else
             tv[it] = i < TBL ? table[(long)(zz * 169 + yx) * p.nH + head] : 0.f;
+#endif
         }
         const int wave_differs = __any(differs);
         if (SHIFTED && lane == 0) wflag[wave] = wave_differs ? 1 : 0;
@@ -1595,7 +1647,6 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_stream_kernel(
     int stamp_slot = 4;
     (void)stamp_slot;
 
-    const int n32 = lane & 31, hh = lane >> 5;
     const unsigned tbase = (unsigned)(uintptr_t)(lds_cfloat*)Tb;
     const unsigned kaddr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)Kp;
     const unsigned vaddr = kaddr + 3 * PLANEB;
@@ -1625,37 +1676,18 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_stream_kernel(
         }
     }
     auto k_read = [&](int pl, int kk, int off) -> bf16x8 {            // K fragment of plane pl, k-step kk at byte offset off
+#if defined(SOC_K1_VAR) && (SOC_K1_VAR & 2)          // diagnostic: no LDS reads of K / V fragments
+        return __builtin_bit_cast(bf16x8, (u32x4){kb01[kk] + (unsigned)off, kb2[kk], 0x3f803f80u, (unsigned)pl});
+#endif
         return pl == 2 ? b128_read_at(kb2[kk], off) : b128_read_at(kb01[kk], pl * PLANEB + off);
     };
     auto v_read = [&](int pl, int jj, int off) -> bf16x4 {            // V key quartet jj of plane pl at byte offset off
+#if defined(SOC_K1_VAR) && (SOC_K1_VAR & 2)
+        return __builtin_bit_cast(bf16x4, (f32x2){__builtin_bit_cast(float, vb01[jj] + (unsigned)off), __builtin_bit_cast(float, 0x3f803f80u + (unsigned)pl)});
+#endif
         return pl == 2 ? tr_read_at(vb2[jj], off) : tr_read_at(vb01[jj], pl * PLANEB + off);
     };
 
-    // Q of a tile: lane (query n32, dims 8 hh .. + 7 and 16 + 8 hh ..), raw; + the query's token / bias code / region
-    auto load_q = [&](int qt, float (&qf)[16], int& qsrc, int& qcode) {
-        int reg, cc;
-        const int slot = qt * 32 + n32;
-        qsrc = -2; qcode = 0;
-        if (slot < FN) {
-            qsrc = slot_info(slot, reg, cc);
-            qcode = cc | (reg << 16);
-        }
-        if (qsrc >= 0) {
-            const float4* qrow = reinterpret_cast<const float4*>(qkv + (long)qsrc * C3 + head * HD + 8 * hh);
-            const float4 a = qrow[0], c = qrow[1], d = qrow[4], e = qrow[5];
-            qf[0] = a.x; qf[1] = a.y; qf[2] = a.z; qf[3] = a.w; qf[4] = c.x; qf[5] = c.y; qf[6] = c.z; qf[7] = c.w;
-            qf[8] = d.x; qf[9] = d.y; qf[10] = d.z; qf[11] = d.w; qf[12] = e.x; qf[13] = e.y; qf[14] = e.z; qf[15] = e.w;
-        } else if (qsrc == -1) {
-#pragma unroll
-            for (int kk = 0; kk < 8; ++kk) {
-                qf[kk] = qkv_bias[head * HD + 8 * hh + kk];
-                qf[8 + kk] = qkv_bias[head * HD + 16 + 8 * hh + kk];
-            }
-        } else {
-#pragma unroll
-            for (int kk = 0; kk < 16; ++kk) qf[kk] = 0.f;
-        }
-    };
     auto split_q = [&](const float (&qf)[16], bf16x8 (&qs)[2][3]) {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -1722,6 +1754,10 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_stream_kernel(
         // slot k of a phase: segment k % 3 of pair k / 3 of the 8 scores s[8 half ..]; pairs >= npairs are keys that do not exist
         // (P = 0); nprev = pairs of the phase before (0: none), whose last one is finished in slot 0
         auto soft_slot = [&](const f32x16& s, int half, int k, int npairs, u32x4 (&P)[3], u32x4 (&Pprev)[3], int nprev) {
+#if defined(SOC_K1_VAR) && (SOC_K1_VAR & 1)          // diagnostic (tools/k1_probe.py --flags): no vector work in the tile
+            if (k == 0) { P[0] = (u32x4){0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}; P[1] = P[0]; P[2] = P[0]; sum += s[half]; }
+            return;
+#endif
             const int i = k / 3, seg = k % 3;
             if (seg == 0) {
                 if (i == 0 && nprev > 0) finish(Pprev, nprev - 1);
@@ -1734,11 +1770,19 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_stream_kernel(
             }
         };
         auto mf_pv = [&](int k, const bf16x4 (&lo)[3], const bf16x4 (&hi)[3], const u32x4 (&P)[3]) {
+#if defined(SOC_K1_VAR) && (SOC_K1_VAR & 4)          // diagnostic: no MFMAs (the operands are still consumed)
+            if (k == 5) O[0] += (float)lo[0][0] + (float)hi[1][0] + (float)lo[2][1] + __builtin_bit_cast(float, P[0][0] ^ P[1][1] ^ P[2][2]);
+            return;
+#endif
             const bf16x4 l = lo[PA[k]], h = hi[PA[k]];
             const bf16x8 vf = {l[0], l[1], l[2], l[3], h[0], h[1], h[2], h[3]};
             O = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, __builtin_bit_cast(bf16x8, P[PB[k]]), O, 0, 0, 0);
         };
         auto mf_qk = [&](int k, f32x16& s, const bf16x8 (&kfr)[3], int kk) {
+#if defined(SOC_K1_VAR) && (SOC_K1_VAR & 4)
+            if (k == 5) s[kk] += (float)kfr[0][0] + (float)kfr[1][1] + (float)kfr[2][2];
+            return;
+#endif
             s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[PA[k]], qs[kk][PB[k]], s, 0, 0, 0);
         };
         // bias of key column j of chunk c into scores 4 j .. 4 j + 3 (+ the shift-mask penalty)
@@ -1938,19 +1982,6 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_stream_kernel(
         }
     };
 
-    // ---- tiles of this wave.  Unsplit workgroup: waves 0..3 own tiles w and w + 4, waves 4..7 tile w + 4 (8..11), tile 12
-    //      (8 queries) is shared below.  A part of a split pair: tiles qpart + qsplit k, dealt k = wave, wave + 8, ...
-    const bool share_last = qsplit == 1;
-    int qt, qstep, qend;
-    if (share_last) {
-        qt = wave < 4 ? wave : wave + 4;
-        qstep = 4;
-        qend = wave < 4 ? 8 : SNQ - 1;
-    } else {
-        qt = qpart + qsplit * wave;
-        qstep = (THREADS / 64) * qsplit;
-        qend = SNQ;
-    }
     // `carry`: the NEXT tile's raw Q in the waves that own two tiles (waves 0..3 of an unsplit workgroup, any wave of a part), and in
     // waves 4..7 of an unsplit workgroup -- which own one tile and never prefetch -- their partial O of the shared tile: one set of
     // 16 registers for both.
@@ -1959,13 +1990,11 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_stream_kernel(
     float* xsum = reinterpret_cast<float*>(gtab + FNT * 4);          // [4 waves][8 queries], in the slack behind the group table
     auto shared_partial = [&](const bool use_max) __attribute__((always_inline)) {
         // tile 12 (queries 384..391 in lanes n32 < 8): wave w takes key chunks w - 4, w, w + 4 (, 12)
-        float qf[16];
-        int qsrc, qcode;
-        load_q(SNQ - 1, qf, qsrc, qcode);
+        if (use_max) load_q(SNQ - 1, q_shared, qsrc_shared, qcode_shared);        // (the redo: the registers were given up)
         bf16x8 qs[2][3];
-        split_q(qf, qs);
-        const unsigned sh_qb = tbase + (unsigned)((qcode & 0xFFFF) + C0 - 32 + 16 * hh);
-        const int sh_qreg = qcode >> 16;
+        split_q(q_shared, qs);
+        const unsigned sh_qb = tbase + (unsigned)((qcode_shared & 0xFFFF) + C0 - 32 + 16 * hh);
+        const int sh_qreg = qcode_shared >> 16;
         f32x16 O;
 #pragma unroll
         for (int i = 0; i < 16; ++i) O[i] = 0.f;
@@ -1996,7 +2025,6 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_stream_kernel(
 #pragma unroll
         for (int i = 0; i < 16; ++i) carry[i] = O[i];
     };
-    const bool light = share_last && wave >= 4;
     if (light) {
         // FIRST, not last: these chunk-at-a-time passes stall on every LDS read and MFMA chain, which costs nothing while the SIMD's
         // other wave streams its whole tiles -- at the end of the workgroup they were 12-17 k cycles with the other wave idle
@@ -2005,13 +2033,9 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_stream_kernel(
     }
     STAMP(stamp_slot); ++stamp_slot;
     {
-        float q0[16];
-        int qsrc_n = -2, qcode_n = 0;
+        int qsrc_n = qsrc_first, qcode_n = qcode_first;
         bf16x8 qs[2][3];
-        if (qt < qend) {
-            load_q(qt, q0, qsrc_n, qcode_n);
-            split_q(q0, qs);
-        }
+        if (qt < qend) split_q(q_first, qs);
         for (; qt < qend; qt += qstep) {
             const int qsrc = qsrc_n;
             const unsigned qb = tbase + (unsigned)((qcode_n & 0xFFFF) + C0 - 32 + 16 * hh);
@@ -2025,7 +2049,7 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_stream_kernel(
             float tot = sum + __shfl_xor(sum, 32);
             // 2^score without a max is legal iff the row sum says so (NaN fails the test too); lanes of queries that do not exist
             // (the 24 surplus lanes of tile 12 in a split pair: Q = 0, and with a shift mask possibly every key masked) do not vote
-#if defined(SOC_K1_DBG) && (SOC_K1_DBG == 1 || SOC_K1_DBG >= 3)
+#if (defined(SOC_K1_DBG) && (SOC_K1_DBG == 1 || SOC_K1_DBG >= 3)) || defined(SOC_K1_VAR)
             if (false) {
 #elif defined(SOC_K1_DBG) && SOC_K1_DBG == 2
             if (true) {
@@ -2059,6 +2083,9 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_stream_kernel(
             const float tq = (xsum[q] + xsum[8 + q]) + (xsum[16 + q] + xsum[24 + q]);
             legal = legal && tq > 0x1p-60f && tq < 0x1p60f;             // (NaN fails too)
         }
+#ifdef SOC_K1_VAR
+        legal = true;
+#endif
         if (!legal) {                                      // block-uniform: every thread read the same 32 words
             if (light) shared_partial(true);
             __syncthreads();                               // ... and now every wave is done with the K planes

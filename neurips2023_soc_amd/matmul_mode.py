@@ -59,8 +59,13 @@ def split_wins(rows: int, N: int, K: int, fused_passes: int = 0, site: str = "pl
     runs at 100-125 TFLOP/s f32-equivalent once the grid fills the chip and K is short, about what the tuned f32 library
     GEMM reaches, so it wins where it also removes separate passes (`fused_passes`: LayerNorm, GELU, residual / mul /
     positional adds), and loses on long-K layers with few row tiles (K >= 768 with < 30 000 rows)."""
-    if not split_enabled() or K % 8 or N % 4 or rows < 1024 or K > 768 or site in _SPLIT_OFF:
+    if not split_enabled() or K % 8 or N % 4 or rows < 1024 or site in _SPLIT_OFF:
         return False
+    if K > 768:
+        # long reductions (Video-Swin stage-3 fc2 + shortcut: K = 3072; the last merging reduction: K = 1536), round 6,
+        # tools/experiments/longk_probe.py: at the 19 200 rows of a ten-clip launch group K20 runs them at 180 TFLOP/s where the
+        # f32 library GEMM (+ its add pass) reaches 110; a tie at 7 680 rows (four clips), a loss at one clip's 1 920 (35 against 95)
+        return rows >= 12288 and N >= 512
     if rows * N < 5_500_000:                    # too few tiles to fill 256 CUs (stage-2/3 proj, stage-3 qkv, coarse levels)
         return False
     if K > 512:                                 # K = 768: only the wide, GELU-fused fc1 of stage 3 (1920 x 768 -> 3072)

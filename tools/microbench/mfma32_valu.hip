@@ -17,7 +17,11 @@ template <>
 struct Acc<true> {
     f32x16 c[2];
     __device__ void init() { for (int j = 0; j < 2; ++j) for (int i = 0; i < 16; ++i) c[j][i] = 0.f; }
+#ifdef CHAIN_BLOCKS      // six dependent MFMAs on one accumulator, then six on the other (K1's phases) instead of alternating
+    __device__ void mfma(int j, bf16x8 a, bf16x8 b) { c[(j / 6) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c[(j / 6) & 1], 0, 0, 0); }
+#else
     __device__ void mfma(int j, bf16x8 a, bf16x8 b) { c[j & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c[j & 1], 0, 0, 0); }
+#endif
     __device__ float sum() { return c[0][0] + c[1][5]; }
 };
 template <>
