@@ -18,7 +18,8 @@ sys.path.insert(0, ROOT)
 ap = argparse.ArgumentParser()
 ap.add_argument("--videos", type=int, default=64)
 ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r05_files_to_png.json"))
-ap.add_argument("--group", type=int, default=1, help="clips per launch group of the driver's graph pipeline (1, 2, 4)")
+ap.add_argument("--group", type=int, default=8, help="clips per launch group of the driver's graph pipeline (the driver's default with --graphs: 8)")
+ap.add_argument("--ragged", action="store_true", help="1-5 expressions per video (as the real set: infer_refytb.py:185), mean 3, instead of 3 each")
 a = ap.parse_args()
 
 import numpy as np  # noqa: E402
@@ -28,7 +29,8 @@ from neurips2023_soc_amd.clip_parallel import granted_cpus  # noqa: E402
 
 tmp = tempfile.mkdtemp(prefix="soc_f2p_")
 root, out_dir = os.path.join(tmp, "data"), os.path.join(tmp, "out")
-synthetic_dataset.make_dataset(root, videos=a.videos, frames=8, expressions=3, n_words=8)
+counts = [(1, 3, 5, 2, 4, 3, 2, 4)[v % 8] for v in range(a.videos)] if a.ragged else 3          # mean 3 either way
+synthetic_dataset.make_dataset(root, videos=a.videos, frames=8, expressions=counts, n_words=8)
 # ---- the driver itself, warm pass reported (child process: its own GPU context, the parent stays CPU-only)
 cmd = [sys.executable, "-m", "neurips2023_soc_amd.infer", "--dataset", "refytb", "--root", root, "--out", out_dir, "--graphs",
        "--repeat", "2", "--group", str(a.group)]
@@ -63,7 +65,9 @@ cpu_s_per_clip = dec_s / 3.0 + enc_s                 # a video's frames are deco
 cpus = granted_cpus()
 res = {
     "driver": {k: stats[k] for k in ("videos", "expressions", "frames", "seconds", "clips_per_s", "seconds_input", "seconds_model",
-                                     "seconds_writer_tail") if k in stats},
+                                     "seconds_writer_tail", "group_replays", "part_filled_replays", "stale_slots",
+                                     "remainder_singles") if k in stats},
+    "expressions_per_video": "1-5, ragged (mean 3)" if a.ragged else "3",
     "driver_command": " ".join(cmd[1:]), "driver_wall_s_two_passes_plus_start": wall,
     "host_cpu_seconds": {"jpeg_decode_8x720p_one_video": dec_s, "png_encode_8x720p_one_clip": enc_s,
                          "per_clip_at_3_expressions_per_video": cpu_s_per_clip},

@@ -1,5 +1,6 @@
 """K2 (multi-scale deformable attention, fused form) at the encoder size of the BASELINE configurations.
-usage: python tools/k2_probe.py [reps] [360p|720p] [offset scale]      (run under rocprofv3 --pmc ... for the cache counters)
+usage: python tools/k2_probe.py [reps] [360p|720p] [offset scale] [clips]      (run under rocprofv3 --pmc ... for the cache counters)
+clips: frames = 8 x clips in one launch (a launch group: 10 -> N = 80)
 360p: S = 4 820 per frame (configs 1-3, 5); 720p: S = 19 160 (config 4)."""
 import sys
 
@@ -12,7 +13,8 @@ from neurips2023_soc_amd.deformable_transformer import DeformableTransformerEnco
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 which = sys.argv[2] if len(sys.argv) > 2 else "360p"
 shapes = {"360p": [[45, 80], [23, 40], [12, 20], [6, 10]], "720p": [[90, 160], [45, 80], [23, 40], [12, 20]]}[which]
-N, M = 8, 8
+CLIPS = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+N, M = 8 * CLIPS, 8
 sh = torch.tensor(shapes).cuda()
 lsi = torch.cat((sh.new_zeros(1), sh.prod(1).cumsum(0)[:-1]))
 S = int(sh.prod(1).sum())
