@@ -40,7 +40,7 @@ _NO_RECORD_COPY = os.environ.get('BENCH_NO_RECORD_COPY', '0') == '1'
 _STREAM_MODE = os.environ.get('BENCH_STREAM_MODE', 'full')     # diagnostics of the streamed pass: nowait | d2d
 _FEED_DEPTH = int(os.environ.get('BENCH_FEED_DEPTH', '2'))     # device slots of the streamed pass's feeder
 WEIGHT_SEED = 2023
-PROFILE_TAG = "r05"            # the round whose rocprofv3 summaries under profiles/ belong to this bench.py
+PROFILE_TAG = "r06"            # the round whose rocprofv3 summaries under profiles/ belong to this bench.py
 MAX_LINE_BYTES = 8000          # the driver reads the line from a bounded stdout tail: round 4's 21.5 KB line did not parse
 FLIP_WINDOW = 6e-5             # |reference logit| below which a thresholded pixel may differ: the reference's own
                                # 1-vs-8-thread noise at this logit scale; everywhere else masks are bit-exact
@@ -543,7 +543,7 @@ def main():
     # own B = 1 result (selected query equal, record within 1e-4).  Records 0..3 are additionally checked against the reference
     # golden / the CPU oracle further down.
     slot_check = None
-    if per > 1 and world == 1:
+    if per > 1 and world == 1 and graph is not None:         # (an --eager run has no graph slots to mix up, and the PMC passes count its launches)
         if single_pass is not None:
             ref_recs, how = single_pass["records"], "single-clip pipeline pass (PipelinedClipGraph)"
         else:
@@ -669,7 +669,7 @@ def main():
         # HBM bytes per clip from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE collected
         # separately and corrected as MI355X_MICROARCH.md prescribes): profiles/r01_hbm_traffic_pmc.json
         traffic, traffic_file = {}, None
-        for name in ("r05_hbm_traffic_pmc.json", "r04_hbm_traffic_pmc.json", "r03_hbm_traffic_pmc.json", "r02_hbm_traffic_pmc.json", "r01_hbm_traffic_pmc.json"):
+        for name in ("r06_hbm_traffic_pmc.json", "r05_hbm_traffic_pmc.json", "r04_hbm_traffic_pmc.json", "r03_hbm_traffic_pmc.json", "r02_hbm_traffic_pmc.json", "r01_hbm_traffic_pmc.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as f:
                     traffic = {k: v["hbm_total"] for k, v in json.load(f)["per_clip_bytes"].items()}
@@ -687,7 +687,7 @@ def main():
                 "mlp_split": "soc_mlp_split_f32 (K23: LayerNorm + linear + activation + linear + residual (+ LayerNorm) in one "
                              "launch, hidden layer in registers -- the Video-Swin MLPs of stages 0-2 and the encoder's feed-forward "
                              "blocks)"}
-        stats_rows = {"win_attn3d": "win_attn3d_split_kernel<false|true>", "linear_split": "linear_split_kernel<...>",
+        stats_rows = {"win_attn3d": "win_attn3d_stream_kernel<false|true>", "linear_split": "linear_split_kernel<...>",
                       "ws_linear": "ws_linear_split_kernel<...> (+ ws_linear_kernel<...>)", "xs_linear": "xs_linear_kernel<...>",
                       "mlp_split": "mlp_split_kernel<...> (+ mlp_reduce_kernel)"}
 
@@ -704,9 +704,10 @@ def main():
         def vector_share(fam):
             """VALU cycles per matrix-pipe cycle of the family's kernels, from the committed rocprofv3 counter passes
             (SQ_INSTS_VALU x 2 clk / (SQ_INSTS_MFMA x 16.7 clk); v_exp and packed forms counted as one instruction).  On a
-            gfx950 SIMD the two do not overlap (tools/microbench/mfma_valu_roles.hip), so 1 / (1 + share) bounds the kernel
-            below the 417 TFLOP/s ceiling before any LDS / barrier stall."""
-            src = {"win_attn3d": ("r04_k1_pmc.json", lambda d: d["counters"]["k1_stage0_split"]),
+            gfx950 SIMD the two do not overlap beside v_mfma_f32_16x16x32_bf16 (tools/microbench/mfma_valu_roles.hip), so
+            1 / (1 + share) bounds such a kernel below the 417 TFLOP/s ceiling before any LDS / barrier stall; beside the
+            32x32x16 form (K1 since round 6) about four vector instructions per MFMA do (tools/microbench/mfma32_valu.hip)."""
+            src = {"win_attn3d": ("r06_k1_pmc.json", lambda d: d["counters"]["k1s0_stream_x10"]),
                    "mlp_split": ("r04_k23enc_counters.json", lambda d: d["k23enc"]),
                    "xs_linear": ("r04_k24_counters.json", lambda d: d["counters"]["k24qkv2"])}.get(fam)
             if src is None:
@@ -714,8 +715,9 @@ def main():
             try:
                 with open(os.path.join(ROOT, "profiles", src[0])) as fh:
                     c = src[1](json.load(fh))
+                mfma_clk = 33.4 if fam == "win_attn3d" else 16.7        # K1 (round 6) issues v_mfma_f32_32x32x16_bf16: twice the cycles each
                 return {"valu_cycles_per_mfma_cycle": round(2.0 * c["SQ_INSTS_VALU"]["mean_per_launch"]
-                                                            / (16.7 * c["SQ_INSTS_MFMA"]["mean_per_launch"]), 3),
+                                                            / (mfma_clk * c["SQ_INSTS_MFMA"]["mean_per_launch"]), 3),
                         "source": "profiles/" + src[0],
                         "note": "matrix-pipe and vector-ALU time add on a gfx950 SIMD (DESIGN.md section 3, "
                                 "tools/microbench/mfma_valu_roles.hip): 1 / (1 + this) bounds frac_of_ceiling"}
@@ -786,10 +788,14 @@ def main():
             # K2's binding unit is not HBM: the CU's vector-memory (texture) path, 64 B per clock -- measured busy share from
             # the committed counter passes
             try:
-                with open(os.path.join(ROOT, "profiles", "r05_k2_counters.json")) as fh:
-                    k2 = json.load(fh)["k2_fused_720p" if H >= 720 else "k2_fused_360p"]["derived"]
+                if H >= 720:
+                    k2_file, k2_key = "r05_k2_counters.json", "k2_fused_720p"
+                else:                       # round 6: counters at the frame count of a launch group (80 frames) and of one clip
+                    k2_file, k2_key = "r06_k2_counters.json", "k2_fused_360p_x10" if per > 1 else "k2_fused_360p_x1"
+                with open(os.path.join(ROOT, "profiles", k2_file)) as fh:
+                    k2 = json.load(fh)[k2_key]["derived"]
                 other["msda_fwd"]["binding_unit"] = ("vector-memory (texture) path of the CUs, 64 B/clk each: busy "
-                                                     f"{k2['ta_busy_share']:.2f} of the launch (profiles/r05_k2_counters.json)")
+                                                     f"{k2['ta_busy_share']:.2f} of the launch (profiles/{k2_file})")
                 other["msda_fwd"]["ta_busy_share"] = round(k2["ta_busy_share"], 3)
             except (OSError, KeyError, ValueError):
                 pass

@@ -128,7 +128,10 @@ int soc_msda_fused_fwd_f32(const float* value, const uint8_t* value_pad_mask, co
  * win_d*win_h*win_w <= 400.  Shift mask value is -100 (:328), not -inf.
  * split: arithmetic of THIS launch (full 8x7x7 windows only, ignored otherwise): != 0 = scores and P.V on the bf16 matrix
  * cores with every f32 operand split exactly into three bf16 terms (six products, f32 accumulation: f32-level error, see
- * K20 below); 0 = the f32-input MFMA form.  Same results to f32 rounding.
+ * K20 below); 0 = the f32-input MFMA form.  Same results to f32 rounding.  Since round 6 the split arithmetic has two kernels:
+ * 1 (and any value other than 0 and 2) = the streaming form (32-query tiles, key chunks of 32, softmax between the MFMAs; the
+ * row max is subtracted only for tiles whose row sum says it is needed), 2 = round 3's form (a 16-query tile's whole score
+ * block in registers), kept for A/B measurements.  Same entry point, same results to f32 rounding.
  */
 int soc_win_attn3d_f32(const float* qkv, const float* qkv_bias, const float* bias_table,
                        float* out, int B, int D, int H, int W, int C, int n_heads, int win_d,

@@ -149,6 +149,49 @@ def test_window_attention_large_scores(ops, gain):
     assert d < 2e-5 * gain * max(scale, 1.0), (d, scale)
 
 
+@pytest.mark.parametrize("where", ["shared_tile", "one_tile", "keys", "straddle"])
+def test_window_attention_streaming_form_takes_its_max_path_per_tile(ops, where):
+    """K1's streaming form (round 6) exponentiates scores without a max and redoes a TILE with the two-pass form when its row sums
+    say that was not legal (outside [2^-60, 2^60]).  Large scores confined to (a) the 8 queries of the shared last tile (slots
+    384..391 = the window's last spatial position: only the shared tile's redo runs), (b) one 32-query tile, (c) a few KEYS (every
+    tile overflows), (d) magnitudes that straddle the threshold (some rows legal, some not, inside one tile) -- all against the
+    oracle, whose softmax subtracts the max everywhere."""
+    g = torch.Generator().manual_seed(41)
+    nH, D, H, W = 3, 8, 14, 21
+    C = nH * 32
+    qkv = torch.randn(1, D, H, W, 3 * C, generator=g)
+    bias = torch.randn(3 * C, generator=g) * 0.5
+    table = torch.randn(15 * 13 * 13, nH, generator=g) * 0.5
+    if where == "shared_tile":
+        qkv[:, :, 6::7, 6::7, :C] *= 40.0                 # q of the tokens at (dy, dx) = (6, 6) of every window: slots 384..391
+    elif where == "one_tile":
+        qkv[:, :4, 0::7, 0::7, :C] *= 40.0                # a few queries of tile 0
+    elif where == "keys":
+        qkv[:, 2, 3::7, 2::7, C:2 * C] *= 60.0            # k of one token per window
+    else:
+        qkv[..., :C] *= torch.linspace(1.0, 14.0, W).view(1, 1, 1, W, 1)      # |score| from a few to ~100 across a window row
+    for shift in ((0, 0, 0), (4, 3, 3)):
+        ref = O.window_attention_core(qkv, bias, table, nH, O.WINDOW, shift)
+        out = ops.window_attention3d(dev(qkv), dev(bias), dev(table), nH, O.WINDOW, shift)
+        # one f32 ulp of a score of magnitude s is 6e-8 s, which the exponential turns into a relative error of that size
+        assert maxdiff(out, ref) < 4e-4 * max(1.0, float(ref.abs().max())), (where, shift, maxdiff(out, ref))
+        assert bool(torch.isfinite(out).all())
+
+
+def test_window_attention_streaming_and_round3_forms_agree(ops, monkeypatch):
+    """split_arith = 1 (streaming, round 6) and 2 (round 3's split form, SOC_K1_FORM=r3) are the same arithmetic in another order:
+    stage-2 geometry (whole pairs + pairs split over query tiles), shifted, to f32 rounding."""
+    g = torch.Generator().manual_seed(9)
+    qkv = torch.randn(1, 8, 23, 40, 3 * 384, generator=g)
+    bias = torch.randn(3 * 384, generator=g) * 0.5
+    table = torch.randn(2535, 12, generator=g) * 0.5
+    monkeypatch.delenv("SOC_K1_FORM", raising=False)
+    a = ops.window_attention3d(dev(qkv), dev(bias), dev(table), 12, O.WINDOW, (4, 3, 3))
+    monkeypatch.setenv("SOC_K1_FORM", "r3")
+    b = ops.window_attention3d(dev(qkv), dev(bias), dev(table), 12, O.WINDOW, (4, 3, 3))
+    assert maxdiff(a, b.cpu()) < 3e-6 * max(1.0, float(b.abs().max()))
+
+
 def test_window_attention_batch_gt1(ops):
     d, scale = _win_case(ops, 2, 8, 9, 15, 2, (4, 3, 3), seed=5)
     assert d < 2e-5 * max(scale, 1.0)

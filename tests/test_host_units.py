@@ -190,7 +190,14 @@ def test_clip_inferencer_group_bookkeeping_with_a_stub_pipeline(monkeypatch):
             self.record = None
 
         def stage_inputs(self, clip, ids, attn=None, slot=0):
-            self.slots[slot] = float(clip.view(-1)[0])
+            self.slots[slot] = float(clip.reshape(-1)[0])
+            if self.CLIPS > 1:           # the static inputs a group graph keeps: the remainder policy reads the staged clips back from them
+                if getattr(self, "clip", None) is None or self.clip.shape[2:] != clip.shape[1:]:
+                    self.clip = torch.zeros(clip.shape[0], self.CLIPS, *clip.shape[1:])
+                    self.ids = torch.ones(self.CLIPS, ids.numel(), dtype=torch.long)
+                    self.attn = torch.ones(self.CLIPS, ids.numel(), dtype=torch.long)
+                self.clip[:, slot] = clip
+                self.ids[slot] = ids.view(-1)
 
         def replay(self):
             prev, self.in_head = self.in_head, list(self.slots)
@@ -221,6 +228,8 @@ def test_clip_inferencer_group_bookkeeping_with_a_stub_pipeline(monkeypatch):
             return eng._pipes[key]
 
         monkeypatch.setattr(eng, "_pipeline", pipeline)
+        singles = {}
+        monkeypatch.setattr(eng, "_single_pipeline", lambda key, singles=singles: singles.setdefault(key, StubPipe(1)))
         monkeypatch.setattr(eng, "_unpack", lambda rec, key, tag, osz: {"tag": tag, "osz": osz, "clip": float(rec.view(-1)[0]), "key": key})
         got = []
         # 7 clips of one geometry, then 3 of another (drains a part-filled group), then the end of the stream
@@ -233,6 +242,13 @@ def test_clip_inferencer_group_bookkeeping_with_a_stub_pipeline(monkeypatch):
         assert all(r["tag"] == ("tag", int(r["clip"])) for r in got)
         assert all(r["osz"] == (r["key"][1] * 2, r["key"][2] * 2) for r in got)
         assert len(made) == 2 and eng.drain() == []
+        # 7 + 3 clips: full groups, then per geometry a remainder -- at least half a group: one replay with stale slots; fewer:
+        # the one-clip pipeline of that geometry
+        if group > 1:
+            rests = [7 % group, 3 % group]
+            assert eng.stats["remainder_singles"] == sum(r for r in rests if 2 * r < group), (group, eng.stats)
+            assert eng.stats["stale_slots"] == sum(group - r for r in rests if r and 2 * r >= group), (group, eng.stats)
+            assert set(singles) <= set(made)
     import pytest
     with pytest.raises(ValueError):
         infer.ClipInferencer(Model(), "cpu", group=0)

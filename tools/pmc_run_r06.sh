@@ -72,4 +72,7 @@ png)
   ;;
 esac
 done
-ls -la $P | head -60
+# only summaries travel back (gpurun merges at most 64 MiB): the raw traces / counter databases stay on the box
+find $P -mindepth 1 -maxdepth 1 -type d -exec rm -rf {} +
+du -sh $P
+ls -la $P | head -80
