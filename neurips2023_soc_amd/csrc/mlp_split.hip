@@ -52,7 +52,11 @@ struct Geo {
 
 template <int N>
 __device__ __forceinline__ void handoff() {        // my part of the next block has landed; everyone is done with this one
+#ifdef SOC_K23_NO_BARRIER          // diagnostic build only (tools/experiments/k23_time.py, K23_EXTRA_FLAGS): what the ring would cost
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");         // WITHOUT its hand-off barrier -- results are wrong (races)
+#else
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+#endif
 }
 
 // DBG (diagnostics only) bit 0: no LDS-DMA inside the block loop, bit 1: no MFMA work (stream ceiling), bit 2: no fragment

@@ -1572,11 +1572,17 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_stream_kernel(
                 s = slot_info(i, reg, cc);
                 differs |= (reg != reg0);
             }
+#if defined(SOC_K1_VAR) && (SOC_K1_VAR & 16)         // diagnostic: no K / V row loads
+            if (s >= 0) {
+                kv[it][0] = kv[it][1] = vv[it][0] = vv[it][1] = make_float4(0.01f * c, 0.02f, 0.03f * s, 0.04f);
+            } else {
+#else
             if (s >= 0) {
                 const float4* row = reinterpret_cast<const float4*>(qkv + (long)s * C3 + head * HD + 8 * c);
                 kv[it][0] = row[p.C / 4]; kv[it][1] = row[p.C / 4 + 1];
                 vv[it][0] = row[p.C / 2]; vv[it][1] = row[p.C / 2 + 1];
             } else {
+#endif
                 const float4* kb = reinterpret_cast<const float4*>(qkv_bias + p.C + head * HD + 8 * c);
                 const float4* vb = reinterpret_cast<const float4*>(qkv_bias + 2 * p.C + head * HD + 8 * c);
                 kv[it][0] = kb[0]; kv[it][1] = kb[1];
@@ -1617,6 +1623,10 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_stream_kernel(
                 const float vf[8] = {vv[it][0].x, vv[it][0].y, vv[it][0].z, vv[it][0].w, vv[it][1].x, vv[it][1].y, vv[it][1].z, vv[it][1].w};
                 bf16x8 h0, h1, h2;
                 char* dst = Kp + i * KROWB + ((c ^ swz(i)) << 4);
+#if defined(SOC_K1_VAR) && (SOC_K1_VAR & 32)         // diagnostic: no operand split, one LDS store per item
+                *reinterpret_cast<float4*>(dst) = make_float4(kf[0] + vf[1], kf[2], vf[3], kf[4]);
+                continue;
+#endif
                 split8v(kf, h0, h1, h2);
                 *reinterpret_cast<bf16x8*>(dst) = h0;
                 *reinterpret_cast<bf16x8*>(dst + PLANEB) = h1;

@@ -12,13 +12,14 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 BUILD = os.path.join(ROOT, "tools", "experiments", "_build")
-LIB = os.path.join(BUILD, "libk23_probe.so")
+LIB = os.path.join(BUILD, "libk23_probe%s.so" % os.environ.get("K23_LIB_TAG", ""))
 CSRC = os.path.join(ROOT, "neurips2023_soc_amd", "csrc")
 
 
 def build():
     os.makedirs(BUILD, exist_ok=True)
     cmd = ["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17", "-DSOC_K23_VARIANTS",
+           *os.environ.get("K23_EXTRA_FLAGS", "").split(),
            "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-o", LIB, os.path.join(CSRC, "mlp_split.hip"),
            os.path.join(CSRC, "soc_capi.hip")]
     print(" ".join(cmd), flush=True)
@@ -117,6 +118,11 @@ def vr(ns=3, lsb=0, stag=0, pf=1, dbg=0):
 
 
 V = [0, vr(3), vr(3, stag=4), vr(2, stag=4)]
+if "--enc-only" in sys.argv:         # round 6: the encoder form with and without its hand-off barrier (K23_EXTRA_FLAGS=-DSOC_K23_NO_BARRIER)
+    case("enc", 32768, 256, 2048, "relu", False, True, [(256, 1)], [0, vr(3, dbg=13), vr(3, dbg=1), vr(3, dbg=4)])
+    case("s0", 115200, 96, 384, "gelu", True, True, [(256, 1)], [0])
+    case("s2", 7360, 384, 1536, "gelu", True, True, [None], [0])
+    sys.exit(0)
 case("enc", 32768, 256, 2048, "relu", False, True, [(256, 1)], V)
 case("s0", 115200, 96, 384, "gelu", True, True, [(256, 1)], [0, vr(3), vr(3, stag=4), vr(4, stag=4)])
 case("s1", 28800, 192, 768, "gelu", True, True, [None], V)
