@@ -556,7 +556,10 @@ def main():
         distinct = float((all_timed_records[1:min(a.steps, n_pool)] - all_timed_records[0]).abs().amax(1).min()) if min(a.steps, n_pool) > 1 else None
         slot_check = {"records": int(a.steps), "against": how, "max_abs_diff": float(d_each.max()), "selected_query_equal": q_same,
                       "distinct_clips": min(a.steps, n_pool), "min_abs_diff_between_different_clips": distinct}
-        assert q_same and slot_check["max_abs_diff"] < 1e-4, slot_check
+        # a mixed-up slot is a difference of order 1 (different clips); the run-to-run noise of a record is 5-6e-5.  The hard failure is
+        # at the north_star tolerance -- a finished run must not lose its line to a box with a little more noise -- and the committed
+        # line is held to 1e-4 by tests/test_bench_contract.py
+        assert q_same and slot_check["max_abs_diff"] < 1e-3, slot_check
         assert distinct is None or distinct > 1e-2, slot_check      # the pool's clips really differ: a swapped slot would show
 
     # The dominant kernel families: replay the launches of ONE forward back to back between one HIP-event pair on the launch
