@@ -57,6 +57,20 @@ def ws_plain_ok(x: torch.Tensor, weight: torch.Tensor) -> bool:
         and x.numel() // K >= 16384 and hot_ops.ws_linear_supported(x, weight, False))
 
 
+def w256_tall_ok(x: torch.Tensor, weight: torch.Tensor) -> bool:
+    """256 x 256 layers at the row counts of a launch group (the encoder's value_proj / output_proj + shortcut over 385 600 rows, the
+    fusion blocks' projections over 288 000): K20's tiles edge out K13b's four column ranges and K24's streamed weights there
+    (round 6, tools/experiments/w256_probe.py: 335 / 378 / 346 us at 385 600 rows, 242 / 265 / 259 at 288 000; K13b keeps 73 600)."""
+    return (x.is_cuda and x.dtype == torch.float32 and x.shape[-1] == 256 and tuple(weight.shape) == (256, 256)
+            and x.numel() // 256 >= 200_000 and hot_ops.split_enabled() and not _SPLIT_OFF_SITES()
+            and hot_ops.linear_split_supported(x, weight))
+
+
+def _SPLIT_OFF_SITES() -> bool:
+    from .matmul_mode import _SPLIT_OFF
+    return "plain" in _SPLIT_OFF or "w256" in _SPLIT_OFF
+
+
 def _split_ok(x: torch.Tensor, weight: torch.Tensor, fused_passes: int, site: str = "plain") -> bool:
     K = x.shape[-1]
     return (x.is_cuda and x.dtype == torch.float32 and hot_ops.linear_split_supported(x, weight)
@@ -80,6 +94,8 @@ def route_linear(x, weight, bias=None, add=None, relu: bool = False, mul=None, r
     BASELINE configurations and pins the answers, so that a silent fall-back to the library fails a test)."""
     if is_small(x):
         return "k7"
+    if add is None and mul is None and w256_tall_ok(x, weight):
+        return "k20"
     if add is None and mul is None and xs_ok(x, weight):
         return "k24"
     if add is None and mul is None and ws_plain_ok(x, weight):
