@@ -67,9 +67,10 @@ def test_msda_model_capture(ops, golden):
     assert maxdiff(out, g["msda_dec_out"]) < 2e-5
 
 
-@pytest.mark.parametrize("N,Lq,D", [(8, 4820, 32), (3, 77, 32), (2, 5, 16), (1, 0, 32)])
+@pytest.mark.parametrize("N,Lq,D", [(8, 4820, 32), (3, 77, 32), (2, 5, 16), (1, 0, 32), (16, 77, 32), (24, 301, 32), (12, 77, 32)])
 def test_msda_vs_oracle_seeded(ops, N, Lq, D):
-    """Config-sized encoder call (N=8, Lq=S=4820) plus ragged / empty shapes."""
+    """Config-sized encoder call (N=8, Lq=S=4820) plus ragged / empty shapes; N = 16 / 24 (multiples of 8: the frames of a launch
+    group -- an XCD walks its frames one after the other, round 6's block -> (frame, chunk) map) and N = 12 (the old map)."""
     g = torch.Generator().manual_seed(N * 1000 + Lq)
     shapes = torch.tensor([[45, 80], [23, 40], [12, 20], [6, 10]]) if Lq == 4820 else torch.tensor([[9, 7], [5, 4], [3, 2], [1, 1]])
     lsi = torch.cat((shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]))
@@ -337,7 +338,8 @@ def test_add_layernorm_rejects_unsupported(ops):
 
 
 # ------------------------------------------------------------------ K2 fused form
-@pytest.mark.parametrize("N,Lq,rd,padding", [(8, 4820, 2, False), (3, 77, 2, True), (2, 20, 4, True), (2, 20, 4, False)])
+@pytest.mark.parametrize("N,Lq,rd,padding", [(8, 4820, 2, False), (3, 77, 2, True), (2, 20, 4, True), (2, 20, 4, False),
+                                             (16, 77, 2, True), (24, 301, 2, False), (12, 77, 4, False)])      # N = 16 / 24: a launch group's frames (round 6 map)
 def test_msda_fused_vs_oracle(ops, N, Lq, rd, padding):
     g = torch.Generator().manual_seed(N * 100 + Lq + rd)
     shapes = torch.tensor([[45, 80], [23, 40], [12, 20], [6, 10]]) if Lq == 4820 else torch.tensor([[9, 7], [5, 4], [3, 2], [1, 1]])
