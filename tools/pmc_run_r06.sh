@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-6 evidence run on the MI355X box (gpurun): everything lands under gpurun_out/r06/, the summaries are then copied
 # into profiles/.  Counters are collected in their own passes (--pmc with --kernel-trace only), the program directly after
-# `--`.  Parts: trace | traffic | counters | k2 | png (default: all).
+# `--`.  Parts: trace | traffic | counters | k2 | png | swinb (default: all but swinb).
 set -x
 cd "$GRAFT_REPO_ROOT"
 export TMPDIR=/tmp
@@ -63,6 +63,16 @@ k2)
     rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $P/k2_x${clips}_write -- python3 tools/k2_probe.py 12 360p 1.0 $clips > $P/k2_x${clips}_write.log 2>&1
     rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TA_TA_BUSY_sum GRBM_GUI_ACTIVE -d $P/k2_x${clips}_tcc -- python3 tools/k2_probe.py 12 360p 1.0 $clips > $P/k2_x${clips}_tcc.log 2>&1
     python3 tools/pmc_agg.py --kernels "k2_fused_x${clips}=msda_fused_tiles_kernel" -- $P/k2_x${clips}_fetch $P/k2_x${clips}_write $P/k2_x${clips}_tcc > $P/k2_x${clips}_counters.json
+  done
+  ;;
+swinb)
+  # ---- (f) BASELINE configs 4 / 5: Video-Swin-B at 360p (groups of ten) and 720p (pairs) -- kernel stats and forward breakdown
+  #      (the bench lines with cpu_baseline + golden parity: profiles/bench_r06_swinb_*.json)
+  for geo in 360p 720p; do
+    if [ $geo = 720p ]; then G="--height 720 --width 1280 --steps 6"; PERG=2; else G="--steps 40"; PERG=$GROUP; fi
+    rocprofv3 --kernel-trace --stats --output-format csv -d $P/trace_swinb_$geo -- python3 bench.py --backbone video-swin-b $G --warmup 2 --no-cpu-baseline --no-stream --no-f32-pass --no-single-pass --detail $P/trace_swinb_${geo}_detail.json > $P/trace_swinb_$geo.json 2> $P/trace_swinb_$geo.err
+    cp $(ls $P/trace_swinb_$geo/*/*kernel_stats.csv | head -1) $P/r06_swinb_${geo}_kernel_stats.csv
+    SOC_TRACE_CLIPS_PER_GROUP=$PERG python3 tools/analyze_trace.py $(ls $P/trace_swinb_$geo/*/*kernel_trace.csv | head -1) --top 25 > $P/r06_swinb_${geo}_forward_breakdown.txt
   done
   ;;
 png)
