@@ -1461,6 +1461,9 @@ __device__ __forceinline__ bf16x8 b128_read_at(const unsigned base, const int of
     return *(const __attribute__((address_space(3))) bf16x8*)((lds_char*)(uintptr_t)base + off);
 }
 
+#ifndef SOC_K1_PF_DIST
+#define SOC_K1_PF_DIST 256                                    // workgroups ahead whose K / V rows are prefetched (same XCD, one round later)
+#endif
 template <bool SHIFTED>
 __global__ __launch_bounds__(THREADS, 2) void win_attn3d_stream_kernel(
     const float* __restrict__ qkv, const float* __restrict__ qkv_bias,
@@ -1491,6 +1494,13 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_stream_kernel(
     const int wz = bid % p.nwd; bid /= p.nwd;
     const int b = bid;
     const int C3 = 3 * p.C;
+#ifdef SOC_K1_STAGGER                                         // diagnostic: the first round of workgroups starts spread over
+    if (blockIdx.x < 256) {                                   // 8 steps of SOC_K1_STAGGER cycles (are the K / V bursts of a round in lockstep?)
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        const unsigned long long wait = (unsigned long long)((blockIdx.x >> 3) & 7) * SOC_K1_STAGGER;
+        while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(8);
+    }
+#endif
     STAMP_RT(30);
     STAMP_HWID(29);
     STAMP(0);
@@ -1564,14 +1574,26 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_stream_kernel(
         constexpr int PASSES = (ITEMS + THREADS - 1) / THREADS;
         float4 kv[PASSES][2], vv[PASSES][2];
         const int c = tid & 3;
-#pragma unroll
-        for (int it = 0; it < PASSES; ++it) {
-            const int i = (tid + THREADS * it) >> 2;
-            int s = -2, reg = 0, cc = 0;
+        // The four lanes of a quad stage the same slot in every pass (8 dims each): lane c derives the token of the quad's slot of
+        // pass c, once, and the quad reads it from that lane in pass c (one DPP move) -- every lane deriving all four was a third
+        // of this phase's vector instructions.
+        static_assert(PASSES == 4, "one pass per lane of a quad");
+        int s_mine = -2;
+        {
+            const int i = (tid >> 2) + (THREADS / 4) * c;
+            int reg = 0, cc = 0;
             if (i < FN) {
-                s = slot_info(i, reg, cc);
+                s_mine = slot_info(i, reg, cc);
                 differs |= (reg != reg0);
             }
+        }
+        const int s_pass[PASSES] = {__builtin_amdgcn_update_dpp(0, s_mine, 0x00, 0xf, 0xf, false),      // quad_perm: lane 0 of the quad
+                                    __builtin_amdgcn_update_dpp(0, s_mine, 0x55, 0xf, 0xf, false),
+                                    __builtin_amdgcn_update_dpp(0, s_mine, 0xaa, 0xf, 0xf, false),
+                                    __builtin_amdgcn_update_dpp(0, s_mine, 0xff, 0xf, 0xf, false)};
+#pragma unroll
+        for (int it = 0; it < PASSES; ++it) {
+            const int s = s_pass[it];
 #if defined(SOC_K1_VAR) && (SOC_K1_VAR & 16)         // diagnostic: no K / V row loads
             if (s >= 0) {
                 kv[it][0] = kv[it][1] = vv[it][0] = vv[it][1] = make_float4(0.01f * c, 0.02f, 0.03f * s, 0.04f);
@@ -1592,13 +1614,17 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_stream_kernel(
         constexpr int TPASS = (TBL + THREADS - 1) / THREADS;
         float tv[TPASS];
 #pragma unroll
+        // The bias column of this head, walked in the TABLE's order (entry r = zz * 169 + yx at table[r * nH + head]: the 64 lanes of
+        // a load touch 64 * nH floats, 6 cache lines at nH = 3, instead of one line each) and transposed by the LDS store below
+        // (stride 15 words: no bank conflicts).  Measured against the split kernel's walk in the LDS layout's order, same box:
+        // 1 151 -> 1 148 / 1 202 -> 1 198 us at ten clips per launch -- the gather's cost is its five load instructions in the
+        // queue behind the K / V rows (a build without it: -5 %), not the lines it touches.
         for (int it = 0; it < TPASS; ++it) {
-            const int i = it * THREADS + tid;
-            const int yx = i / 15, zz = i - yx * 15;
+            const int r = it * THREADS + tid;
 #if defined(SOC_K1_VAR) && (SOC_K1_VAR & 8)          // diagnostic: no bias-table gather
             tv[it] = 0.f;
 #else
-            tv[it] = i < TBL ? table[(long)(zz * 169 + yx) * p.nH + head] : 0.f;
+            tv[it] = r < TBL ? table[(long)r * p.nH + head] : 0.f;
 #endif
         }
         const int wave_differs = __any(differs);
@@ -1639,9 +1665,9 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_stream_kernel(
         }
 #pragma unroll
         for (int it = 0; it < TPASS; ++it) {
-            const int i = it * THREADS + tid;
-            const int yx = i / 15, zz = i - yx * 15;
-            if (i < TBL) Tb[yx * 15 + 14 - zz] = tv[it] * LOG2E;
+            const int r = it * THREADS + tid;
+            const int zz = r / 169, yx = r - zz * 169;
+            if (r < TBL) Tb[yx * 15 + 14 - zz] = tv[it] * LOG2E;
         }
     }
     STAMP(2);
@@ -1656,6 +1682,41 @@ __global__ __launch_bounds__(THREADS, 2) void win_attn3d_stream_kernel(
     STAMP(3);
     int stamp_slot = 4;
     (void)stamp_slot;
+
+#ifdef SOC_K1_PREFETCH                                          // diagnostic, measured a LOSS (1 148 -> 1 186 us at ten clips, stage 0)
+    // ---- the K / V rows of the workgroup that follows this one on this XCD (workgroup b runs on XCD b % 8: b + 256 is the one a
+    //      round later) are pulled into the XCD's L2 while this workgroup computes: staging is bound by the latency of its 784 row
+    //      reads (12.5 k cycles of a 68 k-cycle workgroup at launch-group sizes, where qkv no longer sits in the MALL), not by any
+    //      bandwidth.  One dword per 128-B row through the LDS-DMA path (no destination register to keep alive), into a dummy
+    //      LDS word per lane that nothing reads.
+    {
+        __shared__ int pf_sink[64];
+        int nb = (int)blockIdx.x + SOC_K1_PF_DIST;
+        if (nb < (int)gridDim.x && tid < FN) {
+            if (nb >= p.n_main) nb = p.n_main + (nb - p.n_main) / p.qsplit;
+            const int head2 = nb % p.nH; nb /= p.nH;
+            const int wx2 = nb % p.nww; nb /= p.nww;
+            const int wy2 = nb % p.nwh; nb /= p.nwh;
+            const int wz2 = nb % p.nwd; nb /= p.nwd;
+            const int col = tid >> 3, dz = tid & 7;
+            const int dy = (col * 37) >> 8, dx = col - dy * 7;
+            int z = wz2 * 8 + dz + p.sd; if (z >= p.Dp) z -= p.Dp;
+            int y = wy2 * 7 + dy + p.sh; if (y >= p.Hp) y -= p.Hp;
+            int x = wx2 * 7 + dx + p.sw; if (x >= p.Wp) x -= p.Wp;
+            if (z < p.D && y < p.H && x < p.W) {
+                const float* row = qkv + (long)(((nb * p.D + z) * p.H + y) * p.W + x) * C3 + head2 * HD;
+                // inline asm, not __builtin_amdgcn_global_load_lds: hipcc would put s_waitcnt vmcnt(0) in front of the first
+                // ds_read_b64_tr_b16 that follows (an LDS access it cannot tell from the sink) -- a stall of one HBM latency per
+                // workgroup.  Untracked, the two loads only make later vmcnt waits conservative (returns are in order).
+                const unsigned sink = (unsigned)(uintptr_t)(__attribute__((address_space(3))) int*)pf_sink;
+                unsigned m0_saved;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\t"
+                             "global_load_lds_dword %2, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(m0_saved) : "v"(row + p.C), "v"(row + 2 * p.C), "s"(sink));
+            }
+        }
+    }
+#endif
 
     const unsigned tbase = (unsigned)(uintptr_t)(lds_cfloat*)Tb;
     const unsigned kaddr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)Kp;
@@ -2184,15 +2245,16 @@ int launch_split(const float* qkv, const float* qkv_bias, const float* table, fl
 
 int launch_stream(const float* qkv, const float* qkv_bias, const float* table, float* out,
                   const WinParams& p, long blocks, hipStream_t st) {
-    const size_t lds = SPLIT_LDS_BYTES;
+    const size_t lds = SPLIT_LDS_BYTES;                        // + 256 B static (the prefetch sink)
+    static_assert(SPLIT_LDS_BYTES + 256 <= 160 * 1024, "LDS");
     static std::atomic<bool> attr_set[SOC_MAX_DEVICES];
     const int dev = soc_current_device();
     if (dev < 0) return SOC_ELAUNCH;
     if (!attr_set[dev].load(std::memory_order_acquire)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(win_attn3d_stream_kernel<false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(win_attn3d_stream_kernel<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess)
             return SOC_ELAUNCH;
         attr_set[dev].store(true, std::memory_order_release);
     }

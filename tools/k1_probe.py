@@ -15,22 +15,23 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 GEO = [(90, 160, 3), (45, 80, 6), (23, 40, 12), (12, 20, 24)]      # Swin-T, T=8, 360x640: (H, W, heads) per stage
-FLOP = lambda H, W, nH: 4.0 * 392 * 392 * 32 * nH * (-(-H // 7)) * (-(-W // 7))   # noqa: E731
+CLIPS = int(os.environ.get("K1_CLIPS", "1"))                       # clips per launch (10 = the launch group of the bench)
+FLOP = lambda H, W, nH: CLIPS * 4.0 * 392 * 392 * 32 * nH * (-(-H // 7)) * (-(-W // 7))   # noqa: E731
 
 
 def inputs(st):
     H, W, nH = GEO[st]
     Cc = nH * 32
     g = torch.Generator().manual_seed(st)
-    return (torch.randn(1, 8, H, W, 3 * Cc, generator=g).cuda(), torch.randn(3 * Cc, generator=g).cuda(),
-            (torch.randn(2535, nH, generator=g) * 0.2).cuda(), torch.empty(1, 8, H, W, Cc).cuda())
+    return (torch.randn(CLIPS, 8, H, W, 3 * Cc, generator=g).cuda(), torch.randn(3 * Cc, generator=g).cuda(),
+            (torch.randn(2535, nH, generator=g) * 0.2).cuda(), torch.empty(CLIPS, 8, H, W, Cc).cuda())
 
 
 def build(flags, tag):
     so = f"/tmp/libk1_{tag}.so"
     subprocess.run(["hipcc", "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17", *flags,
                     "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "neurips2023_soc_amd/csrc"),
-                    "-o", so, os.path.join(ROOT, "neurips2023_soc_amd/csrc/win_attn3d.hip"),
+                    "-o", so, os.path.join(ROOT, "neurips2023_soc_amd/csrc", os.environ.get("K1_SRC", "win_attn3d.hip")),
                     os.path.join(ROOT, "neurips2023_soc_amd/csrc/soc_capi.hip")], check=True)
     return C.CDLL(so)
 
@@ -39,7 +40,7 @@ def call(lib, t, st, shift):
     H, W, nH = GEO[st]
     qkv, bias, table, out = t
     args = [C.c_void_p(x.data_ptr()) for x in (qkv, bias, table, out)] + [C.c_int(v) for v in
-            (1, 8, H, W, nH * 32, nH, 8, 7, 7, *shift, 8, 7, 7, int(os.environ.get('K1_SPLIT', '1')))] + [C.c_void_p(torch.cuda.current_stream().cuda_stream)]
+            (CLIPS, 8, H, W, nH * 32, nH, 8, 7, 7, *shift, 8, 7, 7, int(os.environ.get('K1_SPLIT', '1')))] + [C.c_void_p(torch.cuda.current_stream().cuda_stream)]
     rc = lib.soc_win_attn3d_f32(*args)
     assert rc == 0, rc
 
@@ -67,7 +68,7 @@ def time_lib(lib, stages, reps=200):
 
 def stamps(stages, flags):
     lib = build(["-DSOC_K1_STAMPS", *flags], "stamps")
-    nblk = 8192
+    nblk = 8192 if CLIPS == 1 else 16384
     dbg = torch.zeros(nblk * 8 * 32, dtype=torch.int64).cuda()
     lib.soc_debug_set_buffer(C.c_void_p(dbg.data_ptr()))
     for st in stages:
